@@ -1,0 +1,237 @@
+/* xggm.h -- C ABI of the MI355X-native X-GGM training-step hot path (libxggm_hip.so).
+ *
+ * The reference (jingjing12110/X-GGM) is pure PyTorch and has no native interface; this
+ * header is the boundary SURVEY.md section 8(b) specifies: one extern "C" entry point per
+ * fused op and direction.  Each declaration cites the reference call site it replaces
+ * (paths relative to /root/reference).
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer unless said otherwise; tensors are row-major and
+ *    contiguous except where a stride argument exists.  The caller owns all memory,
+ *    including workspaces; nothing here allocates, frees or synchronises -- work is only
+ *    enqueued on `stream` (graph-capture safe).
+ *  - `_f32` / `_bf16` in a symbol name is the STORAGE type "T" of activations and of the
+ *    GEMM operands.  Arithmetic is fp32 (bf16 MFMA accumulates in fp32).  Parameters that
+ *    are vectors (biases, LayerNorm gains), parameter gradients, adjacency-shaped tensors
+ *    [B,N,N], losses and optimiser state are always fp32.
+ *  - Return value: 0 = ok; non-zero = error, message via xggm_last_error() (thread-local).
+ *    Reentrant and thread-safe: called from the host thread in forward and from the
+ *    autograd thread in backward.
+ *  - Randomness: `rng` points to two device uint64 {seed, offset}; dropout masks and
+ *    Gaussian draws are pure functions of (seed, offset, stream id `sid`, element index), so
+ *    backward regenerates the forward mask.  xggm_rng_advance() bumps the offset once per
+ *    pass.  p == 0 (or a supplied `randn`) ignores `rng`.
+ */
+#ifndef XGGM_H
+#define XGGM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* xggm_stream_t; /* == hipStream_t */
+
+#define XGGM_VERSION 100
+
+/* activation codes of xggm_gemm_* */
+#define XGGM_ACT_NONE 0
+#define XGGM_ACT_GELU 1      /* erf-GELU, src/lxrt/modeling.py:116-124 */
+#define XGGM_ACT_SIGMOID 2   /* encoder_adj, src/vqa/vqacpv2_model.py:91-94 */
+#define XGGM_ACT_TANH 3      /* BertPooler, src/lxrt/modeling.py:614-620 */
+#define XGGM_ACT_GELU_GRAD 4 /* C = acc * gelu'(aux): backward of BertIntermediate fused into dgrad */
+
+/* matrix modes of xggm_aggregate_* */
+#define XGGM_AGG_PLAIN 0
+#define XGGM_AGG_TRANSPOSE 1
+#define XGGM_AGG_SYMMETRIZE 2
+
+int xggm_version(void);
+const char* xggm_last_error(void);
+
+/* ---- dense products --------------------------------------------------------------------
+ * C[z][m][n] = epilogue( alpha * sum_k A(z,m,k) * B(z,k,n) ),
+ *   A(z,m,k) = A[z*a_bs + m*a_rs + k*a_ks],  B(z,k,n) = B[z*b_bs + n*b_ns + k*b_ks],
+ *   C at C[z*c_bs + m*ldc + n].
+ * epilogue: v = alpha*acc + bias[n]; preact (if given) <- v; v = act(v) (GELU_GRAD: v *
+ * gelu'(aux)); v += residual; C = accumulate ? C + v : v; C is T, or float when c_f32.
+ * Replaces nn.Linear forward/backward (src/lxrt/modeling.py:345-347, 385, 429, 442, 617;
+ * src/module/gcn.py:28; src/vqa/vqacpv2_model.py:63-105) and torch.bmm(x, x^T)
+ * (src/module/graph_generative_modeling.py:225). */
+int xggm_gemm_f32(const void* A, const void* B, void* C, int M, int N, int K, int64_t a_rs, int64_t a_ks, int64_t b_ns,
+                  int64_t b_ks, int64_t ldc, int batch, int64_t a_bs, int64_t b_bs, int64_t c_bs, const float* bias,
+                  const void* residual, void* preact, const void* aux, int act, int c_f32, int accumulate, float alpha,
+                  xggm_stream_t stream);
+int xggm_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, int64_t a_rs, int64_t a_ks, int64_t b_ns,
+                   int64_t b_ks, int64_t ldc, int batch, int64_t a_bs, int64_t b_bs, int64_t c_bs, const float* bias,
+                   const void* residual, void* preact, const void* aux, int act, int c_f32, int accumulate, float alpha,
+                   xggm_stream_t stream);
+/* out[n] += sum_m x[m*ld + n]  (bias gradients; `out` must hold the running value) */
+int xggm_colsum_f32(const void* x, float* out, int M, int N, int64_t ld, xggm_stream_t stream);
+int xggm_colsum_bf16(const void* x, float* out, int M, int N, int64_t ld, xggm_stream_t stream);
+
+/* ---- attention core: src/lxrt/modeling.py:355-373 (BertAttention.forward after the
+ * projections).  q/k/v/out rows of sample b start at row b*S of a matrix with the given row
+ * stride (so fused-QKV buffers are addressed in place); head h occupies columns
+ * [64h, 64h+64).  mask: additive [B,Sk] fp32 or NULL.  Sq, Sk <= 64, head_dim == 64. */
+int xggm_attn_fwd_f32(const void* q, const void* k, const void* v, const float* mask, void* out, int B, int heads, int Sq,
+                      int Sk, int head_dim, int64_t q_rs, int64_t k_rs, int64_t v_rs, int64_t o_rs, float scale, float p,
+                      const uint64_t* rng, uint32_t sid, xggm_stream_t stream);
+int xggm_attn_fwd_bf16(const void* q, const void* k, const void* v, const float* mask, void* out, int B, int heads, int Sq,
+                       int Sk, int head_dim, int64_t q_rs, int64_t k_rs, int64_t v_rs, int64_t o_rs, float scale, float p,
+                       const uint64_t* rng, uint32_t sid, xggm_stream_t stream);
+int xggm_attn_bwd_f32(const void* q, const void* k, const void* v, const float* mask, const void* d_out, void* dq, void* dk,
+                      void* dv, int B, int heads, int Sq, int Sk, int head_dim, int64_t q_rs, int64_t k_rs, int64_t v_rs,
+                      int64_t o_rs, int64_t dq_rs, int64_t dk_rs, int64_t dv_rs, float scale, float p, const uint64_t* rng,
+                      uint32_t sid, xggm_stream_t stream);
+int xggm_attn_bwd_bf16(const void* q, const void* k, const void* v, const float* mask, const void* d_out, void* dq,
+                       void* dk, void* dv, int B, int heads, int Sq, int Sk, int head_dim, int64_t q_rs, int64_t k_rs,
+                       int64_t v_rs, int64_t o_rs, int64_t dq_rs, int64_t dk_rs, int64_t dv_rs, float scale, float p,
+                       const uint64_t* rng, uint32_t sid, xggm_stream_t stream);
+
+/* ---- row kernels -----------------------------------------------------------------------
+ * out = [out +] out_scale * drop_post( LN( drop_pre(in + bias) + residual ; gamma, beta, eps) )
+ * in/residual/out/z_out: T [M,H]; z_out (may alias `in`) receives the LN input, stats [M,2]
+ * = {mean, rstd}.  BertAttOutput/BertOutput: src/lxrt/modeling.py:384-388, 441-445; GCNConv
+ * LN: src/module/gcn.py:29; GNN read-outs with dropout(.5) and sum: src/module/gcn.py:70-77;
+ * head tails: src/vqa/vqacpv2_model.py:63-105.  H % 4 == 0, H <= 2048. */
+int xggm_ln_fwd_f32(const void* in, const float* bias, const void* residual, const float* gamma, const float* beta,
+                    void* out, void* z_out, float* stats, int M, int H, float eps, float p_pre, float p_post,
+                    const uint64_t* rng, uint32_t sid_pre, uint32_t sid_post, int accumulate, float out_scale,
+                    xggm_stream_t stream);
+int xggm_ln_fwd_bf16(const void* in, const float* bias, const void* residual, const float* gamma, const float* beta,
+                     void* out, void* z_out, float* stats, int M, int H, float eps, float p_pre, float p_post,
+                     const uint64_t* rng, uint32_t sid_pre, uint32_t sid_post, int accumulate, float out_scale,
+                     xggm_stream_t stream);
+/* dy = grad of `out`.  d_in: grad of `in` (NULL ok); d_res: grad of `residual` (NULL ok,
+ * accumulate_dres adds to it); dgamma/dbeta/dbias (NULL ok) are ACCUMULATED atomically. */
+int xggm_ln_bwd_f32(const void* dy, const void* z, const float* stats, const float* gamma, void* d_in, void* d_res,
+                    float* dgamma, float* dbeta, float* dbias, int M, int H, float p_pre, float p_post, const uint64_t* rng,
+                    uint32_t sid_pre, uint32_t sid_post, float out_scale, int accumulate_dres, xggm_stream_t stream);
+int xggm_ln_bwd_bf16(const void* dy, const void* z, const float* stats, const float* gamma, void* d_in, void* d_res,
+                     float* dgamma, float* dbeta, float* dbias, int M, int H, float p_pre, float p_post,
+                     const uint64_t* rng, uint32_t sid_pre, uint32_t sid_post, float out_scale, int accumulate_dres,
+                     xggm_stream_t stream);
+/* BertEmbeddings: src/lxrt/modeling.py:298-313.  ids/seg: int64 [M] (M = B*Tlen), tables T.
+ * backward scatter-adds into the fp32 table gradients; row 0 (padding_idx) gets none. */
+int xggm_embed_fwd_f32(const int64_t* ids, const int64_t* seg, const void* word, const void* pos, const void* type,
+                       const float* gamma, const float* beta, void* out, void* z_out, float* stats, int M, int Tlen, int H,
+                       float eps, float p, const uint64_t* rng, uint32_t sid, xggm_stream_t stream);
+int xggm_embed_fwd_bf16(const int64_t* ids, const int64_t* seg, const void* word, const void* pos, const void* type,
+                        const float* gamma, const float* beta, void* out, void* z_out, float* stats, int M, int Tlen, int H,
+                        float eps, float p, const uint64_t* rng, uint32_t sid, xggm_stream_t stream);
+int xggm_embed_bwd_f32(const int64_t* ids, const int64_t* seg, const void* dy, const void* z, const float* stats,
+                       const float* gamma, void* dz_ws, float* dword, float* dpos, float* dtype, float* dgamma,
+                       float* dbeta, int M, int Tlen, int H, float p, const uint64_t* rng, uint32_t sid,
+                       xggm_stream_t stream);
+int xggm_embed_bwd_bf16(const int64_t* ids, const int64_t* seg, const void* dy, const void* z, const float* stats,
+                        const float* gamma, void* dz_ws, float* dword, float* dpos, float* dtype, float* dgamma,
+                        float* dbeta, int M, int Tlen, int H, float p, const uint64_t* rng, uint32_t sid,
+                        xggm_stream_t stream);
+/* VisualFeatEncoder tail: src/lxrt/modeling.py:546-556.  u = feat @ W_f^T (T, from
+ * xggm_gemm); boxes T [M,4]; W_b fp32 [H,4].  z1 may alias u.  stats [M,4]. */
+int xggm_visn_embed_fwd_f32(const void* u, const float* bf, const void* boxes, const float* Wb, const float* bb,
+                            const float* g1, const float* b1, const float* g2, const float* b2, void* out, void* z1,
+                            void* z2, float* stats, int M, int H, float eps, float p, const uint64_t* rng, uint32_t sid,
+                            xggm_stream_t stream);
+int xggm_visn_embed_fwd_bf16(const void* u, const float* bf, const void* boxes, const float* Wb, const float* bb,
+                             const float* g1, const float* b1, const float* g2, const float* b2, void* out, void* z1,
+                             void* z2, float* stats, int M, int H, float eps, float p, const uint64_t* rng, uint32_t sid,
+                             xggm_stream_t stream);
+int xggm_visn_embed_bwd_f32(const void* dy, const void* z1, const void* z2, const float* stats, const void* boxes,
+                            const float* g1, const float* g2, void* du, float* dbf, float* dg1, float* db1, float* dWb,
+                            float* dbb, float* dg2, float* db2, int M, int H, float p, const uint64_t* rng, uint32_t sid,
+                            xggm_stream_t stream);
+int xggm_visn_embed_bwd_bf16(const void* dy, const void* z1, const void* z2, const float* stats, const void* boxes,
+                             const float* g1, const float* g2, void* du, float* dbf, float* dg1, float* db1, float* dWb,
+                             float* dbb, float* dg2, float* db2, int M, int H, float p, const uint64_t* rng, uint32_t sid,
+                             xggm_stream_t stream);
+
+/* ---- graph-generative kernels (adjacency tensors fp32 [B,N,N], N <= 64) -----------------
+ * out = [out +] self_w * x + scale * (1 + *scale_ptr) * M' @ x; x/out T [B,N,H].
+ * GCNConv aggregate src/module/gcn.py:28; GIN src/module/gin.py:32. */
+int xggm_aggregate_f32(const float* M, const void* x, void* out, int B, int N, int H, int mode, float scale,
+                       const float* scale_ptr, float self_w, int accumulate, xggm_stream_t stream);
+int xggm_aggregate_bf16(const float* M, const void* x, void* out, int B, int N, int H, int mode, float scale,
+                        const float* scale_ptr, float self_w, int accumulate, xggm_stream_t stream);
+/* *out += sum_{b,i,c} dh[b,i,c] * (M @ x)[b,i,c]   (gradient of GIN's eps) */
+int xggm_agg_dot_f32(const float* M, const void* x, const void* dh, float* out, int B, int N, int H, xggm_stream_t stream);
+int xggm_agg_dot_bf16(const float* M, const void* x, const void* dh, float* out, int B, int N, int H, xggm_stream_t stream);
+/* adjacency regeneration from S = x x^T: src/module/graph_generative_modeling.py:225-228.
+ * adj[i][j] = sigmoid(S[i][j] / max_r S[r][i]), zero diagonal; colmax/argmax [B,N] saved
+ * (argmax = first index of the column maximum, as torch.max). */
+int xggm_adj_regen_fwd(const float* S, float* adj, float* colmax, int32_t* argmax, int B, int N, xggm_stream_t stream);
+int xggm_adj_regen_bwd(const float* d_adj, const float* S, const float* adj, const float* colmax, const int32_t* argmax,
+                       float* dS, int B, int N, xggm_stream_t stream);
+/* adjacency initialisation: src/vqa/vqacpv2.py:195-202 + src/module/graph_utils.py:162-168.
+ * e fp32 [B, N(N-1)/2] (NULL = zeros); entry k goes to (i,j), the k-th element of the strict
+ * upper triangle in row-major order, and to (j,i).  Noise: sigma * randn[b,min,max] mirrored
+ * (randn fp32 [B,N,N] or NULL = Philox draw); gradlog = -noise / sigma^2 (NULL ok). */
+int xggm_adj_init_fwd(const float* e, const float* randn, float* adj, float* gradlog, int B, int N, float sigma,
+                      const uint64_t* rng, uint32_t sid, xggm_stream_t stream);
+int xggm_adj_init_bwd(const float* d_adj, float* d_e, int B, int N, xggm_stream_t stream);
+/* HOST helper: the (i,j) of entry k (bit-exactness tests of the index map) */
+int xggm_triu_index(int k, int N, int* i_out, int* j_out);
+/* add_feature_noise_v2: src/module/graph_utils.py:144-149; gradlog fp32 */
+int xggm_feature_noise_f32(const void* x, const float* randn, void* out, float* gradlog, int64_t n, float sigma,
+                           const uint64_t* rng, uint32_t sid, xggm_stream_t stream);
+int xggm_feature_noise_bf16(const void* x, const float* randn, void* out, float* gradlog, int64_t n, float sigma,
+                            const uint64_t* rng, uint32_t sid, xggm_stream_t stream);
+/* out[B,2H] = [x, tanh(mean_n nodes)]: src/vqa/vqacpv2.py:216-218 */
+int xggm_pool_concat_fwd_f32(const void* x, const void* nodes, void* out, int B, int N, int H, xggm_stream_t stream);
+int xggm_pool_concat_fwd_bf16(const void* x, const void* nodes, void* out, int B, int N, int H, xggm_stream_t stream);
+int xggm_pool_concat_bwd_f32(const void* d_out, const void* out, void* dx, void* dnodes, int B, int N, int H,
+                             int accumulate_dx, xggm_stream_t stream);
+int xggm_pool_concat_bwd_bf16(const void* d_out, const void* out, void* dx, void* dnodes, int B, int N, int H,
+                              int accumulate_dx, xggm_stream_t stream);
+/* x.unsqueeze(1).repeat(1,N,1) and its backward: src/vqa/vqacpv2.py:228 */
+int xggm_bcast_rows_f32(const void* x, void* out, int B, int N, int H, xggm_stream_t stream);
+int xggm_bcast_rows_bf16(const void* x, void* out, int B, int N, int H, xggm_stream_t stream);
+int xggm_sum_rows_f32(const void* g, void* out, int B, int N, int H, xggm_stream_t stream);
+int xggm_sum_rows_bf16(const void* g, void* out, int B, int N, int H, xggm_stream_t stream);
+
+/* ---- losses (scalars are device fp32; *loss must hold the running value, usually 0) ------
+ * loss_func: src/vqa/vqacpv2.py:48-51.  *loss += coef * sum (s-g)^2; ds = gout*2*coef*(s-g) */
+int xggm_dsm_loss_fwd_f32(const void* s, const float* g, float* loss, int64_t n, float coef, xggm_stream_t stream);
+int xggm_dsm_loss_fwd_bf16(const void* s, const float* g, float* loss, int64_t n, float coef, xggm_stream_t stream);
+int xggm_dsm_loss_bwd_f32(const void* s, const float* g, const float* gout, void* ds, int64_t n, float coef,
+                          xggm_stream_t stream);
+int xggm_dsm_loss_bwd_bf16(const void* s, const float* g, const float* gout, void* ds, int64_t n, float coef,
+                           xggm_stream_t stream);
+/* compute_kl_loss: src/vqa/vqacpv2.py:54-61.  rows x W; *loss += coef * sum_rows f (NULL
+ * skips); dx/dy (NULL ok) = [+] *gout * coef * df. */
+int xggm_symkl_f32(const void* x, const void* y, float* loss, const float* gout, void* dx, void* dy, int rows, int W,
+                   float coef, int accumulate, xggm_stream_t stream);
+int xggm_symkl_bf16(const void* x, const void* y, float* loss, const float* gout, void* dx, void* dy, int rows, int W,
+                    float coef, int accumulate, xggm_stream_t stream);
+/* nn.BCEWithLogitsLoss()(logit, target) * A: src/vqa/vqacpv2.py:131,173; logits fp32 */
+int xggm_bce_fwd(const float* logit, const float* target, float* loss, int64_t n, float coef, xggm_stream_t stream);
+int xggm_bce_bwd_f32(const float* logit, const float* target, const float* gout, void* dlogit, int64_t n, float coef,
+                     xggm_stream_t stream);
+int xggm_bce_bwd_bf16(const float* logit, const float* target, const float* gout, void* dlogit, int64_t n, float coef,
+                      xggm_stream_t stream);
+
+/* ---- optimiser ---------------------------------------------------------------------------
+ * *out += sum g^2 over a flat fp32 range (clip_grad_norm_, src/vqa/vqacpv2.py:175) */
+int xggm_sqnorm_f32(const float* g, int64_t n, float* out, xggm_stream_t stream);
+/* BertAdam.step (src/lxrt/optimization.py:159-193) fused with the clip scale
+ * min(1, max_norm/(sqrt(*sqnorm)+1e-6)) and the bf16 shadow-weight write. */
+int xggm_bertadam_f32(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, const float* sqnorm,
+                      float max_norm, float lr, const float* lr_scale, float b1, float b2, float eps, float weight_decay,
+                      xggm_stream_t stream);
+/* *lr_scale = warmup_linear(*step / t_total, warmup); *step += 1 (optimization.py:42-48) */
+int xggm_sched_step(int64_t* step, float* lr_scale, int64_t t_total, float warmup, xggm_stream_t stream);
+
+/* ---- utilities ---------------------------------------------------------------------------*/
+int xggm_rng_advance(uint64_t* rng, uint64_t by, xggm_stream_t stream);
+int xggm_cast_f32_to_bf16(const float* x, void* out, int64_t n, xggm_stream_t stream);
+/* test hooks: the dropout keep-scale (0 or 1/(1-p)) and N(0,1) draw of elements 0..n-1 */
+int xggm_dropout_mask(float* out, int64_t n, float p, const uint64_t* rng, uint32_t sid, xggm_stream_t stream);
+int xggm_normal(float* out, int64_t n, const uint64_t* rng, uint32_t sid, xggm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XGGM_H */

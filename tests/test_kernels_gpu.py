@@ -1,0 +1,520 @@
+"""Per-kernel parity of the C-ABI entry points against the CPU oracle / fp64 torch on the
+same seeded inputs.  fp32 storage: tolerance 1e-5..1e-4 relative (fp32 MFMA is an exact
+fma chain, differences are summation order only).  bf16 storage: inputs are rounded to
+bf16 first and the checker consumes the SAME rounded values, so what remains is the output
+rounding: 1e-2 relative on tensors."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import rel_err  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from xggm_amd import ops as o
+    return o
+
+
+DEV = "cuda"
+DTS = [torch.float32, torch.bfloat16]
+
+
+def tol(dt, f32=2e-5, bf=1.2e-2):
+    return f32 if dt == torch.float32 else bf
+
+
+def rnd(shape, dt, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(shape, generator=g) * scale).to(dt)
+    return x.to(DEV), x.double()
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("M,N,K", [(640, 768, 768), (1152, 2304, 768), (37, 50, 100), (32, 2274, 1536),
+                                   (64, 64, 64), (1, 630, 768), (200, 96, 40)])
+def test_linear_fwd_dgrad_wgrad(ops, dt, M, N, K):
+    x, xr = rnd((M, K), dt, 1)
+    w, wr = rnd((N, K), dt, 2, 0.05)
+    b = torch.randn(N, generator=torch.Generator().manual_seed(3)).to(DEV)
+    y, _ = ops.linear_fwd(x, w, b)
+    ref = xr @ wr.t() + b.double().cpu()
+    assert rel_err(y, ref) < tol(dt)
+    # gelu + preact
+    y2, pre = ops.linear_fwd(x, w, b, act=ops.ACT_GELU, want_preact=True)
+    assert rel_err(pre, ref) < tol(dt)
+    pr = pre.double().cpu()
+    assert rel_err(y2, pr * 0.5 * (1 + torch.erf(pr / math.sqrt(2)))) < tol(dt)
+    # f32 output with sigmoid
+    y3, _ = ops.linear_fwd(x, w, b, act=ops.ACT_SIGMOID, out_f32=True)
+    assert y3.dtype == torch.float32 and rel_err(y3, torch.sigmoid(ref)) < tol(dt, 2e-5, 2e-3)
+    # dgrad
+    dy, dyr = rnd((M, N), dt, 4)
+    res, resr = rnd((M, K), dt, 5)
+    dx = ops.linear_dgrad(dy, w, residual=res)
+    assert rel_err(dx, dyr @ wr + resr) < tol(dt)
+    # dgrad fused with GELU backward
+    u, ur = rnd((M, K), dt, 6)
+    dxg = ops.linear_dgrad(dy, w, gelu_aux=u)
+    cdf = 0.5 * (1 + torch.erf(ur / math.sqrt(2)))
+    pdf = torch.exp(-0.5 * ur * ur) / math.sqrt(2 * math.pi)
+    assert rel_err(dxg, (dyr @ wr) * (cdf + ur * pdf)) < tol(dt)
+    # wgrad (fp32 out), overwrite then accumulate
+    gw = torch.full((N, K), 7.0, device=DEV)
+    ops.linear_wgrad(dy, x, gw, accumulate=False)
+    assert rel_err(gw, dyr.t() @ xr) < tol(dt, 2e-5, 1e-4)
+    ops.linear_wgrad(dy, x, gw, accumulate=True)
+    assert rel_err(gw, 2 * (dyr.t() @ xr)) < tol(dt, 2e-5, 1e-4)
+    # bias grad
+    gb = torch.zeros(N, device=DEV)
+    ops.colsum(dy, gb)
+    assert rel_err(gb, dyr.sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_linear_strided_rows(ops, dt):
+    """pooler input lang[:, 0]: rows strided by T*H"""
+    B, T, H = 5, 20, 128
+    x, xr = rnd((B, T, H), dt, 1)
+    w, wr = rnd((H, H), dt, 2, 0.1)
+    y, _ = ops.linear_fwd(x[:, 0], w, None, act=ops.ACT_TANH)
+    assert rel_err(y, torch.tanh(xr[:, 0] @ wr.t())) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("N,H", [(36, 768), (64, 768), (36, 128), (5, 64)])
+def test_bmm_nt(ops, dt, N, H):
+    x, xr = rnd((3, N, H), dt, 1)
+    S = ops.bmm_nt(x, x)
+    assert rel_err(S, xr @ xr.transpose(1, 2)) < tol(dt, 2e-5, 1e-4)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("Sq,Sk", [(20, 20), (36, 36), (20, 36), (36, 20), (64, 64), (1, 7)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_attention(ops, dt, Sq, Sk, masked):
+    B, heads = 3, 2
+    H = heads * 64
+    # fused-QKV style buffers: q from one [B*Sq, 3H] buffer, k/v from another
+    bufq, bufqr = rnd((B * Sq, 3 * H), dt, 1)
+    bufk, bufkr = rnd((B * Sk, 3 * H), dt, 2)
+    q, k, v = bufq[:, :H], bufk[:, H:2 * H], bufk[:, 2 * H:]
+    qr, kr, vr = bufqr[:, :H], bufkr[:, H:2 * H], bufkr[:, 2 * H:]
+    mask = None
+    mr = 0.0
+    if masked:
+        lens = torch.tensor([Sk, max(1, Sk // 2), max(1, Sk - 3)])
+        m01 = (torch.arange(Sk)[None, :] < lens[:, None]).float()
+        mask = ((1 - m01) * -10000.0).to(DEV)
+        mr = mask.double().cpu()[:, None, None, :]
+
+    def ref(qr, kr, vr):
+        qh = qr.reshape(B, Sq, heads, 64).permute(0, 2, 1, 3)
+        kh = kr.reshape(B, Sk, heads, 64).permute(0, 2, 1, 3)
+        vh = vr.reshape(B, Sk, heads, 64).permute(0, 2, 1, 3)
+        p = torch.softmax(qh @ kh.transpose(-1, -2) / 8.0 + mr, dim=-1)
+        return (p @ vh).permute(0, 2, 1, 3).reshape(B * Sq, H)
+
+    out = ops.attn_fwd(q, k, v, mask, B, heads, Sq, Sk, 0.0, None, 0)
+    assert rel_err(out, ref(qr, kr, vr)) < tol(dt)
+    # backward vs autograd of the fp64 reference
+    do, dor = rnd((B * Sq, H), dt, 3)
+    qa, ka, va = (t.clone().requires_grad_(True) for t in (qr, kr, vr))
+    (ref(qa, ka, va) * dor).sum().backward()
+    dq = torch.empty((B * Sq, H), device=DEV, dtype=dt)
+    dkv = torch.empty((B * Sk, 2 * H), device=DEV, dtype=dt)
+    ops.attn_bwd(q, k, v, mask, do, dq, dkv[:, :H], dkv[:, H:], B, heads, Sq, Sk, 0.0, None, 0)
+    assert rel_err(dq, qa.grad) < tol(dt, 5e-5)
+    assert rel_err(dkv[:, :H], ka.grad) < tol(dt, 5e-5)
+    assert rel_err(dkv[:, H:], va.grad) < tol(dt, 5e-5)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_attention_dropout_consistency(ops, dt):
+    """with dropout the forward equals the reference fed the exported Philox mask, and the
+    backward uses the same mask."""
+    B, heads, Sq, Sk, H = 2, 2, 20, 36, 128
+    q, qr = rnd((B * Sq, H), dt, 1)
+    k, kr = rnd((B * Sk, H), dt, 2)
+    v, vr = rnd((B * Sk, H), dt, 3)
+    rng = ops.make_rng(1234, DEV)
+    p, sid = 0.1, 77
+    out = ops.attn_fwd(q, k, v, None, B, heads, Sq, Sk, p, rng, sid)
+    mask = ops.dropout_mask(B * heads * Sq * Sk, p, rng, sid, DEV).double().cpu().view(B, heads, Sq, Sk)
+    keep = (mask > 0).double().mean().item()
+    assert abs(keep - 0.9) < 0.03 and abs(mask.max().item() - 1 / 0.9) < 1e-6
+
+    def ref(qr, kr, vr):
+        qh = qr.reshape(B, Sq, heads, 64).permute(0, 2, 1, 3)
+        kh = kr.reshape(B, Sk, heads, 64).permute(0, 2, 1, 3)
+        vh = vr.reshape(B, Sk, heads, 64).permute(0, 2, 1, 3)
+        pm = torch.softmax(qh @ kh.transpose(-1, -2) / 8.0, dim=-1) * mask
+        return (pm @ vh).permute(0, 2, 1, 3).reshape(B * Sq, H)
+
+    assert rel_err(out, ref(qr, kr, vr)) < tol(dt)
+    do, dor = rnd((B * Sq, H), dt, 4)
+    qa, ka, va = (t.clone().requires_grad_(True) for t in (qr, kr, vr))
+    (ref(qa, ka, va) * dor).sum().backward()
+    dq, dk, dv = (torch.empty_like(t) for t in (q, k, v))
+    ops.attn_bwd(q, k, v, None, do, dq, dk, dv, B, heads, Sq, Sk, p, rng, sid)
+    assert rel_err(dq, qa.grad) < tol(dt, 5e-5) and rel_err(dk, ka.grad) < tol(dt, 5e-5)
+    assert rel_err(dv, va.grad) < tol(dt, 5e-5)
+    # a different offset gives a different mask
+    ops.rng_advance(rng)
+    m2 = ops.dropout_mask(B * heads * Sq * Sk, p, rng, sid, DEV).double().cpu()
+    assert (m2 != mask.view(-1)).any()
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("M,H", [(1152, 768), (7, 128), (32, 1536), (100, 256), (9, 2048)])
+def test_layernorm_fwd_bwd(ops, dt, M, H):
+    x, xr = rnd((M, H), dt, 1)
+    res, resr = rnd((M, H), dt, 2)
+    gen = torch.Generator().manual_seed(3)
+    bias = torch.randn(H, generator=gen)
+    gamma = 1 + 0.1 * torch.randn(H, generator=gen)
+    beta = 0.1 * torch.randn(H, generator=gen)
+    eps = 1e-12
+    xin = x.clone()
+    out, z, stats = ops.ln_fwd(xin, bias.to(DEV), res, gamma.to(DEV), beta.to(DEV), eps)
+    zr = xr + bias.double() + resr
+    za = zr.clone().requires_grad_(True)
+    ga, ba = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(za, (H,), ga, ba, eps)
+    assert rel_err(z, zr) < tol(dt, 1e-6, 5e-3)
+    assert rel_err(out, yr) < tol(dt)
+    dy, dyr = rnd((M, H), dt, 4)
+    # the kernel normalises the stored (rounded) z; mirror that in the checker
+    zs = z.double().cpu().requires_grad_(True)
+    ys = torch.nn.functional.layer_norm(zs, (H,), ga, ba, eps)
+    (ys * dyr).sum().backward()
+    dg, db, dbias = (torch.zeros(H, device=DEV) for _ in range(3))
+    d_in, d_res = ops.ln_bwd(dy, z, stats, gamma.to(DEV), dg, db, dbias, want_dres=True)
+    assert rel_err(d_in, zs.grad) < tol(dt, 1e-4)
+    assert rel_err(d_res, zs.grad) < tol(dt, 1e-4)
+    assert rel_err(dg, ga.grad) < tol(dt, 1e-4, 2e-3)
+    assert rel_err(db, ba.grad) < tol(dt, 1e-4, 2e-3)
+    assert rel_err(dbias, zs.grad.sum(0)) < tol(dt, 1e-4, 5e-3)
+    # accumulate into an existing residual gradient
+    acc = d_res.clone()
+    ops.ln_bwd(dy, z, stats, gamma.to(DEV), None, None, None, want_din=False, d_res=acc)
+    assert rel_err(acc, 2 * zs.grad) < tol(dt, 1e-4, 1.5e-2)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_layernorm_dropout_and_accumulate(ops, dt):
+    """GNN read-out form: out += drop_.5(LN(x)); pre-dropout form: LN(drop_.1(x+b)+res)."""
+    M, H = 108, 768
+    x, xr = rnd((M, H), dt, 1)
+    res, resr = rnd((M, H), dt, 2)
+    gamma = torch.ones(H)
+    beta = torch.zeros(H)
+    rng = ops.make_rng(99, DEV)
+    m_pre = ops.dropout_mask(M * H, 0.1, rng, 5, DEV).double().cpu().view(M, H)
+    m_post = ops.dropout_mask(M * H, 0.5, rng, 6, DEV).double().cpu().view(M, H)
+    assert abs((m_post > 0).double().mean().item() - 0.5) < 0.02
+    base, baser = rnd((M, H), dt, 3)
+    out = base.clone()
+    _, z, stats = ops.ln_fwd(x.clone(), None, res, gamma.to(DEV), beta.to(DEV), 1e-5, p_pre=0.1, p_post=0.5,
+                             rng=rng, sid_pre=5, sid_post=6, out=out, accumulate=True)
+    zr = xr * m_pre + resr
+    yr = torch.nn.functional.layer_norm(zr, (H,), gamma.double(), beta.double(), 1e-5) * m_post + baser
+    assert rel_err(out, yr) < tol(dt)
+    dy, dyr = rnd((M, H), dt, 4)
+    zs = z.double().cpu().requires_grad_(True)
+    xs = xr.clone().requires_grad_(True)
+    (torch.nn.functional.layer_norm(zs, (H,), gamma.double(), beta.double(), 1e-5) * m_post * dyr).sum().backward()
+    d_in, d_res = ops.ln_bwd(dy, z, stats, gamma.to(DEV), None, None, None, want_dres=True, p_pre=0.1, p_post=0.5,
+                             rng=rng, sid_pre=5, sid_post=6)
+    assert rel_err(d_res, zs.grad) < tol(dt, 1e-4)
+    assert rel_err(d_in, zs.grad * m_pre) < tol(dt, 1e-4)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_embeddings(ops, dt):
+    from oracle import xggm_oracle as O
+    B, T, H, V = 4, 20, 128, 64
+    gen = torch.Generator().manual_seed(1)
+    P = {"e.word_embeddings.weight": torch.randn(V, H, generator=gen).to(dt).double(),
+         "e.position_embeddings.weight": torch.randn(32, H, generator=gen).to(dt).double(),
+         "e.token_type_embeddings.weight": torch.randn(2, H, generator=gen).to(dt).double(),
+         "e.LayerNorm.weight": (1 + 0.1 * torch.randn(H, generator=gen)).double(),
+         "e.LayerNorm.bias": (0.1 * torch.randn(H, generator=gen)).double()}
+    P = {k: v.requires_grad_(True) for k, v in P.items()}
+    ids = torch.randint(0, V, (B, T), generator=gen)
+    ids[:, -3:] = 0  # padding rows
+    seg = torch.zeros_like(ids)
+    seg[1] = 1
+    ref = O.bert_embeddings(P, "e.", ids, seg)
+    dev = {k: v.detach().to(DEV, dt if "embeddings" in k else torch.float32) for k, v in P.items()}
+    out, z, stats = ops.embed_fwd(ids.to(DEV), seg.to(DEV), dev["e.word_embeddings.weight"],
+                                  dev["e.position_embeddings.weight"], dev["e.token_type_embeddings.weight"],
+                                  dev["e.LayerNorm.weight"], dev["e.LayerNorm.bias"], 1e-12, 0.0, None, 0)
+    assert rel_err(out.view(B, T, H), ref) < tol(dt)
+    dy, dyr = rnd((B * T, H), dt, 2)
+    (ref * dyr.view(B, T, H)).sum().backward()
+    g = {k: torch.zeros(v.shape, device=DEV) for k, v in P.items()}
+    ops.embed_bwd(ids.to(DEV), seg.to(DEV), dy, z, stats, dev["e.LayerNorm.weight"], g["e.word_embeddings.weight"],
+                  g["e.position_embeddings.weight"], g["e.token_type_embeddings.weight"], g["e.LayerNorm.weight"],
+                  g["e.LayerNorm.bias"], 0.0, None, 0)
+    for k in P:
+        assert rel_err(g[k], P[k].grad) < tol(dt, 1e-4, 2e-2), k
+    assert float(g["e.word_embeddings.weight"][0].abs().max()) == 0.0  # padding_idx row
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("H,F", [(768, 2048), (128, 64)])
+def test_visual_embedding(ops, dt, H, F):
+    from oracle import xggm_oracle as O
+    M = 72
+    gen = torch.Generator().manual_seed(1)
+    P = {"v.visn_fc.weight": (0.02 * torch.randn(H, F, generator=gen)).to(dt).double(),
+         "v.visn_fc.bias": 0.1 * torch.randn(H, generator=gen).double(),
+         "v.visn_layer_norm.weight": (1 + 0.1 * torch.randn(H, generator=gen)).double(),
+         "v.visn_layer_norm.bias": 0.1 * torch.randn(H, generator=gen).double(),
+         "v.box_fc.weight": torch.randn(H, 4, generator=gen).double(),
+         "v.box_fc.bias": 0.1 * torch.randn(H, generator=gen).double(),
+         "v.box_layer_norm.weight": (1 + 0.1 * torch.randn(H, generator=gen)).double(),
+         "v.box_layer_norm.bias": 0.1 * torch.randn(H, generator=gen).double()}
+    P = {k: v.requires_grad_(True) for k, v in P.items()}
+    feats, fr = rnd((M, F), dt, 2)
+    fr = (fr.abs()).clone()
+    feats = feats.abs()
+    boxes, br = rnd((M, 4), dt, 3)
+    ref = O.visual_feat_encoder(P, "v.", fr, br)
+    d32 = {k: v.detach().float().to(DEV) for k, v in P.items()}
+    u, _ = ops.linear_fwd(feats, d32["v.visn_fc.weight"].to(dt), None)
+    out, z1, z2, stats = ops.visn_embed_fwd(u, d32["v.visn_fc.bias"], boxes, d32["v.box_fc.weight"],
+                                            d32["v.box_fc.bias"], d32["v.visn_layer_norm.weight"],
+                                            d32["v.visn_layer_norm.bias"], d32["v.box_layer_norm.weight"],
+                                            d32["v.box_layer_norm.bias"], 1e-12, 0.0, None, 0)
+    assert rel_err(out, ref) < tol(dt, 5e-5)
+    dy, dyr = rnd((M, H), dt, 4)
+    (ref * dyr).sum().backward()
+    grads = {k: torch.zeros(s, device=DEV) for k, s in
+             dict(dbf=H, dg1=H, db1=H, dWb=(H, 4), dbb=H, dg2=H, db2=H).items()}
+    du = ops.visn_embed_bwd(dy, z1, z2, stats, boxes, d32["v.visn_layer_norm.weight"],
+                            d32["v.box_layer_norm.weight"], grads, 0.0, None, 0)
+    names = dict(dbf="v.visn_fc.bias", dg1="v.visn_layer_norm.weight", db1="v.visn_layer_norm.bias",
+                 dWb="v.box_fc.weight", dbb="v.box_fc.bias", dg2="v.box_layer_norm.weight",
+                 db2="v.box_layer_norm.bias")
+    for k, n in names.items():
+        assert rel_err(grads[k], P[n].grad) < tol(dt, 2e-4, 2e-2), n
+    gw = torch.zeros(H, F, device=DEV)
+    ops.linear_wgrad(du, feats, gw, False)
+    assert rel_err(gw, P["v.visn_fc.weight"].grad) < tol(dt, 2e-4, 2e-2)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("N", [36, 64, 5])
+def test_aggregate(ops, dt, N):
+    B, H = 3, 768
+    x, xr = rnd((B, N, H), dt, 1)
+    adj = torch.randn(B, N, N, generator=torch.Generator().manual_seed(2))
+    a = adj.double()
+    assert rel_err(ops.aggregate(adj.to(DEV), x), a @ xr) < tol(dt)
+    assert rel_err(ops.aggregate(adj.to(DEV), x, mode=ops.AGG_TRANSPOSE), a.transpose(1, 2) @ xr) < tol(dt)
+    assert rel_err(ops.aggregate(adj.to(DEV), x, mode=ops.AGG_SYMMETRIZE), (a + a.transpose(1, 2)) @ xr) < tol(dt)
+    eps = torch.tensor([0.3], device=DEV)
+    out = x.clone()
+    ops.aggregate(adj.to(DEV), x, scale_ptr=eps, self_w=1.0, out=out)
+    assert rel_err(out, xr + xr + 1.3 * (a @ xr)) < tol(dt)
+    dh, dhr = rnd((B, N, H), dt, 3)
+    acc = torch.zeros(1, device=DEV)
+    ops.agg_dot(adj.to(DEV), x, dh, acc)
+    assert abs(float(acc) - float(((a @ xr) * dhr).sum())) < 1e-3 * float(((a @ xr) * dhr).abs().sum())
+
+
+@pytest.mark.parametrize("N", [36, 64, 7])
+def test_adj_regen(ops, N):
+    from oracle import xggm_oracle as O
+    B, H = 4, 96
+    x = torch.randn(B, N, H, generator=torch.Generator().manual_seed(1)).double()
+    S = (x @ x.transpose(1, 2))
+    S[0, 2, 3] = S[0, :, 3].max() + 1.0  # an off-diagonal column maximum
+    S[1, 4, 5] = S[1, 5, 5]              # an exact tie: torch picks the first index (row 4)
+    Sd = S.float().to(DEV)
+    adj, colmax, argmax = ops.adj_regen_fwd(Sd)
+    Sr = S.float().double().requires_grad_(True)
+    s = Sr / Sr.max(dim=1)[0].unsqueeze(-1)
+    s = torch.sigmoid(s)
+    ref = s.triu(1) + s.tril(-1)
+    assert rel_err(adj, ref) < 1e-6
+    assert torch.equal(argmax.cpu().long(), Sr.max(dim=1)[1])  # bit-exact indices
+    assert int(argmax[0, 3]) == 2 and int(argmax[1, 5]) == 4
+    g = torch.randn(B, N, N, generator=torch.Generator().manual_seed(2))
+    (ref * g.double()).sum().backward()
+    dS = ops.adj_regen_bwd(g.to(DEV), Sd, adj, colmax, argmax)
+    assert rel_err(dS, Sr.grad) < 1e-5
+    # the whole regeneration incl. S = x x^T against the oracle
+    xs = x.float()
+    Sx = ops.bmm_nt(xs.to(DEV), xs.to(DEV))
+    a2, _, _ = ops.adj_regen_fwd(Sx)
+    assert rel_err(a2, O.regen_adj(xs.double())) < 1e-5
+
+
+@pytest.mark.parametrize("N", [36, 64, 4])
+def test_adj_init_index_map_bit_exact(ops, N):
+    from oracle import xggm_oracle as O
+    B = 3
+    NE = N * (N - 1) // 2
+    ii, jj = O.triu_index_table(N)
+    for k in (0, 1, NE // 2, NE - 1):
+        assert ops.triu_index(k, N) == (int(ii[k]), int(jj[k]))
+    e = torch.arange(B * NE, dtype=torch.float32).view(B, NE) + 1.0
+    randn = torch.randn(B, N, N, generator=torch.Generator().manual_seed(1))
+    adj, g = ops.adj_init_fwd(e.to(DEV), N, 0.7, randn=randn.to(DEV))
+    a0 = O.adj_init(e, N)
+    an, ag = O.add_edge_noise_v2(a0, randn, 0.7)
+    # noiseless scatter is exact (integers): compare positions bit for bit
+    adj0, _ = ops.adj_init_fwd(e.to(DEV), N, 0.7, randn=torch.zeros(B, N, N, device=DEV))
+    assert torch.equal(adj0.cpu(), a0)
+    assert rel_err(adj, an) < 1e-6 and rel_err(g, ag) < 1e-6
+    d = torch.randn(B, N, N, generator=torch.Generator().manual_seed(2))
+    de = ops.adj_init_bwd(d.to(DEV))
+    assert rel_err(de, d[:, ii, jj] + d[:, jj, ii]) < 1e-6
+    # Philox noise: symmetric, zero diagonal, unit variance
+    rng = ops.make_rng(5, DEV)
+    an2, g2 = ops.adj_init_fwd(None, N, 1.0, rng=rng, sid=9, B=64)
+    assert torch.equal(an2, an2.transpose(1, 2)) and float(an2.diagonal(dim1=1, dim2=2).abs().max()) == 0
+    if N >= 36:
+        off = an2[:, ii, jj]
+        assert abs(float(off.mean())) < 0.05 and abs(float(off.std()) - 1.0) < 0.05
+        assert torch.equal(g2, -an2)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_feature_noise_pool_bcast(ops, dt):
+    B, N, H = 3, 36, 128
+    x, xr = rnd((B, N, H), dt, 1)
+    z = torch.randn(B, N, H, generator=torch.Generator().manual_seed(2))
+    out, g = ops.feature_noise(x, 0.7, randn=z.to(DEV))
+    assert rel_err(out, xr + 0.7 * z.double()) < tol(dt) and rel_err(g, -z.double() / 0.7) < 1e-6
+    rng = ops.make_rng(3, DEV)
+    o2, g2 = ops.feature_noise(x, 1.0, rng=rng, sid=4)
+    assert abs(float(g2.std()) - 1.0) < 0.05 and abs(float(g2.mean())) < 0.05
+    p, pr = rnd((B, H), dt, 3)
+    cat = ops.pool_concat_fwd(p, x)
+    ref = torch.cat([pr, torch.tanh(xr.mean(1))], dim=-1)
+    assert rel_err(cat, ref) < tol(dt)
+    d, dr = rnd((B, 2 * H), dt, 4)
+    dx, dn = ops.pool_concat_bwd(d, cat, N)
+    t = cat.double().cpu()[:, H:]
+    assert rel_err(dx, dr[:, :H]) < tol(dt)
+    assert rel_err(dn, (dr[:, H:] * (1 - t * t) / N).unsqueeze(1).expand(B, N, H)) < tol(dt)
+    bc = ops.bcast_rows(p, N)
+    assert torch.equal(bc, p.unsqueeze(1).expand(B, N, H))
+    assert rel_err(ops.sum_rows(x), xr.sum(1)) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_losses(ops, dt):
+    from oracle import xggm_oracle as O
+    B, N, W = 4, 36, 768
+    s, sr = rnd((B, N, W), dt, 1)
+    g = torch.randn(B, N, W, generator=torch.Generator().manual_seed(2))
+    sigma = 0.7
+    coef = 0.5 * sigma ** 2 / (B * N * W)
+    loss = ops.dsm_fwd(s, g.to(DEV), coef)
+    sa = sr.clone().requires_grad_(True)
+    ref = O.loss_func(sa, g.double(), sigma)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 1e-5 * abs(float(ref))
+    gout = torch.tensor(2.5, device=DEV)
+    ds = ops.dsm_bwd(s, g.to(DEV), gout, coef)
+    assert rel_err(ds, 2.5 * sa.grad) < tol(dt)
+    # symmetric KL over 768-wide and 36-wide rows
+    for W2, dt2 in ((768, dt), (36, torch.float32)):
+        x, xr = rnd((B, N, W2), dt2, 3)
+        y, yr = rnd((B, N, W2), dt2, 4)
+        coef = 1.0 / (B * N * W2)
+        l = ops.symkl_fwd(x, y, coef)
+        xa, ya = xr.clone().requires_grad_(True), yr.clone().requires_grad_(True)
+        r = O.compute_kl_loss(xa, ya)
+        r.backward()
+        assert abs(float(l) - float(r)) < 2e-5 * abs(float(r))
+        dx, dy = ops.symkl_bwd(x, y, gout, coef, True, True)
+        assert rel_err(dx, 2.5 * xa.grad) < tol(dt2, 1e-4) and rel_err(dy, 2.5 * ya.grad) < tol(dt2, 1e-4)
+    A = 2274
+    lg = (3 * torch.randn(B, A, generator=torch.Generator().manual_seed(5)))
+    tg = (torch.rand(B, A, generator=torch.Generator().manual_seed(6)) > 0.99).float()
+    l = ops.bce_fwd(lg.to(DEV), tg.to(DEV), 1.0 / B)
+    la = lg.double().requires_grad_(True)
+    r = O.bce_with_logits_mean(la, tg.double()) * A
+    r.backward()
+    assert abs(float(l) - float(r)) < 1e-5 * abs(float(r))
+    dl = ops.bce_bwd(lg.to(DEV), tg.to(DEV), gout, 1.0 / B, dt)
+    assert rel_err(dl, 2.5 * la.grad) < tol(dt)
+
+
+def test_bertadam_against_golden(ops):
+    """the reference BertAdam trajectory stored in tests/golden/pieces.npz"""
+    from helpers import load_golden
+    from oracle import xggm_oracle as O
+    g = load_golden("pieces")
+    for key, lr in (("1", 4e-3), ("2", 1e-3)):
+        p = torch.from_numpy(g["adam_p%s_0" % key]).clone().to(DEV).view(-1)
+        n = p.numel()
+        # pad to the arena's 16-byte granularity
+        P = torch.zeros(((n + 3) // 4) * 4 + 4, device=DEV)
+        P[:n] = p
+        M, V = torch.zeros_like(P), torch.zeros_like(P)
+        shadow = torch.zeros(P.numel(), device=DEV, dtype=torch.bfloat16)
+        step = torch.zeros(1, dtype=torch.int64, device=DEV)
+        lr_scale = torch.zeros(1, device=DEV)
+        for s in range(6):
+            G = torch.zeros_like(P)
+            G[:n] = torch.from_numpy(g["adam_g%s" % key][s]).view(-1)
+            ops.sched_step(step, lr_scale, 10, 0.1)
+            assert abs(float(lr_scale) - O.warmup_linear(s / 10, 0.1)) < 1e-6
+            ops.bertadam(P[:n], G[:n], M[:n], V[:n], shadow[:n], None, 5.0, lr, lr_scale, 0.9, 0.999, 1e-6, 0.01)
+            assert rel_err(P[:n], torch.from_numpy(g["adam_p%s" % key][s]).view(-1)) < 1e-6
+            assert rel_err(shadow[:n].float(), P[:n]) < 4e-3
+        assert int(step) == 6
+
+
+def test_sqnorm_and_clip(ops):
+    n = 1_000_003
+    g = torch.randn(n + 1, generator=torch.Generator().manual_seed(1)).to(DEV)[:n]
+    gp = torch.zeros(((n + 3) // 4) * 4, device=DEV)
+    gp[:n] = g
+    out = torch.zeros(1, device=DEV)
+    ops.sqnorm(gp[:n], out)
+    ref = float((g.double() ** 2).sum())
+    assert abs(float(out) - ref) < 1e-5 * ref
+    # clip: grads 100x too large are scaled to norm 5 before the update
+    p = torch.ones(8, device=DEV)
+    G = torch.full((8,), 100.0, device=DEV)
+    sq = torch.zeros(1, device=DEV)
+    ops.sqnorm(G, sq)
+    m, v = torch.zeros(8, device=DEV), torch.zeros(8, device=DEV)
+    ops.bertadam(p, G, m, v, None, sq, 5.0, 0.1, None, 0.9, 0.999, 1e-6, 0.0)
+    gc = 100.0 * 5.0 / (math.sqrt(8 * 100.0 ** 2) + 1e-6)
+    mm, vv = 0.1 * gc, 0.001 * gc * gc
+    assert abs(float(p[0]) - (1 - 0.1 * mm / (math.sqrt(vv) + 1e-6))) < 1e-5
+
+
+def test_philox_normal_moments(ops):
+    rng = ops.make_rng(7, DEV)
+    z = ops.normal(1 << 20, rng, 3, DEV).double().cpu()
+    assert abs(float(z.mean())) < 5e-3 and abs(float(z.std()) - 1) < 5e-3
+    assert abs(float((z ** 4).mean()) - 3.0) < 0.05
+    z2 = ops.normal(1 << 20, rng, 4, DEV).double().cpu()
+    assert abs(float((z * z2).mean())) < 5e-3  # streams are independent
+
+
+def test_bad_arguments_fail_loudly(ops):
+    x = torch.zeros(4, 6, device=DEV)
+    with pytest.raises(RuntimeError):
+        ops.ln_fwd(x, None, None, torch.ones(6, device=DEV), torch.zeros(6, device=DEV), 1e-5)  # H % 4
+    with pytest.raises(RuntimeError):
+        ops.attn_fwd(torch.zeros(130, 64, device=DEV), torch.zeros(130, 64, device=DEV),
+                     torch.zeros(130, 64, device=DEV), None, 2, 1, 65, 65, 0.0, None, 0)  # S > 64
+    with pytest.raises(RuntimeError):
+        ops.linear_fwd(torch.zeros(4, 8), torch.zeros(3, 8), None)  # CPU tensors: no fallback

@@ -1,0 +1,253 @@
+// xggm_attn_fwd / xggm_attn_bwd: the small-sequence attention core of BertAttention
+// (src/lxrt/modeling.py:355-373): softmax(Q K^T / sqrt(d) + mask) -> dropout -> P V, and its
+// backward.  Sequences on this path are 20 tokens / 36 objects (<= 64), d = 64, so a whole
+// (batch, head) problem -- Q, K, V tiles, the score matrix and, in backward, dO and dS --
+// lives in the LDS of one 256-thread workgroup: HBM traffic is exactly one read of
+// Q/K/V(/dO) and one write of O (dQ/dK/dV).  Nothing but the inputs is saved for backward:
+// P and the Philox dropout mask are recomputed.  Per-row softmax uses wave64 shuffle
+// reductions; fp32 math throughout (the products are ~1% of the step's FLOPs, MFMA would
+// buy nothing here while the tiles are latency- not throughput-bound).
+#include "common.h"
+#include "xggm.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int D = 64;
+constexpr int LD = D + 4;  // float4-aligned rows, conflict-free 16-byte reads
+
+struct AttnArgs {
+    const void *q, *k, *v;
+    const float* mask;  // additive [B, Sk] or null
+    int64_t q_rs, k_rs, v_rs, o_rs;  // row strides in elements
+    int B, heads, Sq, Sk;
+    float scale, p;
+    const uint64_t* rng;
+    uint32_t sid;
+};
+
+template <typename T>
+__device__ __forceinline__ void load_tile(float* lds, const T* base, int64_t rs, int rows, int tid) {
+    // rows x 64 elements, 16 chunks of 4 per row
+    for (int c = tid; c < rows * 16; c += NT) {
+        const int r = c >> 4, cc = (c & 15) * 4;
+        float t[4];
+        load4(base + (int64_t)r * rs + cc, t);
+        *reinterpret_cast<float4*>(lds + r * LD + cc) = make_float4(t[0], t[1], t[2], t[3]);
+    }
+}
+
+__device__ __forceinline__ float dot64(const float* a, const float* b) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; c += 4) {
+        const float4 x = *reinterpret_cast<const float4*>(a + c);
+        const float4 y = *reinterpret_cast<const float4*>(b + c);
+        s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    }
+    return s;
+}
+
+// scores + softmax (+ dropout scale matrix) into LDS.  P: probabilities, Dm: dropout scale
+// (only written when p > 0).  Wave w owns rows w, w+4, ...
+__device__ __forceinline__ void scores_softmax(const AttnArgs& a, const float* Qs, const float* Ks, float* P, float* Dm, int b,
+                                               int h, int tid) {
+    const int Sq = a.Sq, Sk = a.Sk, ldp = Sk + 1;
+    for (int s = tid; s < Sq * Sk; s += NT) {
+        const int i = s / Sk, j = s % Sk;
+        float v = dot64(Qs + i * LD, Ks + j * LD) * a.scale;
+        if (a.mask) v += a.mask[(int64_t)b * Sk + j];
+        P[i * ldp + j] = v;
+    }
+    __syncthreads();
+    const int lane = tid & 63, wid = tid >> 6;
+    uint64_t seed = 0, off = 0;
+    if (a.p > 0.f) {
+        seed = a.rng[0];
+        off = a.rng[1];
+    }
+    const float ik = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
+    for (int i = wid; i < Sq; i += NT / 64) {
+        const float v = lane < Sk ? P[i * ldp + lane] : -INFINITY;
+        const float m = wave_max(v);
+        const float e = lane < Sk ? __expf(v - m) : 0.f;
+        const float sum = wave_sum(e);
+        if (lane < Sk) {
+            P[i * ldp + lane] = e / sum;
+            if (a.p > 0.f) {
+                const uint64_t idx = (((uint64_t)b * a.heads + h) * Sq + i) * Sk + lane;
+                Dm[i * ldp + lane] = dropout_scale(a.p, ik, seed, off, a.sid, idx);
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <typename T> __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnArgs a, T* out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+    const int Sq = a.Sq, Sk = a.Sk, ldp = Sk + 1;
+    float* Qs = smem;
+    float* Ks = Qs + Sq * LD;
+    float* Vs = Ks + Sk * LD;
+    float* P = Vs + Sk * LD;
+    float* Dm = P + Sq * ldp;
+    load_tile<T>(Qs, (const T*)a.q + (int64_t)b * Sq * a.q_rs + h * D, a.q_rs, Sq, tid);
+    load_tile<T>(Ks, (const T*)a.k + (int64_t)b * Sk * a.k_rs + h * D, a.k_rs, Sk, tid);
+    load_tile<T>(Vs, (const T*)a.v + (int64_t)b * Sk * a.v_rs + h * D, a.v_rs, Sk, tid);
+    __syncthreads();
+    scores_softmax(a, Qs, Ks, P, Dm, b, h, tid);
+    // O[i][c..c+3] = sum_j P[i][j] * D[i][j] * V[j][c..c+3]
+    for (int w = tid; w < Sq * 16; w += NT) {
+        const int i = w >> 4, c = (w & 15) * 4;
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < Sk; ++j) {
+            float pj = P[i * ldp + j];
+            if (a.p > 0.f) pj *= Dm[i * ldp + j];
+            const float4 vv = *reinterpret_cast<const float4*>(Vs + j * LD + c);
+            o[0] += pj * vv.x;
+            o[1] += pj * vv.y;
+            o[2] += pj * vv.z;
+            o[3] += pj * vv.w;
+        }
+        store4(out + ((int64_t)b * Sq + i) * a.o_rs + h * D + c, o);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void attn_bwd_kernel(AttnArgs a, const T* d_out, T* dq, T* dk, T* dv, int64_t dq_rs,
+                                                      int64_t dk_rs, int64_t dv_rs) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+    const int Sq = a.Sq, Sk = a.Sk, ldp = Sk + 1;
+    float* Qs = smem;
+    float* Ks = Qs + Sq * LD;
+    float* Vs = Ks + Sk * LD;
+    float* dOs = Vs + Sk * LD;
+    float* P = dOs + Sq * LD;
+    float* Dm = P + Sq * ldp;
+    float* dS = Dm + Sq * ldp;
+    load_tile<T>(Qs, (const T*)a.q + (int64_t)b * Sq * a.q_rs + h * D, a.q_rs, Sq, tid);
+    load_tile<T>(Ks, (const T*)a.k + (int64_t)b * Sk * a.k_rs + h * D, a.k_rs, Sk, tid);
+    load_tile<T>(Vs, (const T*)a.v + (int64_t)b * Sk * a.v_rs + h * D, a.v_rs, Sk, tid);
+    load_tile<T>(dOs, d_out + (int64_t)b * Sq * a.o_rs + h * D, a.o_rs, Sq, tid);
+    __syncthreads();
+    scores_softmax(a, Qs, Ks, P, Dm, b, h, tid);
+    // dP[i][j] = D[i][j] * sum_c dO[i][c] V[j][c]
+    for (int s = tid; s < Sq * Sk; s += NT) {
+        const int i = s / Sk, j = s % Sk;
+        float v = dot64(dOs + i * LD, Vs + j * LD);
+        if (a.p > 0.f) v *= Dm[i * ldp + j];
+        dS[i * ldp + j] = v;
+    }
+    __syncthreads();
+    // dS = P * (dP - rowsum(dP * P)) * scale
+    {
+        const int lane = tid & 63, wid = tid >> 6;
+        for (int i = wid; i < Sq; i += NT / 64) {
+            const float pv = lane < Sk ? P[i * ldp + lane] : 0.f;
+            const float dp = lane < Sk ? dS[i * ldp + lane] : 0.f;
+            const float rs = wave_sum(pv * dp);
+            if (lane < Sk) dS[i * ldp + lane] = pv * (dp - rs) * a.scale;
+        }
+    }
+    __syncthreads();
+    // dQ[i][c] = sum_j dS[i][j] K[j][c]
+    for (int w = tid; w < Sq * 16; w += NT) {
+        const int i = w >> 4, c = (w & 15) * 4;
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < Sk; ++j) {
+            const float s = dS[i * ldp + j];
+            const float4 kk = *reinterpret_cast<const float4*>(Ks + j * LD + c);
+            o[0] += s * kk.x;
+            o[1] += s * kk.y;
+            o[2] += s * kk.z;
+            o[3] += s * kk.w;
+        }
+        store4(dq + ((int64_t)b * Sq + i) * dq_rs + h * D + c, o);
+    }
+    // dK[j][c] = sum_i dS[i][j] Q[i][c];  dV[j][c] = sum_i P[i][j] D[i][j] dO[i][c]
+    for (int w = tid; w < Sk * 16; w += NT) {
+        const int j = w >> 4, c = (w & 15) * 4;
+        float ok[4] = {0.f, 0.f, 0.f, 0.f}, ov[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < Sq; ++i) {
+            const float s = dS[i * ldp + j];
+            float pj = P[i * ldp + j];
+            if (a.p > 0.f) pj *= Dm[i * ldp + j];
+            const float4 qq = *reinterpret_cast<const float4*>(Qs + i * LD + c);
+            const float4 gg = *reinterpret_cast<const float4*>(dOs + i * LD + c);
+            ok[0] += s * qq.x;
+            ok[1] += s * qq.y;
+            ok[2] += s * qq.z;
+            ok[3] += s * qq.w;
+            ov[0] += pj * gg.x;
+            ov[1] += pj * gg.y;
+            ov[2] += pj * gg.z;
+            ov[3] += pj * gg.w;
+        }
+        store4(dk + ((int64_t)b * Sk + j) * dk_rs + h * D + c, ok);
+        store4(dv + ((int64_t)b * Sk + j) * dv_rs + h * D + c, ov);
+    }
+}
+
+int check(const char* who, const AttnArgs& a, int head_dim) {
+    XGGM_REQUIRE(head_dim == D, "%s: head_dim %d != 64", who, head_dim);
+    XGGM_REQUIRE(a.B > 0 && a.heads > 0 && a.Sq > 0 && a.Sk > 0, "%s: empty problem", who);
+    XGGM_REQUIRE(a.Sq <= 64 && a.Sk <= 64, "%s: Sq=%d Sk=%d exceed the 64-row LDS tile", who, a.Sq, a.Sk);
+    XGGM_REQUIRE(a.q && a.k && a.v, "%s: null pointer", who);
+    XGGM_REQUIRE(a.q_rs % 4 == 0 && a.k_rs % 4 == 0 && a.v_rs % 4 == 0 && a.o_rs % 4 == 0, "%s: row strides must be multiples of 4",
+                 who);
+    XGGM_REQUIRE(a.p >= 0.f && a.p < 1.f && (a.p == 0.f || a.rng), "%s: bad dropout arguments", who);
+    XGGM_REQUIRE((int64_t)a.B * a.heads < (1 << 30), "%s: grid too large", who);
+    return XGGM_OK;
+}
+
+template <typename T>
+int attn_fwd(const void* q, const void* k, const void* v, const float* mask, void* out, int B, int heads, int Sq, int Sk,
+             int head_dim, int64_t q_rs, int64_t k_rs, int64_t v_rs, int64_t o_rs, float scale, float p, const uint64_t* rng,
+             uint32_t sid, hipStream_t st) {
+    AttnArgs a{q, k, v, mask, q_rs, k_rs, v_rs, o_rs, B, heads, Sq, Sk, scale, p, rng, sid};
+    if (int e = check("xggm_attn_fwd", a, head_dim)) return e;
+    XGGM_REQUIRE(out, "xggm_attn_fwd: null output");
+    const size_t lds = sizeof(float) * ((size_t)(Sq + 2 * Sk) * LD + 2 * (size_t)Sq * (Sk + 1));
+    hipLaunchKernelGGL((attn_fwd_kernel<T>), dim3(B * heads), dim3(NT), lds, st, a, (T*)out);
+    return xggm_check_launch("xggm_attn_fwd");
+}
+
+template <typename T>
+int attn_bwd(const void* q, const void* k, const void* v, const float* mask, const void* d_out, void* dq, void* dk, void* dv,
+             int B, int heads, int Sq, int Sk, int head_dim, int64_t q_rs, int64_t k_rs, int64_t v_rs, int64_t o_rs,
+             int64_t dq_rs, int64_t dk_rs, int64_t dv_rs, float scale, float p, const uint64_t* rng, uint32_t sid,
+             hipStream_t st) {
+    AttnArgs a{q, k, v, mask, q_rs, k_rs, v_rs, o_rs, B, heads, Sq, Sk, scale, p, rng, sid};
+    if (int e = check("xggm_attn_bwd", a, head_dim)) return e;
+    XGGM_REQUIRE(d_out && dq && dk && dv, "xggm_attn_bwd: null pointer");
+    XGGM_REQUIRE(dq_rs % 4 == 0 && dk_rs % 4 == 0 && dv_rs % 4 == 0, "xggm_attn_bwd: row strides must be multiples of 4");
+    const size_t lds = sizeof(float) * ((size_t)(2 * Sq + 2 * Sk) * LD + 3 * (size_t)Sq * (Sk + 1));
+    hipLaunchKernelGGL((attn_bwd_kernel<T>), dim3(B * heads), dim3(NT), lds, st, a, (const T*)d_out, (T*)dq, (T*)dk, (T*)dv,
+                       dq_rs, dk_rs, dv_rs);
+    return xggm_check_launch("xggm_attn_bwd");
+}
+
+}  // namespace
+
+#define ATTN_API(SUF, T)                                                                                                   \
+    extern "C" int xggm_attn_fwd_##SUF(const void* q, const void* k, const void* v, const float* mask, void* out, int B,  \
+                                       int heads, int Sq, int Sk, int head_dim, int64_t q_rs, int64_t k_rs, int64_t v_rs, \
+                                       int64_t o_rs, float scale, float p, const uint64_t* rng, uint32_t sid,            \
+                                       hipStream_t st) {                                                                  \
+        return attn_fwd<T>(q, k, v, mask, out, B, heads, Sq, Sk, head_dim, q_rs, k_rs, v_rs, o_rs, scale, p, rng, sid, st);\
+    }                                                                                                                      \
+    extern "C" int xggm_attn_bwd_##SUF(const void* q, const void* k, const void* v, const float* mask, const void* d_out,  \
+                                       void* dq, void* dk, void* dv, int B, int heads, int Sq, int Sk, int head_dim,      \
+                                       int64_t q_rs, int64_t k_rs, int64_t v_rs, int64_t o_rs, int64_t dq_rs,             \
+                                       int64_t dk_rs, int64_t dv_rs, float scale, float p, const uint64_t* rng,           \
+                                       uint32_t sid, hipStream_t st) {                                                    \
+        return attn_bwd<T>(q, k, v, mask, d_out, dq, dk, dv, B, heads, Sq, Sk, head_dim, q_rs, k_rs, v_rs, o_rs, dq_rs,    \
+                           dk_rs, dv_rs, scale, p, rng, sid, st);                                                          \
+    }
+
+ATTN_API(f32, float)
+ATTN_API(bf16, bf16)

@@ -1,0 +1,155 @@
+// Shared device/host helpers for the xggm HIP kernels (gfx950 / CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <math.h>
+#include <algorithm>
+#include <type_traits>
+
+#define XGGM_OK 0
+#define XGGM_ERR_ARG 1
+#define XGGM_ERR_LAUNCH 2
+
+typedef __hip_bfloat16 bf16;
+
+// ---------------------------------------------------------------- error reporting
+void xggm_set_error(const char* fmt, ...);
+int xggm_check_launch(const char* what);
+
+#define XGGM_REQUIRE(cond, ...)            \
+    do {                                   \
+        if (!(cond)) {                     \
+            xggm_set_error(__VA_ARGS__);   \
+            return XGGM_ERR_ARG;           \
+        }                                  \
+    } while (0)
+
+// ---------------------------------------------------------------- dtype helpers
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16 x) { return __bfloat162float(x); }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float x) { return __float2bfloat16(x); }
+
+// value as the storage type would hold it (bf16 round trip), used where forward and
+// backward must see the same rounded activation
+template <typename T> __device__ __forceinline__ float round_to(float x) { return to_f32(from_f32<T>(x)); }
+
+// vector of 4 elements of T <-> 4 floats
+struct __attribute__((aligned(8))) bf16x4 { bf16 v[4]; };
+__device__ __forceinline__ void load4(const float* p, float (&o)[4]) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+}
+__device__ __forceinline__ void load4(const bf16* p, float (&o)[4]) {
+    bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = __bfloat162float(t.v[i]);
+}
+__device__ __forceinline__ void store4(float* p, const float (&o)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+}
+__device__ __forceinline__ void store4(bf16* p, const float (&o)[4]) {
+    bf16x4 t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t.v[i] = __float2bfloat16(o[i]);
+    *reinterpret_cast<bf16x4*>(p) = t;
+}
+
+// ---------------------------------------------------------------- wave64 reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------- math
+__device__ __forceinline__ float gelu_f(float x) {
+    return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    // d/dx [x Phi(x)] = Phi(x) + x phi(x)
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// ---------------------------------------------------------------- Philox4x32-10
+// Counter-based RNG: the dropout mask / Gaussian draw of element `idx` of random
+// stream `stream_id` at step `offset` is a pure function of (seed, offset, stream_id,
+// idx), so forward and backward regenerate the same mask without storing it.
+struct Philox {
+    uint32_t k0, k1;
+    __host__ __device__ Philox(uint64_t seed) : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)) {}
+    __host__ __device__ static inline void mulhilo(uint32_t a, uint32_t b, uint32_t& hi, uint32_t& lo) {
+        uint64_t p = (uint64_t)a * b;
+        hi = (uint32_t)(p >> 32);
+        lo = (uint32_t)p;
+    }
+    __host__ __device__ inline void gen(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t (&out)[4]) const {
+        uint32_t a = k0, b = k1;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            uint32_t h0, l0, h1, l1;
+            mulhilo(0xD2511F53u, c0, h0, l0);
+            mulhilo(0xCD9E8D57u, c2, h1, l1);
+            uint32_t n0 = h1 ^ c1 ^ a, n1 = l1, n2 = h0 ^ c3 ^ b, n3 = l0;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+            a += 0x9E3779B9u;
+            b += 0xBB67AE85u;
+        }
+        out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+    }
+};
+
+// RNG state lives in device memory so a captured hipGraph replays with fresh numbers:
+// rng[0] = seed, rng[1] = offset (advanced by xggm_rng_advance once per pass).
+struct RngRef {
+    const uint64_t* state;  // may be null when p == 0
+    uint32_t stream_id;
+};
+
+// uniform in [0,1) for element idx (4 elements share one Philox call: idx>>2 counter)
+__device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t offset, uint32_t stream_id, uint64_t idx) {
+    Philox ph(seed);
+    uint32_t o[4];
+    ph.gen((uint32_t)(idx >> 2), (uint32_t)(idx >> 34), stream_id, (uint32_t)offset ^ (uint32_t)(offset >> 32) * 0x9E3779B9u, o);
+    return (float)(o[idx & 3] >> 8) * (1.0f / 16777216.0f);
+}
+// keep-scale of dropout: 0 if dropped, 1/(1-p) if kept
+__device__ __forceinline__ float dropout_scale(float p, float inv_keep, uint64_t seed, uint64_t offset, uint32_t stream_id,
+                                               uint64_t idx) {
+    return philox_uniform(seed, offset, stream_id, idx) >= p ? inv_keep : 0.0f;
+}
+// 4 consecutive elements (idx multiple of 4) in one Philox call
+__device__ __forceinline__ void dropout_scale4(float p, float inv_keep, uint64_t seed, uint64_t offset, uint32_t stream_id,
+                                               uint64_t idx4, float (&s)[4]) {
+    Philox ph(seed);
+    uint32_t o[4];
+    ph.gen((uint32_t)(idx4 >> 2), (uint32_t)(idx4 >> 34), stream_id, (uint32_t)offset ^ (uint32_t)(offset >> 32) * 0x9E3779B9u, o);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s[i] = ((float)(o[i] >> 8) * (1.0f / 16777216.0f)) >= p ? inv_keep : 0.0f;
+}
+// standard normal for element idx (Box-Muller on two of the four words)
+__device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t offset, uint32_t stream_id, uint64_t idx) {
+    Philox ph(seed);
+    uint32_t o[4];
+    ph.gen((uint32_t)(idx >> 1), (uint32_t)(idx >> 33), stream_id ^ 0x5bd1e995u,
+           (uint32_t)offset ^ (uint32_t)(offset >> 32) * 0x9E3779B9u, o);
+    const uint32_t a = o[(idx & 1) * 2], b = o[(idx & 1) * 2 + 1];
+    const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0,1]
+    const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);
+    return sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530717958647692f * u2);
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,241 @@
+// xggm_gemm_{f32,bf16}: C[m,n] = epilogue( alpha * sum_k A(m,k) B(k,n) )
+//
+// One LDS-tiled MFMA kernel serves every dense product on the path -- Linear forward
+// (A=[M,K] k-contiguous, B=W[N,K] k-contiguous), dgrad (B=W read with the reduction
+// index on the slow dimension), wgrad (both operands read with the reduction index on
+// the slow dimension) and the small batched products -- because both operands are
+// addressed through (row stride, k stride) pairs and are transposed, when needed, on
+// their way into LDS.  Replaces torch.nn.Linear / torch.bmm call sites of
+// src/lxrt/modeling.py:345-347,385,429,442,617 and src/module/gcn.py:28.
+//
+// Tile: 64x64 per 256-thread workgroup (4 waves as 2x2, 32x32 per wave = 2x2 MFMA
+// 16x16 tiles).  The skinny shapes of this workload (M = B*20 / B*36) give 120-900
+// workgroups per launch at B = 32, enough to cover 256 CUs, which a 128^2/256^2 tile
+// would not.  bf16: v_mfma_f32_16x16x32_bf16, BK = 64; f32: v_mfma_f32_16x16x4_f32
+// (exact fp32 FMA chain), BK = 32.  LDS rows are k-contiguous and padded by 16 bytes.
+#include "common.h"
+#include "xggm.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) short short8_t;
+typedef __attribute__((ext_vector_type(4))) float float4_t;
+
+struct GemmArgs {
+    const void* A;
+    const void* B;
+    void* C;
+    int M, N, K;
+    int64_t a_rs, a_ks, b_ns, b_ks, ldc;
+    int64_t a_bs, b_bs, c_bs;
+    const float* bias;     // [N] or null
+    const void* residual;  // T, layout of C (same ldc / batch stride), or null
+    void* preact;          // T, layout of C, or null: alpha*acc + bias before the activation
+    const void* aux;       // T, layout of C: pre-activation u for act == GELU_GRAD
+    int act;
+    int c_f32;         // store C as float regardless of T
+    int accumulate;    // C += result
+    float alpha;
+    int a_mode, b_mode;  // 0 scalar, 1 vector along k, 2 vector along rows
+};
+
+template <typename T> struct Tile;
+template <> struct Tile<bf16> {
+    static constexpr int BK = 64;
+    static constexpr int VEC = 8;  // elements per 16-byte chunk
+    static constexpr int LDK = BK + 8;
+};
+template <> struct Tile<float> {
+    static constexpr int BK = 32;
+    static constexpr int VEC = 4;
+    static constexpr int LDK = BK + 4;
+};
+
+constexpr int BM = 64, BN = 64, NT = 256;
+
+// stage a [64 rows][BK] operand tile into LDS (k contiguous).  elem(r,k) = base[r*rs + k*ks]
+template <typename T>
+__device__ __forceinline__ void stage_tile(T* __restrict__ lds, const T* __restrict__ base, int64_t rs, int64_t ks, int r0,
+                                           int k0, int R, int K, int mode, int tid) {
+    constexpr int BK = Tile<T>::BK, VEC = Tile<T>::VEC, LDK = Tile<T>::LDK;
+    typedef typename std::conditional<sizeof(T) == 2, short8_t, float4_t>::type vec_t;
+    if (mode == 1) {
+        // 16-byte chunks along k
+        constexpr int CPR = BK / VEC;  // chunks per row
+#pragma unroll
+        for (int c = tid; c < 64 * CPR; c += NT) {
+            const int row = c / CPR, kc = (c % CPR) * VEC;
+            const int gr = r0 + row, gk = k0 + kc;
+            vec_t v = {};
+            if (gr < R && gk < K) v = *reinterpret_cast<const vec_t*>(base + (int64_t)gr * rs + gk);  // K % VEC == 0
+            *reinterpret_cast<vec_t*>(lds + row * LDK + kc) = v;
+        }
+    } else if (mode == 2) {
+        // 16-byte chunks along rows, transposed while written
+        constexpr int CPL = 64 / VEC;  // chunks per k-line
+#pragma unroll
+        for (int c = tid; c < BK * CPL; c += NT) {
+            const int kl = c / CPL, rc = (c % CPL) * VEC;
+            const int gr = r0 + rc, gk = k0 + kl;
+            vec_t v = {};
+            if (gr < R && gk < K) v = *reinterpret_cast<const vec_t*>(base + (int64_t)gk * ks + gr);  // R % VEC == 0
+            const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) lds[(rc + i) * LDK + kl] = e[i];
+        }
+    } else {
+        for (int c = tid; c < 64 * BK; c += NT) {
+            const int row = c / BK, kk = c % BK;
+            const int gr = r0 + row, gk = k0 + kk;
+            T v = from_f32<T>(0.0f);
+            if (gr < R && gk < K) v = base[(int64_t)gr * rs + (int64_t)gk * ks];
+            lds[row * LDK + kk] = v;
+        }
+    }
+}
+
+template <typename T> __device__ __forceinline__ float act_apply(int act, float v, float aux) {
+    switch (act) {
+        case XGGM_ACT_GELU: return gelu_f(v);
+        case XGGM_ACT_SIGMOID: return sigmoid_f(v);
+        case XGGM_ACT_TANH: return tanhf(v);
+        case XGGM_ACT_GELU_GRAD: return v * gelu_grad_f(aux);
+        default: return v;
+    }
+}
+
+template <typename T> __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
+    constexpr int BK = Tile<T>::BK, LDK = Tile<T>::LDK;
+    __shared__ __attribute__((aligned(16))) T As[BM * LDK];
+    __shared__ __attribute__((aligned(16))) T Bs[BN * LDK];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = (wid >> 1) * 32, wn = (wid & 1) * 32;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, bz = blockIdx.z;
+    const T* A = reinterpret_cast<const T*>(g.A) + (int64_t)bz * g.a_bs;
+    const T* B = reinterpret_cast<const T*>(g.B) + (int64_t)bz * g.b_bs;
+
+    float4_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int k0 = 0; k0 < g.K; k0 += BK) {
+        stage_tile<T>(As, A, g.a_rs, g.a_ks, m0, k0, g.M, g.K, g.a_mode, tid);
+        stage_tile<T>(Bs, B, g.b_ns, g.b_ks, n0, k0, g.N, g.K, g.b_mode, tid);
+        __syncthreads();
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int ks = 0; ks < BK; ks += 32) {
+                short8_t a[2], b[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    a[i] = *reinterpret_cast<const short8_t*>(As + (wm + i * 16 + fr) * LDK + ks + fq * 8);
+                    b[i] = *reinterpret_cast<const short8_t*>(Bs + (wn + i * 16 + fr) * LDK + ks + fq * 8);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, a[i]),
+                            __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, b[j]), acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < BK; ks += 4) {
+                float a[2], b[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    a[i] = As[(wm + i * 16 + fr) * LDK + ks + fq];
+                    b[i] = Bs[(wn + i * 16 + fr) * LDK + ks + fq];
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg
+    const int64_t coff = (int64_t)bz * g.c_bs;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn + j * 16 + fr;
+            if (col >= g.N) continue;
+            const float bias = g.bias ? g.bias[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm + i * 16 + fq * 4 + r;
+                if (row >= g.M) continue;
+                const int64_t idx = coff + (int64_t)row * g.ldc + col;
+                float v = g.alpha * acc[i][j][r] + bias;
+                if (g.preact) reinterpret_cast<T*>(g.preact)[idx] = from_f32<T>(v);
+                float aux = 0.0f;
+                if (g.act == XGGM_ACT_GELU_GRAD) aux = to_f32(reinterpret_cast<const T*>(g.aux)[idx]);
+                if (g.act != XGGM_ACT_NONE) {
+                    // forward activations act on the value as stored (bf16-rounded pre-activation)
+                    if (g.preact) v = round_to<T>(v);
+                    v = act_apply<T>(g.act, v, aux);
+                }
+                if (g.residual) v += to_f32(reinterpret_cast<const T*>(g.residual)[idx]);
+                if (g.c_f32) {
+                    float* c = reinterpret_cast<float*>(g.C) + idx;
+                    *c = g.accumulate ? (*c + v) : v;
+                } else {
+                    T* c = reinterpret_cast<T*>(g.C) + idx;
+                    *c = from_f32<T>(g.accumulate ? (to_f32(*c) + v) : v);
+                }
+            }
+        }
+}
+
+template <typename T> int pick_mode(const void* base, int64_t rs, int64_t ks, int64_t bs, int R, int K) {
+    constexpr int VEC = Tile<T>::VEC;
+    const bool base_ok = (reinterpret_cast<uintptr_t>(base) % 16 == 0) && (bs % VEC == 0);
+    if (ks == 1 && base_ok && rs % VEC == 0 && K % VEC == 0) return 1;
+    if (rs == 1 && base_ok && ks % VEC == 0 && R % VEC == 0) return 2;
+    return 0;
+}
+
+template <typename T> int launch(GemmArgs g, int batch, hipStream_t stream) {
+    XGGM_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && batch > 0, "xggm_gemm: empty problem M=%d N=%d K=%d batch=%d", g.M, g.N,
+                 g.K, batch);
+    XGGM_REQUIRE(g.A && g.B && g.C, "xggm_gemm: null operand");
+    XGGM_REQUIRE(g.act >= 0 && g.act <= XGGM_ACT_GELU_GRAD, "xggm_gemm: bad activation %d", g.act);
+    XGGM_REQUIRE(g.act != XGGM_ACT_GELU_GRAD || g.aux, "xggm_gemm: GELU_GRAD needs aux");
+    XGGM_REQUIRE(g.ldc >= g.N, "xggm_gemm: ldc %lld < N %d", (long long)g.ldc, g.N);
+    g.a_mode = pick_mode<T>(g.A, g.a_rs, g.a_ks, g.a_bs, g.M, g.K);
+    g.b_mode = pick_mode<T>(g.B, g.b_ns, g.b_ks, g.b_bs, g.N, g.K);
+    dim3 grid(ceil_div(g.N, BN), ceil_div(g.M, BM), batch);
+    XGGM_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "xggm_gemm: grid too large");
+    hipLaunchKernelGGL(gemm_kernel<T>, grid, dim3(NT), 0, stream, g);
+    return xggm_check_launch("xggm_gemm");
+}
+
+}  // namespace
+
+#define XGGM_GEMM_IMPL(NAME, T)                                                                                        \
+    extern "C" int NAME(const void* A, const void* B, void* C, int M, int N, int K, int64_t a_rs, int64_t a_ks,       \
+                        int64_t b_ns, int64_t b_ks, int64_t ldc, int batch, int64_t a_bs, int64_t b_bs, int64_t c_bs, \
+                        const float* bias, const void* residual, void* preact, const void* aux, int act, int c_f32,   \
+                        int accumulate, float alpha, hipStream_t stream) {                                            \
+        GemmArgs g;                                                                                                    \
+        g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K;                                                          \
+        g.a_rs = a_rs; g.a_ks = a_ks; g.b_ns = b_ns; g.b_ks = b_ks; g.ldc = ldc;                                       \
+        g.a_bs = a_bs; g.b_bs = b_bs; g.c_bs = c_bs;                                                                   \
+        g.bias = bias; g.residual = residual; g.preact = preact; g.aux = aux;                                         \
+        g.act = act; g.c_f32 = c_f32; g.accumulate = accumulate; g.alpha = alpha;                                     \
+        g.a_mode = g.b_mode = 0;                                                                                       \
+        return launch<T>(g, batch, stream);                                                                            \
+    }
+
+XGGM_GEMM_IMPL(xggm_gemm_f32, float)
+XGGM_GEMM_IMPL(xggm_gemm_bf16, bf16)

@@ -1,0 +1,405 @@
+// Graph-generative kernels over the dense N x N adjacency of the object regions (N = 36,
+// 64 in the stress configuration).  Adjacency-shaped tensors are always fp32 (5-16 KB per
+// sample: they live in LDS inside the kernels and their values feed divisions, sigmoids and
+// an arg-max whose index must be exact); node features are T.
+//
+//   xggm_aggregate        out = [out +] self*x + scale * M' @ x     M' = M | M^T | M + M^T
+//                         GCNConv aggregate (src/module/gcn.py:28), GIN aggregate
+//                         (src/module/gin.py:32) and every backward-through-x of them and of
+//                         S = x x^T.  The adjacency tile is staged (transposed) in LDS, each
+//                         thread owns one feature column and keeps all N outputs in registers:
+//                         x is read from HBM once, out written once.
+//   xggm_adj_regen_fwd/bwd  column-max normalisation + sigmoid + zero diagonal of S = x x^T
+//                         (src/module/graph_generative_modeling.py:225-228); per-column max and
+//                         first-index arg-max by wave64 shuffle reduction.
+//   xggm_adj_init_fwd/bwd  encoder_adj scatter into the strict upper triangle, symmetrise, add
+//                         symmetric Gaussian noise, emit grad_log_noise
+//                         (src/vqa/vqacpv2.py:195-202 + src/module/graph_utils.py:162-168).
+//   xggm_feature_noise    src/module/graph_utils.py:144-149
+//   xggm_pool_concat_fwd/bwd  [x, tanh(mean_n nodes)]  (src/vqa/vqacpv2.py:216-218)
+#include "common.h"
+#include "xggm.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// ------------------------------------------------------------------------------- aggregate
+template <typename T, int NP>
+__global__ __launch_bounds__(NT) void aggregate_kernel(const float* __restrict__ Mx, const T* __restrict__ x, T* out, int N,
+                                                       int H, int mode, float scale, const float* scale_ptr, float self_w,
+                                                       int accumulate) {
+    __shared__ __attribute__((aligned(16))) float Mt[NP * NP];  // Mt[j][i] = M'[i][j]
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const float* Mb = Mx + (int64_t)b * N * N;
+    for (int e = tid; e < NP * NP; e += NT) {
+        const int j = e / NP, i = e % NP;
+        float v = 0.f;
+        if (i < N && j < N) {
+            if (mode == XGGM_AGG_PLAIN) v = Mb[i * N + j];
+            else if (mode == XGGM_AGG_TRANSPOSE) v = Mb[j * N + i];
+            else v = Mb[i * N + j] + Mb[j * N + i];
+        }
+        Mt[e] = v;
+    }
+    __syncthreads();
+    const int c = blockIdx.x * NT + tid;
+    if (c >= H) return;
+    if (scale_ptr) scale *= (1.0f + *scale_ptr);  // GIN: (1 + eps)
+    const T* xb = x + (int64_t)b * N * H + c;
+    float acc[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) acc[i] = 0.f;
+    for (int j = 0; j < N; ++j) {
+        const float xj = to_f32(xb[(int64_t)j * H]);
+#pragma unroll
+        for (int i = 0; i < NP; i += 4) {
+            const float4 m = *reinterpret_cast<const float4*>(Mt + j * NP + i);
+            acc[i] += m.x * xj;
+            acc[i + 1] += m.y * xj;
+            acc[i + 2] += m.z * xj;
+            acc[i + 3] += m.w * xj;
+        }
+    }
+    T* ob = out + (int64_t)b * N * H + c;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        if (i < N) {
+            float v = scale * acc[i];
+            if (self_w != 0.f) v += self_w * to_f32(xb[(int64_t)i * H]);
+            if (accumulate) v += to_f32(ob[(int64_t)i * H]);
+            ob[(int64_t)i * H] = from_f32<T>(v);
+        }
+    }
+}
+
+// d eps of GIN: sum_{b,i,c} dh[b,i,c] * (A @ x)[b,i,c]  -> one scalar (atomic)
+template <typename T, int NP>
+__global__ __launch_bounds__(NT) void agg_dot_kernel(const float* __restrict__ Mx, const T* __restrict__ x,
+                                                     const T* __restrict__ dh, float* out, int N, int H) {
+    __shared__ __attribute__((aligned(16))) float Mt[NP * NP];
+    __shared__ float red[NT / 64];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const float* Mb = Mx + (int64_t)b * N * N;
+    for (int e = tid; e < NP * NP; e += NT) {
+        const int j = e / NP, i = e % NP;
+        Mt[e] = (i < N && j < N) ? Mb[i * N + j] : 0.f;
+    }
+    __syncthreads();
+    const int c = blockIdx.x * NT + tid;
+    float total = 0.f;
+    if (c < H) {
+        const T* xb = x + (int64_t)b * N * H + c;
+        const T* db = dh + (int64_t)b * N * H + c;
+        float acc[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) acc[i] = 0.f;
+        for (int j = 0; j < N; ++j) {
+            const float xj = to_f32(xb[(int64_t)j * H]);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) acc[i] += Mt[j * NP + i] * xj;
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            if (i < N) total += acc[i] * to_f32(db[(int64_t)i * H]);
+    }
+    total = wave_sum(total);
+    if ((tid & 63) == 0) red[tid >> 6] = total;
+    __syncthreads();
+    if (tid == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+// ------------------------------------------------------------------------------- adjacency regeneration
+// one workgroup per sample; wave w owns columns w, w+4, ...
+__global__ __launch_bounds__(NT) void adj_regen_fwd_kernel(const float* __restrict__ S, float* adj, float* colmax,
+                                                           int32_t* argmax, int N) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ss = smem;       // [N][N+1]
+    float* mx = Ss + N * (N + 1);  // [N]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float* Sb = S + (int64_t)b * N * N;
+    for (int e = tid; e < N * N; e += NT) Ss[(e / N) * (N + 1) + e % N] = Sb[e];
+    __syncthreads();
+    for (int i = wid; i < N; i += NT / 64) {
+        // max over rows r of S[r][i]; torch.max(dim=1) returns the FIRST arg-max on ties
+        const float v = lane < N ? Ss[lane * (N + 1) + i] : -INFINITY;
+        const float m = wave_max(v);
+        const unsigned long long hit = __ballot(lane < N && v == m);
+        if (lane == 0) {
+            const int first = __ffsll((long long)hit) - 1;
+            mx[i] = m;
+            colmax[(int64_t)b * N + i] = m;
+            argmax[(int64_t)b * N + i] = first;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < N * N; e += NT) {
+        const int i = e / N, j = e % N;
+        adj[(int64_t)b * N * N + e] = (i == j) ? 0.f : sigmoid_f(Ss[i * (N + 1) + j] / mx[i]);
+    }
+}
+
+// dS from d_adj:  R = S[i][j]/m_i, A = sigmoid(R) off-diagonal;  dR = dA * A (1 - A);
+// dS[i][j] = dR/m_i;  dm_i = -sum_j dR[i][j] S[i][j] / m_i^2;  dS[argmax_i][i] += dm_i
+__global__ __launch_bounds__(NT) void adj_regen_bwd_kernel(const float* __restrict__ d_adj, const float* __restrict__ S,
+                                                           const float* __restrict__ adj, const float* __restrict__ colmax,
+                                                           const int32_t* __restrict__ argmax, float* dS, int N) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* D = smem;  // [N][N+1]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t ob = (int64_t)b * N * N;
+    float* dm = D + N * (N + 1);
+    for (int i = wid; i < N; i += NT / 64) {
+        const float m = colmax[(int64_t)b * N + i];
+        float part = 0.f;
+        if (lane < N) {
+            const int e = i * N + lane;
+            const float a = adj[ob + e];
+            const float dr = (lane == i) ? 0.f : d_adj[ob + e] * a * (1.f - a);
+            D[i * (N + 1) + lane] = dr / m;
+            part = dr * S[ob + e];
+        }
+        part = wave_sum(part);
+        if (lane == 0) dm[i] = -part / (m * m);
+    }
+    __syncthreads();
+    if (tid < N) {
+        const int r = argmax[(int64_t)b * N + tid];
+        D[r * (N + 1) + tid] += dm[tid];  // column tid: unique target per thread
+    }
+    __syncthreads();
+    for (int e = tid; e < N * N; e += NT) dS[ob + e] = D[(e / N) * (N + 1) + e % N];
+}
+
+// ------------------------------------------------------------------------------- adjacency init + edge noise
+// k-th strict-upper-triangle entry in row-major order: (0,1),(0,2)...(0,N-1),(1,2)...
+__host__ __device__ inline int triu_k(int i, int j, int N) { return i * N - (i * (i + 1)) / 2 + (j - i - 1); }
+
+__global__ __launch_bounds__(NT) void adj_init_fwd_kernel(const float* __restrict__ e, const float* __restrict__ randn,
+                                                          float* adj, float* gradlog, int B, int N, int NE, float sigma,
+                                                          const uint64_t* rng, uint32_t sid) {
+    const int64_t total = (int64_t)B * N * N;
+    uint64_t seed = 0, off = 0;
+    if (!randn && rng) {
+        seed = rng[0];
+        off = rng[1];
+    }
+    for (int64_t t = (int64_t)blockIdx.x * NT + threadIdx.x; t < total; t += (int64_t)gridDim.x * NT) {
+        const int b = (int)(t / (N * N)), r = (int)(t % (N * N)), i = r / N, j = r % N;
+        float a = 0.f, n = 0.f;
+        if (i != j) {
+            const int lo = min(i, j), hi = max(i, j);
+            if (e) a = e[(int64_t)b * NE + triu_k(lo, hi, N)];
+            const int64_t uidx = ((int64_t)b * N + lo) * N + hi;  // the upper-triangle draw is mirrored
+            const float z = randn ? randn[uidx] : (rng ? philox_normal(seed, off, sid, (uint64_t)uidx) : 0.f);
+            n = z * sigma;
+        }
+        adj[t] = a + n;
+        if (gradlog) gradlog[t] = -n / (sigma * sigma);
+    }
+}
+
+__global__ __launch_bounds__(NT) void adj_init_bwd_kernel(const float* __restrict__ d_adj, float* d_e, int B, int N, int NE) {
+    const int64_t total = (int64_t)B * NE;
+    for (int64_t t = (int64_t)blockIdx.x * NT + threadIdx.x; t < total; t += (int64_t)gridDim.x * NT) {
+        const int b = (int)(t / NE), k = (int)(t % NE);
+        // invert k -> (i, j): walk rows (N <= 64, trivial)
+        int i = 0, rem = k;
+        while (rem >= N - 1 - i) {
+            rem -= N - 1 - i;
+            ++i;
+        }
+        const int j = i + 1 + rem;
+        const float* g = d_adj + (int64_t)b * N * N;
+        d_e[t] = g[i * N + j] + g[j * N + i];
+    }
+}
+
+// ------------------------------------------------------------------------------- feature noise
+template <typename T>
+__global__ __launch_bounds__(NT) void feature_noise_kernel(const T* __restrict__ x, const float* __restrict__ randn, T* out,
+                                                           float* gradlog, int64_t n, float sigma, const uint64_t* rng,
+                                                           uint32_t sid) {
+    uint64_t seed = 0, off = 0;
+    if (!randn && rng) {
+        seed = rng[0];
+        off = rng[1];
+    }
+    for (int64_t t = (int64_t)blockIdx.x * NT + threadIdx.x; t < n; t += (int64_t)gridDim.x * NT) {
+        const float z = randn ? randn[t] : philox_normal(seed, off, sid, (uint64_t)t);
+        const float nz = z * sigma;
+        out[t] = from_f32<T>(to_f32(x[t]) + nz);
+        gradlog[t] = -nz / (sigma * sigma);
+    }
+}
+
+// ------------------------------------------------------------------------------- pool + concat
+// out[b, 0:H] = x[b,:];  out[b, H:2H] = tanh(mean_i nodes[b,i,:])
+template <typename T>
+__global__ __launch_bounds__(NT) void pool_concat_fwd_kernel(const T* __restrict__ x, const T* __restrict__ nodes, T* out, int B,
+                                                             int N, int H) {
+    const int b = blockIdx.y, c = blockIdx.x * NT + threadIdx.x;
+    if (c >= H) return;
+    float s = 0.f;
+    for (int i = 0; i < N; ++i) s += to_f32(nodes[((int64_t)b * N + i) * H + c]);
+    out[(int64_t)b * 2 * H + c] = x[(int64_t)b * H + c];
+    out[(int64_t)b * 2 * H + H + c] = from_f32<T>(tanhf(s / (float)N));
+}
+template <typename T>
+__global__ __launch_bounds__(NT) void pool_concat_bwd_kernel(const T* __restrict__ d_out, const T* __restrict__ out, T* dx,
+                                                             T* dnodes, int B, int N, int H, int accumulate_dx) {
+    const int b = blockIdx.y, c = blockIdx.x * NT + threadIdx.x;
+    if (c >= H) return;
+    const float g0 = to_f32(d_out[(int64_t)b * 2 * H + c]);
+    const float t = to_f32(out[(int64_t)b * 2 * H + H + c]);
+    const float g1 = to_f32(d_out[(int64_t)b * 2 * H + H + c]) * (1.f - t * t) / (float)N;
+    T* px = dx + (int64_t)b * H + c;
+    *px = from_f32<T>(accumulate_dx ? to_f32(*px) + g0 : g0);
+    const T gv = from_f32<T>(g1);
+    for (int i = 0; i < N; ++i) dnodes[((int64_t)b * N + i) * H + c] = gv;
+}
+
+// broadcast one row per sample to N node rows (x.unsqueeze(1).repeat(1, N, 1)) and its
+// backward (sum over the N rows).  node_fc is applied to the B pooled rows only and its output
+// broadcast: exactly the values the reference computes on 36 identical rows (vqacpv2.py:228-229)
+template <typename T>
+__global__ __launch_bounds__(NT) void bcast_rows_kernel(const T* __restrict__ x, T* out, int B, int N, int H) {
+    const int b = blockIdx.y, c = blockIdx.x * NT + threadIdx.x;
+    if (c >= H) return;
+    const T v = x[(int64_t)b * H + c];
+    for (int i = 0; i < N; ++i) out[((int64_t)b * N + i) * H + c] = v;
+}
+template <typename T>
+__global__ __launch_bounds__(NT) void sum_rows_kernel(const T* __restrict__ g, T* out, int B, int N, int H) {
+    const int b = blockIdx.y, c = blockIdx.x * NT + threadIdx.x;
+    if (c >= H) return;
+    float s = 0.f;
+    for (int i = 0; i < N; ++i) s += to_f32(g[((int64_t)b * N + i) * H + c]);
+    out[(int64_t)b * H + c] = from_f32<T>(s);
+}
+
+inline int grid1d(int64_t n) { return (int)std::min<int64_t>(ceil_div64(n, NT), 2048); }
+
+template <typename T>
+int aggregate(const float* M, const void* x, void* out, int B, int N, int H, int mode, float scale, const float* scale_ptr,
+              float self_w, int accumulate, hipStream_t st) {
+    XGGM_REQUIRE(M && x && out && B > 0 && N > 0 && H > 0, "xggm_aggregate: bad arguments");
+    XGGM_REQUIRE(N <= 64, "xggm_aggregate: N=%d exceeds the 64x64 LDS adjacency tile", N);
+    XGGM_REQUIRE(mode >= 0 && mode <= XGGM_AGG_SYMMETRIZE, "xggm_aggregate: bad mode %d", mode);
+    XGGM_REQUIRE(B <= 65535, "xggm_aggregate: batch too large");
+    dim3 grid(ceil_div(H, NT), B);
+    if (N <= 40)
+        hipLaunchKernelGGL((aggregate_kernel<T, 40>), grid, dim3(NT), 0, st, M, (const T*)x, (T*)out, N, H, mode, scale,
+                           scale_ptr, self_w, accumulate);
+    else
+        hipLaunchKernelGGL((aggregate_kernel<T, 64>), grid, dim3(NT), 0, st, M, (const T*)x, (T*)out, N, H, mode, scale,
+                           scale_ptr, self_w, accumulate);
+    return xggm_check_launch("xggm_aggregate");
+}
+
+template <typename T>
+int agg_dot(const float* M, const void* x, const void* dh, float* out, int B, int N, int H, hipStream_t st) {
+    XGGM_REQUIRE(M && x && dh && out && B > 0 && N > 0 && N <= 64 && H > 0 && B <= 65535, "xggm_agg_dot: bad arguments");
+    dim3 grid(ceil_div(H, NT), B);
+    if (N <= 40)
+        hipLaunchKernelGGL((agg_dot_kernel<T, 40>), grid, dim3(NT), 0, st, M, (const T*)x, (const T*)dh, out, N, H);
+    else
+        hipLaunchKernelGGL((agg_dot_kernel<T, 64>), grid, dim3(NT), 0, st, M, (const T*)x, (const T*)dh, out, N, H);
+    return xggm_check_launch("xggm_agg_dot");
+}
+
+}  // namespace
+
+extern "C" int xggm_adj_regen_fwd(const float* S, float* adj, float* colmax, int32_t* argmax, int B, int N, hipStream_t st) {
+    XGGM_REQUIRE(S && adj && colmax && argmax && B > 0 && N > 0, "xggm_adj_regen_fwd: bad arguments");
+    XGGM_REQUIRE(N <= 64, "xggm_adj_regen_fwd: N=%d > 64", N);
+    const size_t lds = sizeof(float) * (N * (N + 1) + N);
+    hipLaunchKernelGGL(adj_regen_fwd_kernel, dim3(B), dim3(NT), lds, st, S, adj, colmax, argmax, N);
+    return xggm_check_launch("xggm_adj_regen_fwd");
+}
+
+extern "C" int xggm_adj_regen_bwd(const float* d_adj, const float* S, const float* adj, const float* colmax,
+                                  const int32_t* argmax, float* dS, int B, int N, hipStream_t st) {
+    XGGM_REQUIRE(d_adj && S && adj && colmax && argmax && dS && B > 0 && N > 0, "xggm_adj_regen_bwd: bad arguments");
+    XGGM_REQUIRE(N <= 64, "xggm_adj_regen_bwd: N=%d > 64", N);
+    const size_t lds = sizeof(float) * (N * (N + 1) + N);
+    hipLaunchKernelGGL(adj_regen_bwd_kernel, dim3(B), dim3(NT), lds, st, d_adj, S, adj, colmax, argmax, dS, N);
+    return xggm_check_launch("xggm_adj_regen_bwd");
+}
+
+extern "C" int xggm_adj_init_fwd(const float* e, const float* randn, float* adj, float* gradlog, int B, int N, float sigma,
+                                 const uint64_t* rng, uint32_t sid, hipStream_t st) {
+    XGGM_REQUIRE(adj && B > 0 && N > 1 && N <= 64, "xggm_adj_init_fwd: bad arguments B=%d N=%d", B, N);
+    XGGM_REQUIRE(sigma > 0.f, "xggm_adj_init_fwd: sigma must be > 0");
+    hipLaunchKernelGGL(adj_init_fwd_kernel, dim3(grid1d((int64_t)B * N * N)), dim3(NT), 0, st, e, randn, adj, gradlog, B, N,
+                       N * (N - 1) / 2, sigma, rng, sid);
+    return xggm_check_launch("xggm_adj_init_fwd");
+}
+
+extern "C" int xggm_adj_init_bwd(const float* d_adj, float* d_e, int B, int N, hipStream_t st) {
+    XGGM_REQUIRE(d_adj && d_e && B > 0 && N > 1 && N <= 64, "xggm_adj_init_bwd: bad arguments");
+    const int NE = N * (N - 1) / 2;
+    hipLaunchKernelGGL(adj_init_bwd_kernel, dim3(grid1d((int64_t)B * NE)), dim3(NT), 0, st, d_adj, d_e, B, N, NE);
+    return xggm_check_launch("xggm_adj_init_bwd");
+}
+
+extern "C" int xggm_triu_index(int k, int N, int* i_out, int* j_out) {
+    // host helper exposing the index map used by the kernels (bit-exactness tests)
+    XGGM_REQUIRE(N > 1 && k >= 0 && k < N * (N - 1) / 2 && i_out && j_out, "xggm_triu_index: bad arguments");
+    int i = 0, rem = k;
+    while (rem >= N - 1 - i) {
+        rem -= N - 1 - i;
+        ++i;
+    }
+    *i_out = i;
+    *j_out = i + 1 + rem;
+    return (triu_k(*i_out, *j_out, N) == k) ? XGGM_OK : XGGM_ERR_ARG;
+}
+
+#define GRAPH_API(SUF, T)                                                                                                  \
+    extern "C" int xggm_aggregate_##SUF(const float* M, const void* x, void* out, int B, int N, int H, int mode,          \
+                                        float scale, const float* scale_ptr, float self_w, int accumulate,               \
+                                        hipStream_t st) {                                                                 \
+        return aggregate<T>(M, x, out, B, N, H, mode, scale, scale_ptr, self_w, accumulate, st);                          \
+    }                                                                                                                      \
+    extern "C" int xggm_agg_dot_##SUF(const float* M, const void* x, const void* dh, float* out, int B, int N, int H,     \
+                                      hipStream_t st) {                                                                   \
+        return agg_dot<T>(M, x, dh, out, B, N, H, st);                                                                    \
+    }                                                                                                                      \
+    extern "C" int xggm_feature_noise_##SUF(const void* x, const float* randn, void* out, float* gradlog, int64_t n,      \
+                                            float sigma, const uint64_t* rng, uint32_t sid, hipStream_t st) {             \
+        XGGM_REQUIRE(x && out && gradlog && n > 0 && sigma > 0.f && (randn || rng), "xggm_feature_noise: bad arguments"); \
+        hipLaunchKernelGGL((feature_noise_kernel<T>), dim3(grid1d(n)), dim3(NT), 0, st, (const T*)x, randn, (T*)out,      \
+                           gradlog, n, sigma, rng, sid);                                                                  \
+        return xggm_check_launch("xggm_feature_noise");                                                                   \
+    }                                                                                                                      \
+    extern "C" int xggm_pool_concat_fwd_##SUF(const void* x, const void* nodes, void* out, int B, int N, int H,           \
+                                              hipStream_t st) {                                                           \
+        XGGM_REQUIRE(x && nodes && out && B > 0 && B <= 65535 && N > 0 && H > 0, "xggm_pool_concat_fwd: bad arguments");  \
+        hipLaunchKernelGGL((pool_concat_fwd_kernel<T>), dim3(ceil_div(H, NT), B), dim3(NT), 0, st, (const T*)x,           \
+                           (const T*)nodes, (T*)out, B, N, H);                                                            \
+        return xggm_check_launch("xggm_pool_concat_fwd");                                                                 \
+    }                                                                                                                      \
+    extern "C" int xggm_pool_concat_bwd_##SUF(const void* d_out, const void* out, void* dx, void* dnodes, int B, int N,   \
+                                              int H, int accumulate_dx, hipStream_t st) {                                 \
+        XGGM_REQUIRE(d_out && out && dx && dnodes && B > 0 && B <= 65535 && N > 0 && H > 0,                               \
+                     "xggm_pool_concat_bwd: bad arguments");                                                              \
+        hipLaunchKernelGGL((pool_concat_bwd_kernel<T>), dim3(ceil_div(H, NT), B), dim3(NT), 0, st, (const T*)d_out,       \
+                           (const T*)out, (T*)dx, (T*)dnodes, B, N, H, accumulate_dx);                                    \
+        return xggm_check_launch("xggm_pool_concat_bwd");                                                                 \
+    }                                                                                                                      \
+    extern "C" int xggm_bcast_rows_##SUF(const void* x, void* out, int B, int N, int H, hipStream_t st) {                 \
+        XGGM_REQUIRE(x && out && B > 0 && B <= 65535 && N > 0 && H > 0, "xggm_bcast_rows: bad arguments");                \
+        hipLaunchKernelGGL((bcast_rows_kernel<T>), dim3(ceil_div(H, NT), B), dim3(NT), 0, st, (const T*)x, (T*)out, B, N, \
+                           H);                                                                                            \
+        return xggm_check_launch("xggm_bcast_rows");                                                                      \
+    }                                                                                                                      \
+    extern "C" int xggm_sum_rows_##SUF(const void* g, void* out, int B, int N, int H, hipStream_t st) {                   \
+        XGGM_REQUIRE(g && out && B > 0 && B <= 65535 && N > 0 && H > 0, "xggm_sum_rows: bad arguments");                   \
+        hipLaunchKernelGGL((sum_rows_kernel<T>), dim3(ceil_div(H, NT), B), dim3(NT), 0, st, (const T*)g, (T*)out, B, N,   \
+                           H);                                                                                            \
+        return xggm_check_launch("xggm_sum_rows");                                                                        \
+    }
+
+GRAPH_API(f32, float)
+GRAPH_API(bf16, bf16)

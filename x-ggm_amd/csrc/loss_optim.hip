@@ -1,0 +1,365 @@
+// Loss kernels and the fused optimiser.
+//   xggm_dsm_loss_fwd/bwd   denoising score matching  (src/vqa/vqacpv2.py:48-51)
+//   xggm_symkl_fwd/bwd      symmetric KL of row softmaxes (src/vqa/vqacpv2.py:54-61)
+//   xggm_bce_fwd/bwd        BCEWithLogits(mean) * A   (src/vqa/vqacpv2.py:131,173)
+//   xggm_sqnorm_f32         sum of squares of a flat fp32 gradient range (clip_grad_norm_, vqacpv2.py:175)
+//   xggm_bertadam_f32       clip-scale + BertAdam update + bf16 shadow weight, ONE pass over
+//                           p/g/m/v (src/lxrt/optimization.py:159-193): 16 B read + 12(+2) B
+//                           written per parameter, the HBM floor of the update.
+//   xggm_sched_step         warmup_linear(step/t_total) on the device-resident step counter
+//                           (optimization.py:42-48,177-181) so a captured graph replays correctly
+// Scalars (losses, norms, schedule values, upstream gradients) live in device memory: nothing
+// here synchronises with the host.
+#include "common.h"
+#include "xggm.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ float block_sum(float v) {
+    __shared__ float red[NT / 64];
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+inline int grid1d(int64_t n, int cap = 1024) { return (int)std::min<int64_t>(ceil_div64(n, NT), cap); }
+
+// ------------------------------------------------------------------------------- DSM
+template <typename T>
+__global__ __launch_bounds__(NT) void dsm_fwd_kernel(const T* __restrict__ s, const float* __restrict__ g, float* loss,
+                                                     int64_t n, float coef) {
+    float acc = 0.f;
+    for (int64_t t = (int64_t)blockIdx.x * NT + threadIdx.x; t < n; t += (int64_t)gridDim.x * NT) {
+        const float d = to_f32(s[t]) - g[t];
+        acc += d * d;
+    }
+    acc = block_sum(acc);
+    if (threadIdx.x == 0) atomicAdd(loss, acc * coef);
+}
+template <typename T>
+__global__ __launch_bounds__(NT) void dsm_bwd_kernel(const T* __restrict__ s, const float* __restrict__ g,
+                                                     const float* __restrict__ gout, T* ds, int64_t n, float coef) {
+    const float k = 2.f * coef * (gout ? *gout : 1.f);
+    for (int64_t t = (int64_t)blockIdx.x * NT + threadIdx.x; t < n; t += (int64_t)gridDim.x * NT)
+        ds[t] = from_f32<T>(k * (to_f32(s[t]) - g[t]));
+}
+
+// ------------------------------------------------------------------------------- symmetric KL
+// per row: f = sum_c (px - py)(lpx - lpy);  df/dx_k = px_k (u_k - <u>_px) + w_k,
+// df/dy_k = -py_k (u_k - <u>_py) - w_k  with u = lpx - lpy, w = px - py.
+template <typename T, int NV>
+__global__ __launch_bounds__(NT) void symkl_kernel(const T* __restrict__ x, const T* __restrict__ y, float* loss,
+                                                   const float* __restrict__ gout, T* dx, T* dy, int rows, int W, float coef,
+                                                   int accumulate) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const float gk = coef * ((dx || dy) && gout ? *gout : 1.f);
+    float total = 0.f;
+    for (int row = blockIdx.x * 4 + wid; row < rows; row += gridDim.x * 4) {
+        const int64_t rb = (int64_t)row * W;
+        float xv[NV], yv[NV];
+        float mx = -INFINITY, my = -INFINITY;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c = v * 64 + lane;
+            xv[v] = c < W ? to_f32(x[rb + c]) : -INFINITY;
+            yv[v] = c < W ? to_f32(y[rb + c]) : -INFINITY;
+            mx = fmaxf(mx, xv[v]);
+            my = fmaxf(my, yv[v]);
+        }
+        mx = wave_max(mx);
+        my = wave_max(my);
+        float sx = 0.f, sy = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c = v * 64 + lane;
+            if (c < W) {
+                sx += __expf(xv[v] - mx);
+                sy += __expf(yv[v] - my);
+            }
+        }
+        const float lx = mx + __logf(wave_sum(sx)), ly = my + __logf(wave_sum(sy));
+        float f = 0.f, upx = 0.f, upy = 0.f;
+        float u[NV], px[NV], py[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c = v * 64 + lane;
+            u[v] = px[v] = py[v] = 0.f;
+            if (c < W) {
+                const float lpx = xv[v] - lx, lpy = yv[v] - ly;
+                px[v] = __expf(lpx);
+                py[v] = __expf(lpy);
+                u[v] = lpx - lpy;
+                f += (px[v] - py[v]) * u[v];
+                upx += px[v] * u[v];
+                upy += py[v] * u[v];
+            }
+        }
+        total += f;  // lane partial; reduced once per block below
+        if (dx || dy) {
+            upx = wave_sum(upx);
+            upy = wave_sum(upy);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int c = v * 64 + lane;
+                if (c < W) {
+                    const float w = px[v] - py[v];
+                    if (dx) {
+                        float gx = gk * (px[v] * (u[v] - upx) + w);
+                        if (accumulate) gx += to_f32(dx[rb + c]);
+                        dx[rb + c] = from_f32<T>(gx);
+                    }
+                    if (dy) {
+                        float gy = gk * (-py[v] * (u[v] - upy) - w);
+                        if (accumulate) gy += to_f32(dy[rb + c]);
+                        dy[rb + c] = from_f32<T>(gy);
+                    }
+                }
+            }
+        }
+    }
+    if (loss) {
+        total = block_sum(total);
+        if (threadIdx.x == 0) atomicAdd(loss, total * coef);
+    }
+}
+
+// ------------------------------------------------------------------------------- BCE with logits
+__global__ __launch_bounds__(NT) void bce_fwd_kernel(const float* __restrict__ l, const float* __restrict__ t, float* loss,
+                                                     int64_t n, float coef) {
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const float z = l[i];
+        acc += fmaxf(z, 0.f) - z * t[i] + log1pf(__expf(-fabsf(z)));
+    }
+    acc = block_sum(acc);
+    if (threadIdx.x == 0) atomicAdd(loss, acc * coef);
+}
+template <typename T>
+__global__ __launch_bounds__(NT) void bce_bwd_kernel(const float* __restrict__ l, const float* __restrict__ t,
+                                                     const float* __restrict__ gout, T* dl, int64_t n, float coef) {
+    const float k = coef * (gout ? *gout : 1.f);
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT)
+        dl[i] = from_f32<T>(k * (sigmoid_f(l[i]) - t[i]));
+}
+
+// ------------------------------------------------------------------------------- optimiser
+__global__ __launch_bounds__(NT) void sqnorm_kernel(const float* __restrict__ g, int64_t n, float* out) {
+    float acc = 0.f;
+    const int64_t n4 = n >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT) {
+        const float4 v = g4[i];
+        acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const float v = g[(n4 << 2) + threadIdx.x];
+        acc += v * v;
+    }
+    acc = block_sum(acc);
+    if (threadIdx.x == 0) atomicAdd(out, acc);
+}
+
+struct AdamArgs {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    bf16* shadow;
+    int64_t n;
+    const float* sqnorm;    // device scalar: sum of squares over ALL grads of the step (or null)
+    float max_norm;
+    float lr;
+    const float* lr_scale;  // device scalar from xggm_sched_step (or null = 1)
+    float b1, b2, eps, wd;
+};
+
+__global__ __launch_bounds__(NT) void bertadam_kernel(AdamArgs a) {
+    float coef = 1.f;
+    if (a.sqnorm) {
+        const float total = sqrtf(*a.sqnorm);
+        coef = fminf(a.max_norm / (total + 1e-6f), 1.f);  // torch.nn.utils.clip_grad_norm_
+    }
+    const float lr = a.lr * (a.lr_scale ? *a.lr_scale : 1.f);
+    const int64_t n4 = a.n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT) {
+        float4 p = reinterpret_cast<float4*>(a.p)[i];
+        const float4 g = reinterpret_cast<const float4*>(a.g)[i];
+        float4 m = reinterpret_cast<float4*>(a.m)[i];
+        float4 v = reinterpret_cast<float4*>(a.v)[i];
+        float* pp = &p.x;
+        const float* gg = &g.x;
+        float* mm = &m.x;
+        float* vv = &v.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = gg[k] * coef;
+            mm[k] = mm[k] * a.b1 + (1.f - a.b1) * gk;
+            vv[k] = vv[k] * a.b2 + (1.f - a.b2) * gk * gk;
+            const float u = mm[k] / (sqrtf(vv[k]) + a.eps) + a.wd * pp[k];
+            pp[k] -= lr * u;
+        }
+        reinterpret_cast<float4*>(a.p)[i] = p;
+        reinterpret_cast<float4*>(a.m)[i] = m;
+        reinterpret_cast<float4*>(a.v)[i] = v;
+        if (a.shadow) {
+            bf16x4 s;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s.v[k] = __float2bfloat16(pp[k]);
+            reinterpret_cast<bf16x4*>(a.shadow)[i] = s;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        const float gk = a.g[i] * coef;
+        const float m = a.m[i] * a.b1 + (1.f - a.b1) * gk;
+        const float v = a.v[i] * a.b2 + (1.f - a.b2) * gk * gk;
+        const float p = a.p[i] - lr * (m / (sqrtf(v) + a.eps) + a.wd * a.p[i]);
+        a.m[i] = m;
+        a.v[i] = v;
+        a.p[i] = p;
+        if (a.shadow) a.shadow[i] = __float2bfloat16(p);
+    }
+}
+
+// lr_scale = warmup_linear(step / t_total, warmup); step += 1   (t_total <= 0: scale = 1)
+__global__ void sched_kernel(int64_t* step, float* lr_scale, int64_t t_total, float warmup) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int64_t s = *step;
+    float sc = 1.f;
+    if (t_total > 0) {
+        const float x = (float)((double)s / (double)t_total);
+        sc = x < warmup ? x / warmup : fmaxf((x - 1.f) / (warmup - 1.f), 0.f);
+    }
+    *lr_scale = sc;
+    *step = s + 1;
+}
+
+__global__ void rng_advance_kernel(uint64_t* rng, uint64_t by) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) rng[1] += by;
+}
+
+__global__ __launch_bounds__(NT) void cast_bf16_kernel(const float* __restrict__ x, bf16* out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT)
+        out[i] = __float2bfloat16(x[i]);
+}
+
+__global__ __launch_bounds__(NT) void dropout_mask_kernel(float* out, int64_t n, float p, const uint64_t* rng, uint32_t sid) {
+    const float ik = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT)
+        out[i] = p > 0.f ? dropout_scale(p, ik, rng[0], rng[1], sid, (uint64_t)i) : 1.f;
+}
+
+__global__ __launch_bounds__(NT) void normal_kernel(float* out, int64_t n, const uint64_t* rng, uint32_t sid) {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT)
+        out[i] = philox_normal(rng[0], rng[1], sid, (uint64_t)i);
+}
+
+template <typename T>
+int symkl(const void* x, const void* y, float* loss, const float* gout, void* dx, void* dy, int rows, int W, float coef,
+          int accumulate, hipStream_t st) {
+    XGGM_REQUIRE(x && y && rows > 0 && W > 0, "xggm_symkl: bad arguments");
+    XGGM_REQUIRE(W <= 64 * 16, "xggm_symkl: row width %d > 1024", W);
+    XGGM_REQUIRE(loss || dx || dy, "xggm_symkl: nothing to compute");
+    const int grid = std::min(ceil_div(rows, 4), 1024);
+    const int nv = ceil_div(W, 64);
+#define SYMKL_LAUNCH(NV)                                                                                               \
+    hipLaunchKernelGGL((symkl_kernel<T, NV>), dim3(grid), dim3(NT), 0, st, (const T*)x, (const T*)y, loss, gout, (T*)dx, \
+                       (T*)dy, rows, W, coef, accumulate)
+    if (nv <= 1) SYMKL_LAUNCH(1);
+    else if (nv <= 2) SYMKL_LAUNCH(2);
+    else if (nv <= 4) SYMKL_LAUNCH(4);
+    else if (nv <= 8) SYMKL_LAUNCH(8);
+    else if (nv <= 12) SYMKL_LAUNCH(12);
+    else SYMKL_LAUNCH(16);
+#undef SYMKL_LAUNCH
+    return xggm_check_launch("xggm_symkl");
+}
+
+}  // namespace
+
+#define LOSS_API(SUF, T)                                                                                                   \
+    extern "C" int xggm_dsm_loss_fwd_##SUF(const void* s, const float* g, float* loss, int64_t n, float coef,             \
+                                           hipStream_t st) {                                                              \
+        XGGM_REQUIRE(s && g && loss && n > 0, "xggm_dsm_loss_fwd: bad arguments");                                         \
+        hipLaunchKernelGGL((dsm_fwd_kernel<T>), dim3(grid1d(n)), dim3(NT), 0, st, (const T*)s, g, loss, n, coef);         \
+        return xggm_check_launch("xggm_dsm_loss_fwd");                                                                    \
+    }                                                                                                                      \
+    extern "C" int xggm_dsm_loss_bwd_##SUF(const void* s, const float* g, const float* gout, void* ds, int64_t n,         \
+                                           float coef, hipStream_t st) {                                                  \
+        XGGM_REQUIRE(s && g && ds && n > 0, "xggm_dsm_loss_bwd: bad arguments");                                           \
+        hipLaunchKernelGGL((dsm_bwd_kernel<T>), dim3(grid1d(n)), dim3(NT), 0, st, (const T*)s, g, gout, (T*)ds, n, coef); \
+        return xggm_check_launch("xggm_dsm_loss_bwd");                                                                    \
+    }                                                                                                                      \
+    extern "C" int xggm_symkl_##SUF(const void* x, const void* y, float* loss, const float* gout, void* dx, void* dy,     \
+                                    int rows, int W, float coef, int accumulate, hipStream_t st) {                        \
+        return symkl<T>(x, y, loss, gout, dx, dy, rows, W, coef, accumulate, st);                                         \
+    }                                                                                                                      \
+    extern "C" int xggm_bce_bwd_##SUF(const float* l, const float* t, const float* gout, void* dl, int64_t n, float coef, \
+                                      hipStream_t st) {                                                                   \
+        XGGM_REQUIRE(l && t && dl && n > 0, "xggm_bce_bwd: bad arguments");                                                \
+        hipLaunchKernelGGL((bce_bwd_kernel<T>), dim3(grid1d(n)), dim3(NT), 0, st, l, t, gout, (T*)dl, n, coef);           \
+        return xggm_check_launch("xggm_bce_bwd");                                                                         \
+    }
+
+LOSS_API(f32, float)
+LOSS_API(bf16, bf16)
+
+extern "C" int xggm_bce_fwd(const float* l, const float* t, float* loss, int64_t n, float coef, hipStream_t st) {
+    XGGM_REQUIRE(l && t && loss && n > 0, "xggm_bce_fwd: bad arguments");
+    hipLaunchKernelGGL(bce_fwd_kernel, dim3(grid1d(n)), dim3(NT), 0, st, l, t, loss, n, coef);
+    return xggm_check_launch("xggm_bce_fwd");
+}
+
+extern "C" int xggm_sqnorm_f32(const float* g, int64_t n, float* out, hipStream_t st) {
+    XGGM_REQUIRE(g && out && n > 0, "xggm_sqnorm_f32: bad arguments");
+    XGGM_REQUIRE(reinterpret_cast<uintptr_t>(g) % 16 == 0, "xggm_sqnorm_f32: pointer must be 16-byte aligned");
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(grid1d(n / 4 + 1, 2048)), dim3(NT), 0, st, g, n, out);
+    return xggm_check_launch("xggm_sqnorm_f32");
+}
+
+extern "C" int xggm_bertadam_f32(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n,
+                                 const float* sqnorm, float max_norm, float lr, const float* lr_scale, float b1, float b2,
+                                 float eps, float weight_decay, hipStream_t st) {
+    XGGM_REQUIRE(p && g && m && v && n > 0, "xggm_bertadam_f32: bad arguments");
+    XGGM_REQUIRE((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                  reinterpret_cast<uintptr_t>(v)) % 16 == 0,
+                 "xggm_bertadam_f32: pointers must be 16-byte aligned");
+    XGGM_REQUIRE(!shadow_bf16 || reinterpret_cast<uintptr_t>(shadow_bf16) % 8 == 0, "xggm_bertadam_f32: shadow misaligned");
+    AdamArgs a{p, g, m, v, (bf16*)shadow_bf16, n, sqnorm, max_norm, lr, lr_scale, b1, b2, eps, weight_decay};
+    hipLaunchKernelGGL(bertadam_kernel, dim3(grid1d(n / 4 + 1, 4096)), dim3(NT), 0, st, a);
+    return xggm_check_launch("xggm_bertadam_f32");
+}
+
+extern "C" int xggm_sched_step(int64_t* step, float* lr_scale, int64_t t_total, float warmup, hipStream_t st) {
+    XGGM_REQUIRE(step && lr_scale, "xggm_sched_step: null pointer");
+    hipLaunchKernelGGL(sched_kernel, dim3(1), dim3(64), 0, st, step, lr_scale, t_total, warmup);
+    return xggm_check_launch("xggm_sched_step");
+}
+
+extern "C" int xggm_rng_advance(uint64_t* rng, uint64_t by, hipStream_t st) {
+    XGGM_REQUIRE(rng, "xggm_rng_advance: null pointer");
+    hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, st, rng, by);
+    return xggm_check_launch("xggm_rng_advance");
+}
+
+extern "C" int xggm_cast_f32_to_bf16(const float* x, void* out, int64_t n, hipStream_t st) {
+    XGGM_REQUIRE(x && out && n > 0, "xggm_cast_f32_to_bf16: bad arguments");
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid1d(n, 4096)), dim3(NT), 0, st, x, (bf16*)out, n);
+    return xggm_check_launch("xggm_cast_f32_to_bf16");
+}
+
+extern "C" int xggm_dropout_mask(float* out, int64_t n, float p, const uint64_t* rng, uint32_t sid, hipStream_t st) {
+    XGGM_REQUIRE(out && n > 0 && p >= 0.f && p < 1.f && (p == 0.f || rng), "xggm_dropout_mask: bad arguments");
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid1d(n)), dim3(NT), 0, st, out, n, p, rng, sid);
+    return xggm_check_launch("xggm_dropout_mask");
+}
+
+extern "C" int xggm_normal(float* out, int64_t n, const uint64_t* rng, uint32_t sid, hipStream_t st) {
+    XGGM_REQUIRE(out && n > 0 && rng, "xggm_normal: bad arguments");
+    hipLaunchKernelGGL(normal_kernel, dim3(grid1d(n)), dim3(NT), 0, st, out, n, rng, sid);
+    return xggm_check_launch("xggm_normal");
+}

@@ -1,0 +1,693 @@
+// Row kernels: everything on the path that normalises a row of H features.
+//   xggm_ln_fwd/bwd        out = [out +] s * drop_post( LN( drop_pre(in + bias) + residual ) )
+//                          = BertAttOutput / BertOutput (src/lxrt/modeling.py:384-388, 441-445),
+//                            GCNConv's LN (src/module/gcn.py:29), the "GeLU -> LN" tails of the heads and
+//                            GNN read-outs incl. their dropout(.5) and jump-knowledge sum (gcn.py:70-77)
+//   xggm_embed_fwd/bwd     BertEmbeddings (modeling.py:298-313): 3 gathers + LN + dropout
+//   xggm_visn_embed_fwd/bwd VisualFeatEncoder tail (modeling.py:546-556): (LN(u+b) + LN(W_b box + b_b))/2, dropout
+// One wave64 per row, 4 rows per 256-thread workgroup, 16-byte accesses, fp32 math, wave
+// shuffle reductions; the row stays in registers between the statistics and the output pass,
+// so HBM traffic is one read of each input and one write of each output.
+#include "common.h"
+#include "xggm.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int WPB = 4;  // waves (rows in flight) per block
+
+struct DropArgs {
+    float p_pre, p_post;
+    const uint64_t* rng;
+    uint32_t s_pre, s_post;
+};
+
+__device__ __forceinline__ void rng_load(const uint64_t* rng, uint64_t& seed, uint64_t& off) {
+    seed = rng ? rng[0] : 0;
+    off = rng ? rng[1] : 0;
+}
+
+// ------------------------------------------------------------------------------- LN fwd
+template <typename T, int NV>
+__global__ __launch_bounds__(NT) void ln_fwd_kernel(const T* in, const float* __restrict__ bias,
+                                                    const T* __restrict__ residual, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, T* out, T* z_out, float* stats, int M,
+                                                    int H, float eps, DropArgs d, int accumulate, float out_scale) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint64_t seed, off;
+    rng_load(d.rng, seed, off);
+    const float ik_pre = d.p_pre > 0.f ? 1.f / (1.f - d.p_pre) : 1.f;
+    const float ik_post = d.p_post > 0.f ? 1.f / (1.f - d.p_post) : 1.f;
+    for (int row = blockIdx.x * WPB + wid; row < M; row += gridDim.x * WPB) {
+        const int64_t rb = (int64_t)row * H;
+        float z[NV][4];
+        float sum = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            if (c < H) {
+                load4(in + rb + c, z[v]);
+                if (bias) {
+                    float b4[4];
+                    load4(bias + c, b4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) z[v][i] += b4[i];
+                }
+                if (d.p_pre > 0.f) {
+                    float s4[4];
+                    dropout_scale4(d.p_pre, ik_pre, seed, off, d.s_pre, (uint64_t)(rb + c), s4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) z[v][i] *= s4[i];
+                }
+                if (residual) {
+                    float r4[4];
+                    load4(residual + rb + c, r4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) z[v][i] += r4[i];
+                }
+                if (z_out) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) z[v][i] = round_to<T>(z[v][i]);
+                    store4(z_out + rb + c, z[v]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sum += z[v][i];
+            }
+        }
+        const float mean = wave_sum(sum) / (float)H;
+        float var = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            if (c < H) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float t = z[v][i] - mean;
+                    var += t * t;
+                }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(var) / (float)H + eps);
+        if (stats && lane == 0) {
+            stats[2 * row] = mean;
+            stats[2 * row + 1] = rstd;
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            if (c < H) {
+                float g4[4], b4[4], y[4];
+                load4(gamma + c, g4);
+                load4(beta + c, b4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) y[i] = (z[v][i] - mean) * rstd * g4[i] + b4[i];
+                if (d.p_post > 0.f) {
+                    float s4[4];
+                    dropout_scale4(d.p_post, ik_post, seed, off, d.s_post, (uint64_t)(rb + c), s4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) y[i] *= s4[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) y[i] *= out_scale;
+                if (accumulate) {
+                    float o4[4];
+                    load4(out + rb + c, o4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) y[i] += o4[i];
+                }
+                store4(out + rb + c, y);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------- LN bwd
+// dy: gradient w.r.t. `out`.  Produces d_in (grad of `in`, i.e. through drop_pre), d_res
+// (grad of `residual`), and accumulates dgamma / dbeta / dbias (bias of `in`) with one fp32
+// atomic per column per wave after an in-register partial sum over the wave's rows.
+template <typename T, int NV>
+__global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ z,
+                                                    const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                    T* d_in, T* d_res, float* dgamma, float* dbeta, float* dbias, int M, int H,
+                                                    DropArgs d, float out_scale, int accumulate_dres) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint64_t seed, off;
+    rng_load(d.rng, seed, off);
+    const float ik_pre = d.p_pre > 0.f ? 1.f / (1.f - d.p_pre) : 1.f;
+    const float ik_post = d.p_post > 0.f ? 1.f / (1.f - d.p_post) : 1.f;
+    float pg[NV][4], pb[NV][4], pbias[NV][4], g4[NV][4];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int c = (v * 64 + lane) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pg[v][i] = pb[v][i] = pbias[v][i] = 0.f;
+        if (c < H) load4(gamma + c, g4[v]);
+    }
+    for (int row = blockIdx.x * WPB + wid; row < M; row += gridDim.x * WPB) {
+        const int64_t rb = (int64_t)row * H;
+        const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+        float dyn[NV][4], xh[NV][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            if (c < H) {
+                float zz[4];
+                load4(dy + rb + c, dyn[v]);
+                load4(z + rb + c, zz);
+                if (d.p_post > 0.f) {
+                    float s4[4];
+                    dropout_scale4(d.p_post, ik_post, seed, off, d.s_post, (uint64_t)(rb + c), s4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dyn[v][i] *= s4[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    dyn[v][i] *= out_scale;
+                    xh[v][i] = (zz[i] - mean) * rstd;
+                    pg[v][i] += dyn[v][i] * xh[v][i];
+                    pb[v][i] += dyn[v][i];
+                    const float t = dyn[v][i] * g4[v][i];
+                    s1 += t;
+                    s2 += t * xh[v][i];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)H;
+        s2 = wave_sum(s2) / (float)H;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            if (c < H) {
+                float dz[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dz[i] = rstd * (dyn[v][i] * g4[v][i] - s1 - xh[v][i] * s2);
+                if (d_res) {
+                    if (accumulate_dres) {
+                        float o4[4], w4[4];
+                        load4(d_res + rb + c, o4);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) w4[i] = o4[i] + dz[i];
+                        store4(d_res + rb + c, w4);
+                    } else {
+                        store4(d_res + rb + c, dz);
+                    }
+                }
+                if (d.p_pre > 0.f) {
+                    float s4[4];
+                    dropout_scale4(d.p_pre, ik_pre, seed, off, d.s_pre, (uint64_t)(rb + c), s4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dz[i] *= s4[i];
+                }
+                if (d_in) store4(d_in + rb + c, dz);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pbias[v][i] += dz[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int c = (v * 64 + lane) * 4;
+        if (c < H) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (dgamma) atomicAdd(dgamma + c + i, pg[v][i]);
+                if (dbeta) atomicAdd(dbeta + c + i, pb[v][i]);
+                if (dbias) atomicAdd(dbias + c + i, pbias[v][i]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------- embeddings
+template <typename T, int NV>
+__global__ __launch_bounds__(NT) void embed_fwd_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ seg,
+                                                       const T* __restrict__ word, const T* __restrict__ pos,
+                                                       const T* __restrict__ type, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, T* out, T* z_out, float* stats, int M,
+                                                       int Tlen, int H, float eps, DropArgs d) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint64_t seed, off;
+    rng_load(d.rng, seed, off);
+    const float ik_post = d.p_post > 0.f ? 1.f / (1.f - d.p_post) : 1.f;
+    for (int row = blockIdx.x * WPB + wid; row < M; row += gridDim.x * WPB) {
+        const int64_t rb = (int64_t)row * H;
+        const int64_t wi = ids[row], pi = row % Tlen, ti = seg ? seg[row] : 0;
+        float z[NV][4];
+        float sum = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            if (c < H) {
+                float a[4], b[4], e[4];
+                load4(word + wi * H + c, a);
+                load4(pos + pi * H + c, b);
+                load4(type + ti * H + c, e);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    z[v][i] = round_to<T>(a[i] + b[i] + e[i]);
+                    sum += z[v][i];
+                }
+                store4(z_out + rb + c, z[v]);
+            }
+        }
+        const float mean = wave_sum(sum) / (float)H;
+        float var = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            if (c < H) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float t = z[v][i] - mean;
+                    var += t * t;
+                }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(var) / (float)H + eps);
+        if (lane == 0) {
+            stats[2 * row] = mean;
+            stats[2 * row + 1] = rstd;
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            if (c < H) {
+                float g4[4], b4[4], y[4];
+                load4(gamma + c, g4);
+                load4(beta + c, b4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) y[i] = (z[v][i] - mean) * rstd * g4[i] + b4[i];
+                if (d.p_post > 0.f) {
+                    float s4[4];
+                    dropout_scale4(d.p_post, ik_post, seed, off, d.s_post, (uint64_t)(rb + c), s4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) y[i] *= s4[i];
+                }
+                store4(out + rb + c, y);
+            }
+        }
+    }
+}
+
+// scatter-add of dz rows into the three fp32 embedding gradients; row 0 of every table is
+// nn.Embedding's padding_idx and never receives gradient (modeling.py:284-290).
+template <typename T>
+__global__ __launch_bounds__(NT) void embed_scatter_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ seg,
+                                                           const T* __restrict__ dz, float* dword, float* dpos, float* dtype,
+                                                           int M, int Tlen, int H) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int row = blockIdx.x * WPB + wid; row < M; row += gridDim.x * WPB) {
+        const int64_t wi = ids[row], pi = row % Tlen, ti = seg ? seg[row] : 0;
+        for (int c = lane; c < H; c += 64) {
+            const float g = to_f32(dz[(int64_t)row * H + c]);
+            if (wi != 0) atomicAdd(dword + wi * H + c, g);
+            if (pi != 0) atomicAdd(dpos + pi * H + c, g);
+            if (ti != 0) atomicAdd(dtype + ti * H + c, g);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------- visual embedding
+// u = feat @ W_f^T comes from the GEMM (no bias); this kernel adds b_f, normalises, computes
+// the K = 4 box projection in registers, normalises it, averages and applies dropout.
+// Saved for backward: z1 = u + b_f (T, over u in place), z2 = box projection (T), stats [M,4].
+template <typename T, int NV>
+__global__ __launch_bounds__(NT) void visn_embed_fwd_kernel(const T* u, const float* __restrict__ bf,
+                                                            const T* __restrict__ boxes, const float* __restrict__ Wb,
+                                                            const float* __restrict__ bb, const float* __restrict__ g1,
+                                                            const float* __restrict__ b1, const float* __restrict__ g2,
+                                                            const float* __restrict__ b2, T* out, T* z1_out, T* z2_out,
+                                                            float* stats, int M, int H, float eps, DropArgs d) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint64_t seed, off;
+    rng_load(d.rng, seed, off);
+    const float ik_post = d.p_post > 0.f ? 1.f / (1.f - d.p_post) : 1.f;
+    for (int row = blockIdx.x * WPB + wid; row < M; row += gridDim.x * WPB) {
+        const int64_t rb = (int64_t)row * H;
+        float bx[4];
+        load4(boxes + (int64_t)row * 4, bx);
+        float z1[NV][4], z2[NV][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            if (c < H) {
+                float f4[4], bb4[4];
+                load4(u + rb + c, z1[v]);
+                load4(bf + c, f4);
+                load4(bb + c, bb4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float w4[4];
+                    load4(Wb + (int64_t)(c + i) * 4, w4);
+                    z1[v][i] = round_to<T>(z1[v][i] + f4[i]);
+                    z2[v][i] = round_to<T>(bb4[i] + w4[0] * bx[0] + w4[1] * bx[1] + w4[2] * bx[2] + w4[3] * bx[3]);
+                    s1 += z1[v][i];
+                    s2 += z2[v][i];
+                }
+                store4(z1_out + rb + c, z1[v]);
+                store4(z2_out + rb + c, z2[v]);
+            }
+        }
+        const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H;
+        float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            if (c < H) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float t1 = z1[v][i] - m1, t2 = z2[v][i] - m2;
+                    v1 += t1 * t1;
+                    v2 += t2 * t2;
+                }
+            }
+        }
+        const float r1 = rsqrtf(wave_sum(v1) / (float)H + eps), r2 = rsqrtf(wave_sum(v2) / (float)H + eps);
+        if (lane == 0) {
+            stats[4 * row] = m1;
+            stats[4 * row + 1] = r1;
+            stats[4 * row + 2] = m2;
+            stats[4 * row + 3] = r2;
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            if (c < H) {
+                float ga[4], ba[4], gb[4], bbv[4], y[4];
+                load4(g1 + c, ga);
+                load4(b1 + c, ba);
+                load4(g2 + c, gb);
+                load4(b2 + c, bbv);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    y[i] = 0.5f * (((z1[v][i] - m1) * r1 * ga[i] + ba[i]) + ((z2[v][i] - m2) * r2 * gb[i] + bbv[i]));
+                if (d.p_post > 0.f) {
+                    float s4[4];
+                    dropout_scale4(d.p_post, ik_post, seed, off, d.s_post, (uint64_t)(rb + c), s4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) y[i] *= s4[i];
+                }
+                store4(out + rb + c, y);
+            }
+        }
+    }
+}
+
+// backward: du (grad of the GEMM output u, T), and atomically accumulated fp32 grads of
+// b_f, g1, b1, W_b [H,4], b_b, g2, b2.
+template <typename T, int NV>
+__global__ __launch_bounds__(NT) void visn_embed_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ z1,
+                                                            const T* __restrict__ z2, const float* __restrict__ stats,
+                                                            const T* __restrict__ boxes, const float* __restrict__ g1,
+                                                            const float* __restrict__ g2, T* du, float* dbf, float* dg1,
+                                                            float* db1, float* dWb, float* dbb, float* dg2, float* db2, int M,
+                                                            int H, DropArgs d) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint64_t seed, off;
+    rng_load(d.rng, seed, off);
+    const float ik_post = d.p_post > 0.f ? 1.f / (1.f - d.p_post) : 1.f;
+    float pg1[NV][4], pb1[NV][4], pbf[NV][4], pg2[NV][4], pb2[NV][4], pbb[NV][4], pW[NV][4][4], ga[NV][4], gb[NV][4];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int c = (v * 64 + lane) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            pg1[v][i] = pb1[v][i] = pbf[v][i] = pg2[v][i] = pb2[v][i] = pbb[v][i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pW[v][i][j] = 0.f;
+        }
+        if (c < H) {
+            load4(g1 + c, ga[v]);
+            load4(g2 + c, gb[v]);
+        }
+    }
+    for (int row = blockIdx.x * WPB + wid; row < M; row += gridDim.x * WPB) {
+        const int64_t rb = (int64_t)row * H;
+        const float m1 = stats[4 * row], r1 = stats[4 * row + 1], m2 = stats[4 * row + 2], r2 = stats[4 * row + 3];
+        float bx[4];
+        load4(boxes + (int64_t)row * 4, bx);
+        float dyn[NV][4], x1[NV][4], x2[NV][4];
+        float a1 = 0.f, a2 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            if (c < H) {
+                float za[4], zb[4];
+                load4(dy + rb + c, dyn[v]);
+                load4(z1 + rb + c, za);
+                load4(z2 + rb + c, zb);
+                if (d.p_post > 0.f) {
+                    float s4[4];
+                    dropout_scale4(d.p_post, ik_post, seed, off, d.s_post, (uint64_t)(rb + c), s4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dyn[v][i] *= s4[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    dyn[v][i] *= 0.5f;
+                    x1[v][i] = (za[i] - m1) * r1;
+                    x2[v][i] = (zb[i] - m2) * r2;
+                    pg1[v][i] += dyn[v][i] * x1[v][i];
+                    pb1[v][i] += dyn[v][i];
+                    pg2[v][i] += dyn[v][i] * x2[v][i];
+                    pb2[v][i] += dyn[v][i];
+                    const float t1 = dyn[v][i] * ga[v][i], t2 = dyn[v][i] * gb[v][i];
+                    a1 += t1;
+                    c1 += t1 * x1[v][i];
+                    a2 += t2;
+                    c2 += t2 * x2[v][i];
+                }
+            }
+        }
+        a1 = wave_sum(a1) / (float)H;
+        c1 = wave_sum(c1) / (float)H;
+        a2 = wave_sum(a2) / (float)H;
+        c2 = wave_sum(c2) / (float)H;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            if (c < H) {
+                float d1[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    d1[i] = r1 * (dyn[v][i] * ga[v][i] - a1 - x1[v][i] * c1);
+                    const float d2 = r2 * (dyn[v][i] * gb[v][i] - a2 - x2[v][i] * c2);
+                    pbf[v][i] += d1[i];
+                    pbb[v][i] += d2;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pW[v][i][j] += d2 * bx[j];
+                }
+                store4(du + rb + c, d1);
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int c = (v * 64 + lane) * 4;
+        if (c < H) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                atomicAdd(dg1 + c + i, pg1[v][i]);
+                atomicAdd(db1 + c + i, pb1[v][i]);
+                atomicAdd(dbf + c + i, pbf[v][i]);
+                atomicAdd(dg2 + c + i, pg2[v][i]);
+                atomicAdd(db2 + c + i, pb2[v][i]);
+                atomicAdd(dbb + c + i, pbb[v][i]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) atomicAdd(dWb + (int64_t)(c + i) * 4 + j, pW[v][i][j]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------- column sum
+// out[n] (+)= sum_m x[m, n]  (bias gradients).  One thread per column pair of rows-chunk.
+template <typename T>
+__global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ x, float* out, int M, int N, int64_t ld,
+                                                    int rows_per_block) {
+    const int col = blockIdx.x * NT + threadIdx.x;
+    if (col >= N) return;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += to_f32(x[(int64_t)r * ld + col]);
+    atomicAdd(out + col, s);
+}
+
+inline int rows_grid(int M, int cap) { return std::min(ceil_div(M, WPB), cap); }
+
+#define DISPATCH_NV(H, ...)                                          \
+    do {                                                             \
+        const int nv_ = ceil_div(H, 256);                            \
+        if (nv_ <= 1) { constexpr int NV = 1; __VA_ARGS__; }         \
+        else if (nv_ <= 2) { constexpr int NV = 2; __VA_ARGS__; }    \
+        else if (nv_ <= 3) { constexpr int NV = 3; __VA_ARGS__; }    \
+        else if (nv_ <= 4) { constexpr int NV = 4; __VA_ARGS__; }    \
+        else if (nv_ <= 6) { constexpr int NV = 6; __VA_ARGS__; }    \
+        else { constexpr int NV = 8; __VA_ARGS__; }                  \
+    } while (0)
+
+inline int check_row_shape(const char* who, int M, int H) {
+    XGGM_REQUIRE(M > 0 && H > 0, "%s: empty input M=%d H=%d", who, M, H);
+    XGGM_REQUIRE(H % 4 == 0 && H <= 2048, "%s: H=%d must be a multiple of 4 and <= 2048", who, H);
+    return XGGM_OK;
+}
+
+template <typename T>
+int ln_fwd(const void* in, const float* bias, const void* residual, const float* gamma, const float* beta, void* out,
+           void* z_out, float* stats, int M, int H, float eps, float p_pre, float p_post, const uint64_t* rng,
+           uint32_t s_pre, uint32_t s_post, int accumulate, float out_scale, hipStream_t st) {
+    if (int e = check_row_shape("xggm_ln_fwd", M, H)) return e;
+    XGGM_REQUIRE(in && gamma && beta && out, "xggm_ln_fwd: null pointer");
+    XGGM_REQUIRE((p_pre == 0.f && p_post == 0.f) || rng, "xggm_ln_fwd: dropout needs an rng state");
+    XGGM_REQUIRE(p_pre >= 0.f && p_pre < 1.f && p_post >= 0.f && p_post < 1.f, "xggm_ln_fwd: bad dropout p");
+    DropArgs d{p_pre, p_post, rng, s_pre, s_post};
+    DISPATCH_NV(H, hipLaunchKernelGGL((ln_fwd_kernel<T, NV>), dim3(rows_grid(M, 4096)), dim3(NT), 0, st, (const T*)in, bias,
+                                       (const T*)residual, gamma, beta, (T*)out, (T*)z_out, stats, M, H, eps, d, accumulate,
+                                       out_scale));
+    return xggm_check_launch("xggm_ln_fwd");
+}
+
+template <typename T>
+int ln_bwd(const void* dy, const void* z, const float* stats, const float* gamma, void* d_in, void* d_res, float* dgamma,
+           float* dbeta, float* dbias, int M, int H, float p_pre, float p_post, const uint64_t* rng, uint32_t s_pre,
+           uint32_t s_post, float out_scale, int accumulate_dres, hipStream_t st) {
+    if (int e = check_row_shape("xggm_ln_bwd", M, H)) return e;
+    XGGM_REQUIRE(dy && z && stats && gamma, "xggm_ln_bwd: null pointer");
+    XGGM_REQUIRE((p_pre == 0.f && p_post == 0.f) || rng, "xggm_ln_bwd: dropout needs an rng state");
+    DropArgs d{p_pre, p_post, rng, s_pre, s_post};
+    DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), dim3(rows_grid(M, 128)), dim3(NT), 0, st, (const T*)dy,
+                                       (const T*)z, stats, gamma, (T*)d_in, (T*)d_res, dgamma, dbeta, dbias, M, H, d,
+                                       out_scale, accumulate_dres));
+    return xggm_check_launch("xggm_ln_bwd");
+}
+
+template <typename T>
+int embed_fwd(const int64_t* ids, const int64_t* seg, const void* word, const void* pos, const void* type,
+              const float* gamma, const float* beta, void* out, void* z_out, float* stats, int M, int Tlen, int H,
+              float eps, float p, const uint64_t* rng, uint32_t sid, hipStream_t st) {
+    if (int e = check_row_shape("xggm_embed_fwd", M, H)) return e;
+    XGGM_REQUIRE(ids && word && pos && type && gamma && beta && out && z_out && stats, "xggm_embed_fwd: null pointer");
+    XGGM_REQUIRE(Tlen > 0 && M % Tlen == 0, "xggm_embed_fwd: M=%d is not a multiple of T=%d", M, Tlen);
+    XGGM_REQUIRE(p == 0.f || rng, "xggm_embed_fwd: dropout needs an rng state");
+    DropArgs d{0.f, p, rng, 0, sid};
+    DISPATCH_NV(H, hipLaunchKernelGGL((embed_fwd_kernel<T, NV>), dim3(rows_grid(M, 4096)), dim3(NT), 0, st, ids, seg,
+                                       (const T*)word, (const T*)pos, (const T*)type, gamma, beta, (T*)out, (T*)z_out, stats,
+                                       M, Tlen, H, eps, d));
+    return xggm_check_launch("xggm_embed_fwd");
+}
+
+template <typename T>
+int embed_bwd(const int64_t* ids, const int64_t* seg, const void* dy, const void* z, const float* stats, const float* gamma,
+              void* dz_ws, float* dword, float* dpos, float* dtype, float* dgamma, float* dbeta, int M, int Tlen, int H,
+              float p, const uint64_t* rng, uint32_t sid, hipStream_t st) {
+    if (int e = check_row_shape("xggm_embed_bwd", M, H)) return e;
+    XGGM_REQUIRE(ids && dy && z && stats && gamma && dz_ws && dword && dpos && dtype, "xggm_embed_bwd: null pointer");
+    DropArgs d{0.f, p, rng, 0, sid};
+    DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), dim3(rows_grid(M, 128)), dim3(NT), 0, st, (const T*)dy,
+                                       (const T*)z, stats, gamma, (T*)dz_ws, (T*)nullptr, dgamma, dbeta, (float*)nullptr, M,
+                                       H, d, 1.0f, 0));
+    if (int e = xggm_check_launch("xggm_embed_bwd(ln)")) return e;
+    hipLaunchKernelGGL((embed_scatter_kernel<T>), dim3(rows_grid(M, 1024)), dim3(NT), 0, st, ids, seg, (const T*)dz_ws,
+                       dword, dpos, dtype, M, Tlen, H);
+    return xggm_check_launch("xggm_embed_bwd(scatter)");
+}
+
+template <typename T>
+int visn_fwd(const void* u, const float* bf, const void* boxes, const float* Wb, const float* bb, const float* g1,
+             const float* b1, const float* g2, const float* b2, void* out, void* z1, void* z2, float* stats, int M, int H,
+             float eps, float p, const uint64_t* rng, uint32_t sid, hipStream_t st) {
+    if (int e = check_row_shape("xggm_visn_embed_fwd", M, H)) return e;
+    XGGM_REQUIRE(u && bf && boxes && Wb && bb && g1 && b1 && g2 && b2 && out && z1 && z2 && stats,
+                 "xggm_visn_embed_fwd: null pointer");
+    XGGM_REQUIRE(p == 0.f || rng, "xggm_visn_embed_fwd: dropout needs an rng state");
+    DropArgs d{0.f, p, rng, 0, sid};
+    DISPATCH_NV(H, hipLaunchKernelGGL((visn_embed_fwd_kernel<T, NV>), dim3(rows_grid(M, 4096)), dim3(NT), 0, st,
+                                       (const T*)u, bf, (const T*)boxes, Wb, bb, g1, b1, g2, b2, (T*)out, (T*)z1, (T*)z2,
+                                       stats, M, H, eps, d));
+    return xggm_check_launch("xggm_visn_embed_fwd");
+}
+
+template <typename T>
+int visn_bwd(const void* dy, const void* z1, const void* z2, const float* stats, const void* boxes, const float* g1,
+             const float* g2, void* du, float* dbf, float* dg1, float* db1, float* dWb, float* dbb, float* dg2, float* db2,
+             int M, int H, float p, const uint64_t* rng, uint32_t sid, hipStream_t st) {
+    if (int e = check_row_shape("xggm_visn_embed_bwd", M, H)) return e;
+    XGGM_REQUIRE(dy && z1 && z2 && stats && boxes && g1 && g2 && du && dbf && dg1 && db1 && dWb && dbb && dg2 && db2,
+                 "xggm_visn_embed_bwd: null pointer");
+    XGGM_REQUIRE(H <= 1024, "xggm_visn_embed_bwd: H=%d > 1024", H);
+    DropArgs d{0.f, p, rng, 0, sid};
+    const int nv_ = ceil_div(H, 256);
+    if (nv_ <= 1) {
+        hipLaunchKernelGGL((visn_embed_bwd_kernel<T, 1>), dim3(rows_grid(M, 128)), dim3(NT), 0, st, (const T*)dy,
+                           (const T*)z1, (const T*)z2, stats, (const T*)boxes, g1, g2, (T*)du, dbf, dg1, db1, dWb, dbb, dg2,
+                           db2, M, H, d);
+    } else if (nv_ <= 3) {
+        hipLaunchKernelGGL((visn_embed_bwd_kernel<T, 3>), dim3(rows_grid(M, 128)), dim3(NT), 0, st, (const T*)dy,
+                           (const T*)z1, (const T*)z2, stats, (const T*)boxes, g1, g2, (T*)du, dbf, dg1, db1, dWb, dbb, dg2,
+                           db2, M, H, d);
+    } else {
+        hipLaunchKernelGGL((visn_embed_bwd_kernel<T, 4>), dim3(rows_grid(M, 128)), dim3(NT), 0, st, (const T*)dy,
+                           (const T*)z1, (const T*)z2, stats, (const T*)boxes, g1, g2, (T*)du, dbf, dg1, db1, dWb, dbb, dg2,
+                           db2, M, H, d);
+    }
+    return xggm_check_launch("xggm_visn_embed_bwd");
+}
+
+template <typename T> int colsum(const void* x, float* out, int M, int N, int64_t ld, hipStream_t st) {
+    XGGM_REQUIRE(x && out && M > 0 && N > 0 && ld >= N, "xggm_colsum: bad arguments M=%d N=%d", M, N);
+    const int rpb = 64;
+    hipLaunchKernelGGL((colsum_kernel<T>), dim3(ceil_div(N, NT), ceil_div(M, rpb)), dim3(NT), 0, st, (const T*)x, out, M, N,
+                       ld, rpb);
+    return xggm_check_launch("xggm_colsum");
+}
+
+}  // namespace
+
+#define ROW_API(SUF, T)                                                                                                     \
+    extern "C" int xggm_ln_fwd_##SUF(const void* in, const float* bias, const void* residual, const float* gamma,          \
+                                     const float* beta, void* out, void* z_out, float* stats, int M, int H, float eps,     \
+                                     float p_pre, float p_post, const uint64_t* rng, uint32_t s_pre, uint32_t s_post,      \
+                                     int accumulate, float out_scale, hipStream_t st) {                                   \
+        return ln_fwd<T>(in, bias, residual, gamma, beta, out, z_out, stats, M, H, eps, p_pre, p_post, rng, s_pre, s_post, \
+                         accumulate, out_scale, st);                                                                       \
+    }                                                                                                                       \
+    extern "C" int xggm_ln_bwd_##SUF(const void* dy, const void* z, const float* stats, const float* gamma, void* d_in,    \
+                                     void* d_res, float* dgamma, float* dbeta, float* dbias, int M, int H, float p_pre,    \
+                                     float p_post, const uint64_t* rng, uint32_t s_pre, uint32_t s_post, float out_scale,  \
+                                     int accumulate_dres, hipStream_t st) {                                               \
+        return ln_bwd<T>(dy, z, stats, gamma, d_in, d_res, dgamma, dbeta, dbias, M, H, p_pre, p_post, rng, s_pre, s_post,  \
+                         out_scale, accumulate_dres, st);                                                                  \
+    }                                                                                                                       \
+    extern "C" int xggm_embed_fwd_##SUF(const int64_t* ids, const int64_t* seg, const void* word, const void* pos,         \
+                                        const void* type, const float* gamma, const float* beta, void* out, void* z_out,   \
+                                        float* stats, int M, int Tlen, int H, float eps, float p, const uint64_t* rng,    \
+                                        uint32_t sid, hipStream_t st) {                                                   \
+        return embed_fwd<T>(ids, seg, word, pos, type, gamma, beta, out, z_out, stats, M, Tlen, H, eps, p, rng, sid, st);  \
+    }                                                                                                                       \
+    extern "C" int xggm_embed_bwd_##SUF(const int64_t* ids, const int64_t* seg, const void* dy, const void* z,             \
+                                        const float* stats, const float* gamma, void* dz_ws, float* dword, float* dpos,    \
+                                        float* dtype, float* dgamma, float* dbeta, int M, int Tlen, int H, float p,        \
+                                        const uint64_t* rng, uint32_t sid, hipStream_t st) {                              \
+        return embed_bwd<T>(ids, seg, dy, z, stats, gamma, dz_ws, dword, dpos, dtype, dgamma, dbeta, M, Tlen, H, p, rng,   \
+                            sid, st);                                                                                      \
+    }                                                                                                                       \
+    extern "C" int xggm_visn_embed_fwd_##SUF(const void* u, const float* bf, const void* boxes, const float* Wb,           \
+                                             const float* bb, const float* g1, const float* b1, const float* g2,           \
+                                             const float* b2, void* out, void* z1, void* z2, float* stats, int M, int H,   \
+                                             float eps, float p, const uint64_t* rng, uint32_t sid, hipStream_t st) {     \
+        return visn_fwd<T>(u, bf, boxes, Wb, bb, g1, b1, g2, b2, out, z1, z2, stats, M, H, eps, p, rng, sid, st);          \
+    }                                                                                                                       \
+    extern "C" int xggm_visn_embed_bwd_##SUF(const void* dy, const void* z1, const void* z2, const float* stats,           \
+                                             const void* boxes, const float* g1, const float* g2, void* du, float* dbf,    \
+                                             float* dg1, float* db1, float* dWb, float* dbb, float* dg2, float* db2, int M,\
+                                             int H, float p, const uint64_t* rng, uint32_t sid, hipStream_t st) {         \
+        return visn_bwd<T>(dy, z1, z2, stats, boxes, g1, g2, du, dbf, dg1, db1, dWb, dbb, dg2, db2, M, H, p, rng, sid, st);\
+    }                                                                                                                       \
+    extern "C" int xggm_colsum_##SUF(const void* x, float* out, int M, int N, int64_t ld, hipStream_t st) {                \
+        return colsum<T>(x, out, M, N, ld, st);                                                                            \
+    }
+
+ROW_API(f32, float)
+ROW_API(bf16, bf16)

@@ -1,0 +1,475 @@
+"""Thin tensor-level wrappers over the C ABI (one Python function per kernel family).
+
+No arithmetic happens here: each function checks shapes on the host -- a kernel that
+faults can reset the whole GPU node -- and enqueues one HIP kernel on the current stream.
+"""
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream
+
+ACT_NONE, ACT_GELU, ACT_SIGMOID, ACT_TANH, ACT_GELU_GRAD = 0, 1, 2, 3, 4
+AGG_PLAIN, AGG_TRANSPOSE, AGG_SYMMETRIZE = 0, 1, 2
+F32 = torch.float32
+BF16 = torch.bfloat16
+
+
+def sfx(dt):
+    if dt == F32:
+        return "f32"
+    if dt == BF16:
+        return "bf16"
+    raise TypeError("xggm_amd supports float32 and bfloat16 activations, got %s" % dt)
+
+
+def _chk(t, dt=None, name="tensor"):
+    if not t.is_cuda:
+        raise RuntimeError("xggm_amd: %s must live on the GPU (no CPU fallback)" % name)
+    if dt is not None and t.dtype != dt:
+        raise TypeError("xggm_amd: %s has dtype %s, expected %s" % (name, t.dtype, dt))
+    return t
+
+
+def _c(t, dt=None, name="tensor"):
+    _chk(t, dt, name)
+    if not t.is_contiguous():
+        raise RuntimeError("xggm_amd: %s must be contiguous" % name)
+    return t
+
+
+# ----------------------------------------------------------------------------- GEMM
+def gemm_raw(dt, A, B, C, M, N, K, a_rs, a_ks, b_ns, b_ks, ldc, batch=1, a_bs=0, b_bs=0, c_bs=0,
+             bias=None, residual=None, preact=None, aux=None, act=ACT_NONE, c_f32=False,
+             accumulate=False, alpha=1.0):
+    call("xggm_gemm_" + sfx(dt), ptr(A), ptr(B), ptr(C), M, N, K, a_rs, a_ks, b_ns, b_ks, ldc, batch,
+         a_bs, b_bs, c_bs, ptr(bias), ptr(residual), ptr(preact), ptr(aux), act, int(c_f32),
+         int(accumulate), float(alpha), stream())
+
+
+def _rows(x):
+    """(M, K, row stride) of a 2-D view whose last dim is contiguous."""
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise RuntimeError("xggm_amd: expected a 2-D operand with unit inner stride")
+    return x.shape[0], x.shape[1], x.stride(0)
+
+
+def linear_fwd(x, w, bias=None, act=ACT_NONE, want_preact=False, out_f32=False, residual=None):
+    """y[M,N] = act(x[M,K] @ w[N,K]^T + bias) (+ residual).  Returns (y, preact|None)."""
+    M, K, a_rs = _rows(_chk(x))
+    N, K2 = w.shape
+    if K2 != K or w.dtype != x.dtype or not w.is_contiguous():
+        raise RuntimeError("linear_fwd: weight %s/%s does not match input %s/%s"
+                           % (tuple(w.shape), w.dtype, tuple(x.shape), x.dtype))
+    if bias is not None:
+        _c(bias, F32, "bias")
+        assert bias.numel() == N
+    y = torch.empty((M, N), device=x.device, dtype=F32 if out_f32 else x.dtype)
+    pre = torch.empty((M, N), device=x.device, dtype=x.dtype) if want_preact else None
+    if residual is not None:
+        assert residual.shape == y.shape and residual.dtype == x.dtype and residual.is_contiguous()
+    gemm_raw(x.dtype, x, w, y, M, N, K, a_rs, 1, K, 1, N, bias=bias, preact=pre, act=act,
+             c_f32=out_f32, residual=residual)
+    return y, pre
+
+
+def linear_dgrad(dy, w, residual=None, gelu_aux=None):
+    """dx[M,K] = dy[M,N] @ w[N,K] (+ residual), optionally times gelu'(aux) (aux, dx same shape)."""
+    M, N, a_rs = _rows(_chk(dy))
+    N2, K = w.shape
+    if N2 != N or w.dtype != dy.dtype or not w.is_contiguous():
+        raise RuntimeError("linear_dgrad: weight %s does not match grad %s" % (tuple(w.shape), tuple(dy.shape)))
+    dx = torch.empty((M, K), device=dy.device, dtype=dy.dtype)
+    if residual is not None:
+        assert residual.shape == dx.shape and residual.dtype == dy.dtype and residual.is_contiguous()
+    if gelu_aux is not None:
+        assert gelu_aux.shape == dx.shape and gelu_aux.dtype == dy.dtype and gelu_aux.is_contiguous()
+    # B(k=n', n=k') = w[n', k']: column index contiguous, reduction index strided by K
+    gemm_raw(dy.dtype, dy, w, dx, M, K, N, a_rs, 1, 1, K, K, residual=residual, aux=gelu_aux,
+             act=ACT_GELU_GRAD if gelu_aux is not None else ACT_NONE)
+    return dx
+
+
+def linear_wgrad(dy, x, gw, accumulate):
+    """gw[N,K] (fp32) (+)= dy[M,N]^T @ x[M,K]."""
+    M, N, dy_rs = _rows(_chk(dy))
+    M2, K, x_rs = _rows(_chk(x))
+    if M2 != M or x.dtype != dy.dtype:
+        raise RuntimeError("linear_wgrad: %s vs %s" % (tuple(dy.shape), tuple(x.shape)))
+    _c(gw, F32, "weight grad")
+    assert tuple(gw.shape) == (N, K)
+    # A(m=n, k=m') = dy[m', n]: row index contiguous; B(k=m', n=k) = x[m', k]
+    gemm_raw(dy.dtype, dy, x, gw, N, K, M, 1, dy_rs, 1, x_rs, K, c_f32=True, accumulate=accumulate)
+
+
+def colsum(x, out):
+    """out[n] += sum_m x[m, n]  (fp32 accumulator)."""
+    M, N, ld = _rows(_chk(x))
+    _c(out, F32, "colsum out")
+    assert out.numel() == N
+    call("xggm_colsum_" + sfx(x.dtype), ptr(x), ptr(out), M, N, ld, stream())
+
+
+def bmm_nt(a, b, out_f32=True):
+    """out[z] = a[z] @ b[z]^T for contiguous a [Z,M,K], b [Z,N,K] -> [Z,M,N]."""
+    Z, M, K = a.shape
+    Z2, N, K2 = b.shape
+    assert Z == Z2 and K == K2 and a.dtype == b.dtype
+    _c(a), _c(b)
+    out = torch.empty((Z, M, N), device=a.device, dtype=F32 if out_f32 else a.dtype)
+    gemm_raw(a.dtype, a, b, out, M, N, K, K, 1, K, 1, N, batch=Z, a_bs=M * K, b_bs=N * K, c_bs=M * N,
+             c_f32=out_f32)
+    return out
+
+
+# ----------------------------------------------------------------------------- attention
+def attn_fwd(q, k, v, mask, B, heads, Sq, Sk, p, rng, sid):
+    """q/k/v: 2-D row views [B*S, heads*64] with unit inner stride (may be slices of a fused
+    QKV buffer).  Returns ctx [B*Sq, heads*64]."""
+    d = 64
+    H = heads * d
+    for t, S in ((q, Sq), (k, Sk), (v, Sk)):
+        _chk(t)
+        if t.dim() != 2 or t.shape[0] != B * S or t.shape[1] != H or t.stride(1) != 1:
+            raise RuntimeError("attn_fwd: bad operand shape %s" % (tuple(t.shape),))
+    if mask is not None:
+        _c(mask, F32, "mask")
+        assert tuple(mask.shape) == (B, Sk)
+    out = torch.empty((B * Sq, H), device=q.device, dtype=q.dtype)
+    call("xggm_attn_fwd_" + sfx(q.dtype), ptr(q), ptr(k), ptr(v), ptr(mask), ptr(out), B, heads, Sq, Sk, d,
+         q.stride(0), k.stride(0), v.stride(0), H, 0.125, float(p), ptr(rng), sid, stream())
+    return out
+
+
+def attn_bwd(q, k, v, mask, d_out, dq, dk, dv, B, heads, Sq, Sk, p, rng, sid):
+    d = 64
+    H = heads * d
+    _c(d_out)
+    assert tuple(d_out.shape) == (B * Sq, H) and d_out.dtype == q.dtype
+    for t, S in ((dq, Sq), (dk, Sk), (dv, Sk)):
+        if t.dim() != 2 or t.shape[0] != B * S or t.shape[1] != H or t.stride(1) != 1 or t.dtype != q.dtype:
+            raise RuntimeError("attn_bwd: bad gradient buffer %s" % (tuple(t.shape),))
+    call("xggm_attn_bwd_" + sfx(q.dtype), ptr(q), ptr(k), ptr(v), ptr(mask), ptr(d_out), ptr(dq), ptr(dk),
+         ptr(dv), B, heads, Sq, Sk, d, q.stride(0), k.stride(0), v.stride(0), H, dq.stride(0),
+         dk.stride(0), dv.stride(0), 0.125, float(p), ptr(rng), sid, stream())
+
+
+# ----------------------------------------------------------------------------- row kernels
+def ln_fwd(x, bias, residual, gamma, beta, eps, p_pre=0.0, p_post=0.0, rng=None, sid_pre=0, sid_post=0,
+           out=None, accumulate=False, out_scale=1.0, save=True):
+    """Returns (out, z, stats).  ``z`` overwrites ``x`` in place when ``save``."""
+    _c(x)
+    M, H = x.shape
+    _c(gamma, F32, "gamma"), _c(beta, F32, "beta")
+    assert gamma.numel() == H and beta.numel() == H
+    if bias is not None:
+        _c(bias, F32, "bias")
+        assert bias.numel() == H
+    if residual is not None:
+        _c(residual, x.dtype, "residual")
+        assert residual.shape == x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    else:
+        assert out.shape == x.shape and out.dtype == x.dtype and out.is_contiguous()
+    stats = torch.empty((M, 2), device=x.device, dtype=F32) if save else None
+    z = x if save else None
+    call("xggm_ln_fwd_" + sfx(x.dtype), ptr(x), ptr(bias), ptr(residual), ptr(gamma), ptr(beta), ptr(out),
+         ptr(z), ptr(stats), M, H, float(eps), float(p_pre), float(p_post), ptr(rng), sid_pre, sid_post,
+         int(accumulate), float(out_scale), stream())
+    return out, z, stats
+
+
+def ln_bwd(dy, z, stats, gamma, dgamma, dbeta, dbias, want_din=True, want_dres=False, d_res=None,
+           p_pre=0.0, p_post=0.0, rng=None, sid_pre=0, sid_post=0, out_scale=1.0):
+    """Returns (d_in, d_res).  dgamma/dbeta/dbias (fp32, may be None) are accumulated.
+    If ``d_res`` is given the residual gradient is ADDED into it."""
+    _c(dy), _c(z, dy.dtype)
+    M, H = dy.shape
+    assert z.shape == dy.shape and tuple(stats.shape) == (M, 2)
+    for t in (dgamma, dbeta, dbias):
+        if t is not None:
+            _c(t, F32, "param grad")
+            assert t.numel() == H
+    d_in = torch.empty_like(dy) if want_din else None
+    acc = d_res is not None
+    if want_dres and d_res is None:
+        d_res = torch.empty_like(dy)
+    if d_res is not None:
+        assert d_res.shape == dy.shape and d_res.dtype == dy.dtype and d_res.is_contiguous()
+    call("xggm_ln_bwd_" + sfx(dy.dtype), ptr(dy), ptr(z), ptr(stats), ptr(gamma), ptr(d_in), ptr(d_res),
+         ptr(dgamma), ptr(dbeta), ptr(dbias), M, H, float(p_pre), float(p_post), ptr(rng), sid_pre, sid_post,
+         float(out_scale), int(acc), stream())
+    return d_in, d_res
+
+
+def embed_fwd(ids, seg, word, pos, typ, gamma, beta, eps, p, rng, sid):
+    B, T = ids.shape
+    _c(ids, torch.int64, "input_ids")
+    if seg is not None:
+        _c(seg, torch.int64, "segment_ids")
+        assert seg.shape == ids.shape
+    H = word.shape[1]
+    for t in (word, pos, typ):
+        _c(t)
+        assert t.shape[1] == H and t.dtype == word.dtype
+    assert pos.shape[0] >= T, "sequence longer than the position table"
+    out = torch.empty((B * T, H), device=word.device, dtype=word.dtype)
+    z = torch.empty_like(out)
+    stats = torch.empty((B * T, 2), device=word.device, dtype=F32)
+    call("xggm_embed_fwd_" + sfx(word.dtype), ptr(ids), ptr(seg), ptr(word), ptr(pos), ptr(typ), ptr(gamma),
+         ptr(beta), ptr(out), ptr(z), ptr(stats), B * T, T, H, float(eps), float(p), ptr(rng), sid, stream())
+    return out, z, stats
+
+
+def embed_bwd(ids, seg, dy, z, stats, gamma, dword, dpos, dtyp, dgamma, dbeta, p, rng, sid):
+    B, T = ids.shape
+    M, H = dy.shape
+    _c(dy), _c(z, dy.dtype)
+    for t in (dword, dpos, dtyp, dgamma, dbeta):
+        _c(t, F32, "embedding grad")
+    ws = torch.empty_like(dy)
+    call("xggm_embed_bwd_" + sfx(dy.dtype), ptr(ids), ptr(seg), ptr(dy), ptr(z), ptr(stats), ptr(gamma),
+         ptr(ws), ptr(dword), ptr(dpos), ptr(dtyp), ptr(dgamma), ptr(dbeta), M, T, H, float(p), ptr(rng), sid,
+         stream())
+
+
+def visn_embed_fwd(u, bf, boxes, Wb, bb, g1, b1, g2, b2, eps, p, rng, sid):
+    _c(u), _c(boxes, u.dtype, "boxes")
+    M, H = u.shape
+    assert tuple(boxes.shape) == (M, 4) and tuple(Wb.shape) == (H, 4)
+    for t in (bf, Wb, bb, g1, b1, g2, b2):
+        _c(t, F32, "visn_fc parameter")
+    out = torch.empty_like(u)
+    z2 = torch.empty_like(u)
+    stats = torch.empty((M, 4), device=u.device, dtype=F32)
+    call("xggm_visn_embed_fwd_" + sfx(u.dtype), ptr(u), ptr(bf), ptr(boxes), ptr(Wb), ptr(bb), ptr(g1),
+         ptr(b1), ptr(g2), ptr(b2), ptr(out), ptr(u), ptr(z2), ptr(stats), M, H, float(eps), float(p), ptr(rng),
+         sid, stream())
+    return out, u, z2, stats
+
+
+def visn_embed_bwd(dy, z1, z2, stats, boxes, g1, g2, grads, p, rng, sid):
+    """grads: dict with fp32 accumulators dbf, dg1, db1, dWb, dbb, dg2, db2.  Returns du."""
+    _c(dy)
+    M, H = dy.shape
+    du = torch.empty_like(dy)
+    call("xggm_visn_embed_bwd_" + sfx(dy.dtype), ptr(dy), ptr(z1), ptr(z2), ptr(stats), ptr(boxes), ptr(g1),
+         ptr(g2), ptr(du), ptr(grads["dbf"]), ptr(grads["dg1"]), ptr(grads["db1"]), ptr(grads["dWb"]),
+         ptr(grads["dbb"]), ptr(grads["dg2"]), ptr(grads["db2"]), M, H, float(p), ptr(rng), sid, stream())
+    return du
+
+
+# ----------------------------------------------------------------------------- graph kernels
+def aggregate(Mx, x, mode=AGG_PLAIN, scale=1.0, scale_ptr=None, self_w=0.0, out=None):
+    """out = [out +] self_w*x + scale*(1+*scale_ptr) * M' @ x.  Mx fp32 [B,N,N], x T [B,N,H]."""
+    _c(Mx, F32, "adjacency"), _c(x)
+    B, N, H = x.shape
+    assert tuple(Mx.shape) == (B, N, N), "adjacency %s vs nodes %s" % (tuple(Mx.shape), tuple(x.shape))
+    acc = out is not None
+    if out is None:
+        out = torch.empty_like(x)
+    else:
+        assert out.shape == x.shape and out.dtype == x.dtype and out.is_contiguous()
+    call("xggm_aggregate_" + sfx(x.dtype), ptr(Mx), ptr(x), ptr(out), B, N, H, mode, float(scale),
+         ptr(scale_ptr), float(self_w), int(acc), stream())
+    return out
+
+
+def agg_dot(Mx, x, dh, out):
+    B, N, H = x.shape
+    _c(Mx, F32), _c(x), _c(dh, x.dtype), _c(out, F32)
+    assert tuple(Mx.shape) == (B, N, N) and dh.shape == x.shape
+    call("xggm_agg_dot_" + sfx(x.dtype), ptr(Mx), ptr(x), ptr(dh), ptr(out), B, N, H, stream())
+
+
+def adj_regen_fwd(S):
+    _c(S, F32, "S")
+    B, N, _ = S.shape
+    adj = torch.empty_like(S)
+    colmax = torch.empty((B, N), device=S.device, dtype=F32)
+    argmax = torch.empty((B, N), device=S.device, dtype=torch.int32)
+    call("xggm_adj_regen_fwd", ptr(S), ptr(adj), ptr(colmax), ptr(argmax), B, N, stream())
+    return adj, colmax, argmax
+
+
+def adj_regen_bwd(d_adj, S, adj, colmax, argmax):
+    _c(d_adj, F32, "d_adj")
+    B, N, _ = S.shape
+    assert d_adj.shape == S.shape
+    dS = torch.empty_like(S)
+    call("xggm_adj_regen_bwd", ptr(d_adj), ptr(S), ptr(adj), ptr(colmax), ptr(argmax), ptr(dS), B, N, stream())
+    return dS
+
+
+def adj_init_fwd(e, N, sigma, randn=None, rng=None, sid=0, B=None, want_gradlog=True):
+    if e is not None:
+        _c(e, F32, "encoder_adj output")
+        B = e.shape[0]
+        assert e.shape[1] == N * (N - 1) // 2, "encoder_adj width %d != N(N-1)/2" % e.shape[1]
+    dev = e.device if e is not None else randn.device
+    if randn is not None:
+        _c(randn, F32, "randn")
+        assert tuple(randn.shape) == (B, N, N)
+    adj = torch.empty((B, N, N), device=dev, dtype=F32)
+    g = torch.empty_like(adj) if want_gradlog else None
+    call("xggm_adj_init_fwd", ptr(e), ptr(randn), ptr(adj), ptr(g), B, N, float(sigma), ptr(rng), sid, stream())
+    return adj, g
+
+
+def adj_init_bwd(d_adj):
+    _c(d_adj, F32, "d_adj")
+    B, N, _ = d_adj.shape
+    d_e = torch.empty((B, N * (N - 1) // 2), device=d_adj.device, dtype=F32)
+    call("xggm_adj_init_bwd", ptr(d_adj), ptr(d_e), B, N, stream())
+    return d_e
+
+
+def feature_noise(x, sigma, randn=None, rng=None, sid=0):
+    _c(x)
+    if randn is not None:
+        _c(randn, F32, "randn")
+        assert randn.shape == x.shape
+    out = torch.empty_like(x)
+    g = torch.empty(x.shape, device=x.device, dtype=F32)
+    call("xggm_feature_noise_" + sfx(x.dtype), ptr(x), ptr(randn), ptr(out), ptr(g), x.numel(), float(sigma),
+         ptr(rng), sid, stream())
+    return out, g
+
+
+def pool_concat_fwd(x, nodes):
+    _c(x), _c(nodes, x.dtype)
+    B, N, H = nodes.shape
+    assert tuple(x.shape) == (B, H)
+    out = torch.empty((B, 2 * H), device=x.device, dtype=x.dtype)
+    call("xggm_pool_concat_fwd_" + sfx(x.dtype), ptr(x), ptr(nodes), ptr(out), B, N, H, stream())
+    return out
+
+
+def pool_concat_bwd(d_out, out, N):
+    _c(d_out), _c(out, d_out.dtype)
+    B, H2 = out.shape
+    H = H2 // 2
+    dx = torch.empty((B, H), device=out.device, dtype=out.dtype)
+    dn = torch.empty((B, N, H), device=out.device, dtype=out.dtype)
+    call("xggm_pool_concat_bwd_" + sfx(out.dtype), ptr(d_out), ptr(out), ptr(dx), ptr(dn), B, N, H, 0, stream())
+    return dx, dn
+
+
+def bcast_rows(x, N):
+    _c(x)
+    B, H = x.shape
+    out = torch.empty((B, N, H), device=x.device, dtype=x.dtype)
+    call("xggm_bcast_rows_" + sfx(x.dtype), ptr(x), ptr(out), B, N, H, stream())
+    return out
+
+
+def sum_rows(g):
+    _c(g)
+    B, N, H = g.shape
+    out = torch.empty((B, H), device=g.device, dtype=g.dtype)
+    call("xggm_sum_rows_" + sfx(g.dtype), ptr(g), ptr(out), B, N, H, stream())
+    return out
+
+
+# ----------------------------------------------------------------------------- losses
+def dsm_fwd(s, g, coef):
+    _c(s), _c(g, F32, "grad_log_noise")
+    assert s.shape == g.shape
+    loss = torch.zeros((), device=s.device, dtype=F32)
+    call("xggm_dsm_loss_fwd_" + sfx(s.dtype), ptr(s), ptr(g), ptr(loss), s.numel(), float(coef), stream())
+    return loss
+
+
+def dsm_bwd(s, g, gout, coef):
+    ds = torch.empty_like(s)
+    call("xggm_dsm_loss_bwd_" + sfx(s.dtype), ptr(s), ptr(g), ptr(gout), ptr(ds), s.numel(), float(coef), stream())
+    return ds
+
+
+def symkl_fwd(x, y, coef):
+    _c(x), _c(y, x.dtype)
+    assert x.shape == y.shape
+    W = x.shape[-1]
+    loss = torch.zeros((), device=x.device, dtype=F32)
+    call("xggm_symkl_" + sfx(x.dtype), ptr(x), ptr(y), ptr(loss), None, None, None, x.numel() // W, W,
+         float(coef), 0, stream())
+    return loss
+
+
+def symkl_bwd(x, y, gout, coef, need_x, need_y):
+    W = x.shape[-1]
+    dx = torch.empty_like(x) if need_x else None
+    dy = torch.empty_like(y) if need_y else None
+    call("xggm_symkl_" + sfx(x.dtype), ptr(x), ptr(y), None, ptr(gout), ptr(dx), ptr(dy), x.numel() // W, W,
+         float(coef), 0, stream())
+    return dx, dy
+
+
+def bce_fwd(logit, target, coef):
+    _c(logit, F32, "logit"), _c(target, F32, "target")
+    assert logit.shape == target.shape
+    loss = torch.zeros((), device=logit.device, dtype=F32)
+    call("xggm_bce_fwd", ptr(logit), ptr(target), ptr(loss), logit.numel(), float(coef), stream())
+    return loss
+
+
+def bce_bwd(logit, target, gout, coef, dt):
+    dl = torch.empty(logit.shape, device=logit.device, dtype=dt)
+    call("xggm_bce_bwd_" + sfx(dt), ptr(logit), ptr(target), ptr(gout), ptr(dl), logit.numel(), float(coef), stream())
+    return dl
+
+
+# ----------------------------------------------------------------------------- optimiser / utils
+def sqnorm(g, out):
+    _c(g, F32), _c(out, F32)
+    call("xggm_sqnorm_f32", ptr(g), g.numel(), ptr(out), stream())
+
+
+def bertadam(p, g, m, v, shadow, sqn, max_norm, lr, lr_scale, b1, b2, eps, wd):
+    for t in (p, g, m, v):
+        _c(t, F32)
+        assert t.numel() == p.numel()
+    if shadow is not None:
+        _c(shadow, BF16)
+        assert shadow.numel() == p.numel()
+    call("xggm_bertadam_f32", ptr(p), ptr(g), ptr(m), ptr(v), ptr(shadow), p.numel(), ptr(sqn), float(max_norm),
+         float(lr), ptr(lr_scale), float(b1), float(b2), float(eps), float(wd), stream())
+
+
+def sched_step(step, lr_scale, t_total, warmup):
+    _c(step, torch.int64), _c(lr_scale, F32)
+    call("xggm_sched_step", ptr(step), ptr(lr_scale), int(t_total), float(warmup), stream())
+
+
+def rng_advance(rng, by=1):
+    call("xggm_rng_advance", ptr(rng), int(by), stream())
+
+
+def cast_bf16(x, out):
+    _c(x, F32), _c(out, BF16)
+    assert x.numel() == out.numel()
+    call("xggm_cast_f32_to_bf16", ptr(x), ptr(out), x.numel(), stream())
+
+
+def dropout_mask(n, p, rng, sid, device):
+    out = torch.empty(n, device=device, dtype=F32)
+    call("xggm_dropout_mask", ptr(out), n, float(p), ptr(rng), sid, stream())
+    return out
+
+
+def normal(n, rng, sid, device):
+    out = torch.empty(n, device=device, dtype=F32)
+    call("xggm_normal", ptr(out), n, ptr(rng), sid, stream())
+    return out
+
+
+def make_rng(seed, device):
+    """device-resident {seed, offset} pair (int64 storage of the two uint64 words)."""
+    return torch.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=device)
+
+
+def triu_index(k, N):
+    import ctypes
+    i, j = ctypes.c_int(), ctypes.c_int()
+    _lib.check(_lib.lib.xggm_triu_index(k, N, ctypes.byref(i), ctypes.byref(j)), "xggm_triu_index")
+    return i.value, j.value
