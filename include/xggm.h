@@ -106,14 +106,17 @@ int xggm_ln_fwd_bf16(const void* in, const float* bias, const void* residual, co
                      const uint64_t* rng, uint32_t sid_pre, uint32_t sid_post, int accumulate, float out_scale,
                      xggm_stream_t stream);
 /* dy = grad of `out`.  d_in: grad of `in` (NULL ok); d_res: grad of `residual` (NULL ok,
- * accumulate_dres adds to it); dgamma/dbeta/dbias (NULL ok) are ACCUMULATED atomically. */
+ * accumulate_dres adds to it); dgamma/dbeta/dbias (NULL ok) are ACCUMULATED atomically.
+ * gelu_aux (T [M,H], NULL ok): `in` was gelu(u) of a Linear -> d_in (and dbias) are further
+ * multiplied by gelu'(u), i.e. they become the gradients of u and of that Linear's bias. */
 int xggm_ln_bwd_f32(const void* dy, const void* z, const float* stats, const float* gamma, void* d_in, void* d_res,
                     float* dgamma, float* dbeta, float* dbias, int M, int H, float p_pre, float p_post, const uint64_t* rng,
-                    uint32_t sid_pre, uint32_t sid_post, float out_scale, int accumulate_dres, xggm_stream_t stream);
+                    uint32_t sid_pre, uint32_t sid_post, float out_scale, int accumulate_dres, const void* gelu_aux,
+                    xggm_stream_t stream);
 int xggm_ln_bwd_bf16(const void* dy, const void* z, const float* stats, const float* gamma, void* d_in, void* d_res,
                      float* dgamma, float* dbeta, float* dbias, int M, int H, float p_pre, float p_post,
                      const uint64_t* rng, uint32_t sid_pre, uint32_t sid_post, float out_scale, int accumulate_dres,
-                     xggm_stream_t stream);
+                     const void* gelu_aux, xggm_stream_t stream);
 /* BertEmbeddings: src/lxrt/modeling.py:298-313.  ids/seg: int64 [M] (M = B*Tlen), tables T.
  * backward scatter-adds into the fp32 table gradients; row 0 (padding_idx) gets none. */
 int xggm_embed_fwd_f32(const int64_t* ids, const int64_t* seg, const void* word, const void* pos, const void* type,
@@ -223,6 +226,20 @@ int xggm_bertadam_f32(float* p, const float* g, float* m, float* v, void* shadow
                       xggm_stream_t stream);
 /* *lr_scale = warmup_linear(*step / t_total, warmup); *step += 1 (optimization.py:42-48) */
 int xggm_sched_step(int64_t* step, float* lr_scale, int64_t t_total, float warmup, xggm_stream_t stream);
+
+/* ---- small element-wise kernels ---------------------------------------------------------
+ * out = scale * (1 + *scale_ptr) * x   (GIN's (1+eps), src/module/gin.py:32) */
+int xggm_scale_f32(const void* x, void* out, int64_t n, float scale, const float* scale_ptr, xggm_stream_t stream);
+int xggm_scale_bf16(const void* x, void* out, int64_t n, float scale, const float* scale_ptr, xggm_stream_t stream);
+/* out(T) = dy(fp32) * y(fp32) * (1 - y): backward of encoder_adj's Sigmoid (vqacpv2_model.py:93) */
+int xggm_sigmoid_bwd_f32(const float* dy, const float* y, void* out, int64_t n, xggm_stream_t stream);
+int xggm_sigmoid_bwd_bf16(const float* dy, const float* y, void* out, int64_t n, xggm_stream_t stream);
+/* out(T) = dy(T) * (1 - y(T)^2): backward of BertPooler's tanh (src/lxrt/modeling.py:619) */
+int xggm_tanh_bwd_f32(const void* dy, const void* y, void* out, int64_t n, xggm_stream_t stream);
+int xggm_tanh_bwd_bf16(const void* dy, const void* y, void* out, int64_t n, xggm_stream_t stream);
+/* out(T) = x(fp32): loader tensors (feats, boxes) and fp32 logit gradients entering the T path */
+int xggm_cast_from_f32_f32(const float* x, void* out, int64_t n, xggm_stream_t stream);
+int xggm_cast_from_f32_bf16(const float* x, void* out, int64_t n, xggm_stream_t stream);
 
 /* ---- utilities ---------------------------------------------------------------------------*/
 int xggm_rng_advance(uint64_t* rng, uint64_t by, xggm_stream_t stream);

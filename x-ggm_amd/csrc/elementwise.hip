@@ -1,0 +1,69 @@
+// Small element-wise kernels that sit between the fused ops (HBM-bound, 16-byte accesses
+// where the element count allows, grid-stride).
+#include "common.h"
+#include "xggm.h"
+
+namespace {
+constexpr int NT = 256;
+inline int grid1d(int64_t n) { return (int)std::min<int64_t>(ceil_div64(n, NT), 2048); }
+
+template <typename T>
+__global__ __launch_bounds__(NT) void scale_kernel(const T* __restrict__ x, T* out, int64_t n, float scale,
+                                                   const float* scale_ptr) {
+    if (scale_ptr) scale *= (1.0f + *scale_ptr);
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT)
+        out[i] = from_f32<T>(scale * to_f32(x[i]));
+}
+template <typename T>
+__global__ __launch_bounds__(NT) void sigmoid_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, T* out,
+                                                         int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT)
+        out[i] = from_f32<T>(dy[i] * y[i] * (1.0f - y[i]));
+}
+template <typename T>
+__global__ __launch_bounds__(NT) void tanh_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const float t = to_f32(y[i]);
+        out[i] = from_f32<T>(to_f32(dy[i]) * (1.0f - t * t));
+    }
+}
+template <typename T> __global__ __launch_bounds__(NT) void cast_kernel(const float* __restrict__ x, T* out, int64_t n) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT) {
+        float v[4];
+        load4(x + 4 * i, v);
+        store4(out + 4 * i, v);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) out[(n4 << 2) + threadIdx.x] = from_f32<T>(x[(n4 << 2) + threadIdx.x]);
+}
+}  // namespace
+
+#define EW_API(SUF, T)                                                                                                   \
+    extern "C" int xggm_scale_##SUF(const void* x, void* out, int64_t n, float scale, const float* scale_ptr,          \
+                                    hipStream_t st) {                                                                   \
+        XGGM_REQUIRE(x && out && n > 0, "xggm_scale: bad arguments");                                                    \
+        hipLaunchKernelGGL((scale_kernel<T>), dim3(grid1d(n)), dim3(NT), 0, st, (const T*)x, (T*)out, n, scale,         \
+                           scale_ptr);                                                                                  \
+        return xggm_check_launch("xggm_scale");                                                                         \
+    }                                                                                                                    \
+    extern "C" int xggm_sigmoid_bwd_##SUF(const float* dy, const float* y, void* out, int64_t n, hipStream_t st) {      \
+        XGGM_REQUIRE(dy && y && out && n > 0, "xggm_sigmoid_bwd: bad arguments");                                        \
+        hipLaunchKernelGGL((sigmoid_bwd_kernel<T>), dim3(grid1d(n)), dim3(NT), 0, st, dy, y, (T*)out, n);               \
+        return xggm_check_launch("xggm_sigmoid_bwd");                                                                   \
+    }                                                                                                                    \
+    extern "C" int xggm_tanh_bwd_##SUF(const void* dy, const void* y, void* out, int64_t n, hipStream_t st) {           \
+        XGGM_REQUIRE(dy && y && out && n > 0, "xggm_tanh_bwd: bad arguments");                                           \
+        hipLaunchKernelGGL((tanh_bwd_kernel<T>), dim3(grid1d(n)), dim3(NT), 0, st, (const T*)dy, (const T*)y, (T*)out,  \
+                           n);                                                                                          \
+        return xggm_check_launch("xggm_tanh_bwd");                                                                      \
+    }                                                                                                                    \
+    extern "C" int xggm_cast_from_f32_##SUF(const float* x, void* out, int64_t n, hipStream_t st) {                     \
+        XGGM_REQUIRE(x && out && n > 0, "xggm_cast_from_f32: bad arguments");                                            \
+        XGGM_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 8 == 0,             \
+                     "xggm_cast_from_f32: misaligned pointers");                                                        \
+        hipLaunchKernelGGL((cast_kernel<T>), dim3(grid1d(n / 4 + 1)), dim3(NT), 0, st, x, (T*)out, n);                  \
+        return xggm_check_launch("xggm_cast_from_f32");                                                                 \
+    }
+
+EW_API(f32, float)
+EW_API(bf16, bf16)

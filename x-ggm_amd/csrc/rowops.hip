@@ -129,7 +129,8 @@ template <typename T, int NV>
 __global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ z,
                                                     const float* __restrict__ stats, const float* __restrict__ gamma,
                                                     T* d_in, T* d_res, float* dgamma, float* dbeta, float* dbias, int M, int H,
-                                                    DropArgs d, float out_scale, int accumulate_dres) {
+                                                    DropArgs d, float out_scale, int accumulate_dres,
+                                                    const T* __restrict__ gelu_aux) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     uint64_t seed, off;
     rng_load(d.rng, seed, off);
@@ -198,6 +199,12 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ dy, co
                     dropout_scale4(d.p_pre, ik_pre, seed, off, d.s_pre, (uint64_t)(rb + c), s4);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) dz[i] *= s4[i];
+                }
+                if (gelu_aux) {  // `in` was gelu(u): chain through the activation
+                    float u4[4];
+                    load4(gelu_aux + rb + c, u4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dz[i] *= gelu_grad_f(u4[i]);
                 }
                 if (d_in) store4(d_in + rb + c, dz);
 #pragma unroll
@@ -552,14 +559,14 @@ int ln_fwd(const void* in, const float* bias, const void* residual, const float*
 template <typename T>
 int ln_bwd(const void* dy, const void* z, const float* stats, const float* gamma, void* d_in, void* d_res, float* dgamma,
            float* dbeta, float* dbias, int M, int H, float p_pre, float p_post, const uint64_t* rng, uint32_t s_pre,
-           uint32_t s_post, float out_scale, int accumulate_dres, hipStream_t st) {
+           uint32_t s_post, float out_scale, int accumulate_dres, const void* gelu_aux, hipStream_t st) {
     if (int e = check_row_shape("xggm_ln_bwd", M, H)) return e;
     XGGM_REQUIRE(dy && z && stats && gamma, "xggm_ln_bwd: null pointer");
     XGGM_REQUIRE((p_pre == 0.f && p_post == 0.f) || rng, "xggm_ln_bwd: dropout needs an rng state");
     DropArgs d{p_pre, p_post, rng, s_pre, s_post};
     DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), dim3(rows_grid(M, 128)), dim3(NT), 0, st, (const T*)dy,
                                        (const T*)z, stats, gamma, (T*)d_in, (T*)d_res, dgamma, dbeta, dbias, M, H, d,
-                                       out_scale, accumulate_dres));
+                                       out_scale, accumulate_dres, (const T*)gelu_aux));
     return xggm_check_launch("xggm_ln_bwd");
 }
 
@@ -587,7 +594,7 @@ int embed_bwd(const int64_t* ids, const int64_t* seg, const void* dy, const void
     DropArgs d{0.f, p, rng, 0, sid};
     DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), dim3(rows_grid(M, 128)), dim3(NT), 0, st, (const T*)dy,
                                        (const T*)z, stats, gamma, (T*)dz_ws, (T*)nullptr, dgamma, dbeta, (float*)nullptr, M,
-                                       H, d, 1.0f, 0));
+                                       H, d, 1.0f, 0, (const T*)nullptr));
     if (int e = xggm_check_launch("xggm_embed_bwd(ln)")) return e;
     hipLaunchKernelGGL((embed_scatter_kernel<T>), dim3(rows_grid(M, 1024)), dim3(NT), 0, st, ids, seg, (const T*)dz_ws,
                        dword, dpos, dtype, M, Tlen, H);
@@ -656,9 +663,9 @@ template <typename T> int colsum(const void* x, float* out, int M, int N, int64_
     extern "C" int xggm_ln_bwd_##SUF(const void* dy, const void* z, const float* stats, const float* gamma, void* d_in,    \
                                      void* d_res, float* dgamma, float* dbeta, float* dbias, int M, int H, float p_pre,    \
                                      float p_post, const uint64_t* rng, uint32_t s_pre, uint32_t s_post, float out_scale,  \
-                                     int accumulate_dres, hipStream_t st) {                                               \
+                                     int accumulate_dres, const void* gelu_aux, hipStream_t st) {                         \
         return ln_bwd<T>(dy, z, stats, gamma, d_in, d_res, dgamma, dbeta, dbias, M, H, p_pre, p_post, rng, s_pre, s_post,  \
-                         out_scale, accumulate_dres, st);                                                                  \
+                         out_scale, accumulate_dres, gelu_aux, st);                                                        \
     }                                                                                                                       \
     extern "C" int xggm_embed_fwd_##SUF(const int64_t* ids, const int64_t* seg, const void* word, const void* pos,         \
                                         const void* type, const float* gamma, const float* beta, void* out, void* z_out,   \

@@ -1,0 +1,527 @@
+"""Autograd glue: one ``torch.autograd.Function`` per fused block of the hot path.
+
+PyTorch supplies the tape, memory and streams; every arithmetic step of forward AND backward
+is a HIP kernel behind the C ABI (``ops``).  Parameter gradients are not returned to
+autograd: each backward writes them straight into the flat fp32 gradient arena
+(``arena.target`` / ``arena.atomic_target``) and publishes ``p.grad`` as a view of it, so no
+AccumulateGrad copies happen and the optimiser / all-reduce see contiguous memory.
+Parameters are still passed as inputs (``*params``) so autograd schedules the backward of
+blocks whose data inputs need no gradient.
+"""
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+F32 = torch.float32
+
+
+class Runtime:
+    """per-model execution state shared by all blocks: RNG words, training flag, dropout."""
+
+    def __init__(self, arena, seed=9595):
+        self.arena = arena
+        self.rng = ops.make_rng(seed, arena.device)
+        self.training = True
+        self.p_hidden = 0.1   # config.hidden_dropout_prob (src/lxrt/modeling.py:196)
+        self.p_attn = 0.1     # config.attention_probs_dropout_prob
+        self.p_readout = 0.5  # GCN/GIN read-out dropout (src/module/gcn.py:33)
+
+    def p(self, p):
+        return p if self.training else 0.0
+
+    def advance(self):
+        """new dropout masks / noise for the next pass (graph-capturable)."""
+        ops.rng_advance(self.rng, 1)
+
+
+def _w(rt, p):
+    return rt.arena.w(p)
+
+
+def _wgrad(rt, dy, x, ps):
+    gw, acc = rt.arena.target(ps)
+    ops.linear_wgrad(dy, x, gw, acc)
+
+
+def _colsum(rt, dy, ps):
+    ops.colsum(dy, rt.arena.atomic_target(ps))
+
+
+# --------------------------------------------------------------------------------- embeddings
+class EmbedFn(Function):
+    """BertEmbeddings.forward (src/lxrt/modeling.py:298-313)."""
+
+    @staticmethod
+    def forward(ctx, rt, mod, ids, seg, *params):
+        ctx.np = len(params)
+        a = rt.arena
+        out, z, stats = ops.embed_fwd(ids, seg, a.w(mod.word_embeddings.weight),
+                                      a.w(mod.position_embeddings.weight),
+                                      a.w(mod.token_type_embeddings.weight), mod.LayerNorm.weight.data,
+                                      mod.LayerNorm.bias.data, 1e-12, rt.p(rt.p_hidden), rt.rng, mod._sid)
+        ctx.rt, ctx.mod, ctx.p = rt, mod, rt.p(rt.p_hidden)
+        ctx.saved = (ids, seg, z, stats)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        rt, mod = ctx.rt, ctx.mod
+        ids, seg, z, stats = ctx.saved
+        a = rt.arena
+        ops.embed_bwd(ids, seg, dy.contiguous(), z, stats, mod.LayerNorm.weight.data,
+                      a.atomic_target(mod.word_embeddings.weight), a.atomic_target(mod.position_embeddings.weight),
+                      a.atomic_target(mod.token_type_embeddings.weight), a.atomic_target(mod.LayerNorm.weight),
+                      a.atomic_target(mod.LayerNorm.bias), ctx.p, rt.rng, mod._sid)
+        return (None,) * (4 + ctx.np)
+
+
+class VisnEmbedFn(Function):
+    """VisualFeatEncoder.forward (src/lxrt/modeling.py:546-556); feats/boxes already T."""
+
+    @staticmethod
+    def forward(ctx, rt, mod, feats, boxes, *params):
+        ctx.np = len(params)
+        u, _ = ops.linear_fwd(feats, _w(rt, mod.visn_fc.weight), None)
+        p = rt.p(rt.p_hidden)
+        out, z1, z2, stats = ops.visn_embed_fwd(
+            u, mod.visn_fc.bias.data, boxes, mod.box_fc.weight.data, mod.box_fc.bias.data,
+            mod.visn_layer_norm.weight.data, mod.visn_layer_norm.bias.data, mod.box_layer_norm.weight.data,
+            mod.box_layer_norm.bias.data, 1e-12, p, rt.rng, mod._sid)
+        ctx.rt, ctx.mod, ctx.p = rt, mod, p
+        ctx.saved = (feats, boxes, z1, z2, stats)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        rt, mod = ctx.rt, ctx.mod
+        feats, boxes, z1, z2, stats = ctx.saved
+        a = rt.arena
+        grads = dict(dbf=a.atomic_target(mod.visn_fc.bias), dg1=a.atomic_target(mod.visn_layer_norm.weight),
+                     db1=a.atomic_target(mod.visn_layer_norm.bias), dWb=a.atomic_target(mod.box_fc.weight),
+                     dbb=a.atomic_target(mod.box_fc.bias), dg2=a.atomic_target(mod.box_layer_norm.weight),
+                     db2=a.atomic_target(mod.box_layer_norm.bias))
+        du = ops.visn_embed_bwd(dy.contiguous(), z1, z2, stats, boxes, mod.visn_layer_norm.weight.data,
+                                mod.box_layer_norm.weight.data, grads, ctx.p, rt.rng, mod._sid)
+        _wgrad(rt, du, feats, mod.visn_fc.weight)
+        return (None,) * (4 + ctx.np)  # inputs are data: no gradient w.r.t. feats / boxes
+
+
+# --------------------------------------------------------------------------------- transformer blocks
+class AttnBlockFn(Function):
+    """BertSelfattLayer / BertCrossattLayer (src/lxrt/modeling.py:391-414):
+    y = LN(dropout(W_o attn(W_q x_q, W_k x_kv, W_v x_kv) + b_o) + x_q).
+    ``xkv is None`` = self-attention: one fused [3H,H] projection.  ``salt`` separates the
+    dropout streams of the two calls of the shared ``visual_attention`` block."""
+
+    @staticmethod
+    def forward(ctx, rt, att, outm, xq, xkv, mask, B, Sq, Sk, salt, *params):
+        ctx.np = len(params)
+        a = rt.arena
+        H = xq.shape[1]
+        heads = att.num_attention_heads
+        wq, wk, wv = att.query.weight, att.key.weight, att.value.weight
+        bq, bk, bv = att.query.bias, att.key.bias, att.value.bias
+        self_att = xkv is None
+        if self_att:
+            qkv, _ = ops.linear_fwd(xq, a.fused([wq, wk, wv]), a.fused([bq, bk, bv]))
+            q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+            kv = None
+        else:
+            qkv, _ = ops.linear_fwd(xq, a.w(wq), bq.data)
+            kv, _ = ops.linear_fwd(xkv, a.fused([wk, wv]), a.fused([bk, bv]))
+            q, k, v = qkv, kv[:, :H], kv[:, H:]
+        p_att, p_hid = rt.p(rt.p_attn), rt.p(rt.p_hidden)
+        c = ops.attn_fwd(q, k, v, mask, B, heads, Sq, Sk, p_att, rt.rng, att._sid + salt)
+        h, _ = ops.linear_fwd(c, a.w(outm.dense.weight), None)
+        y, z, stats = ops.ln_fwd(h, outm.dense.bias.data, xq, outm.LayerNorm.weight.data, outm.LayerNorm.bias.data,
+                                 1e-12, p_pre=p_hid, rng=rt.rng, sid_pre=outm._sid + salt)
+        ctx.rt, ctx.att, ctx.outm = rt, att, outm
+        ctx.dims = (B, Sq, Sk, heads, H, p_att, p_hid, self_att, salt)
+        ctx.saved = (xq, xkv, mask, qkv, kv, c, z, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        rt, att, outm = ctx.rt, ctx.att, ctx.outm
+        B, Sq, Sk, heads, H, p_att, p_hid, self_att, salt = ctx.dims
+        xq, xkv, mask, qkv, kv, c, z, stats = ctx.saved
+        a = rt.arena
+        wq, wk, wv = att.query.weight, att.key.weight, att.value.weight
+        bq, bk, bv = att.query.bias, att.key.bias, att.value.bias
+        d_h, d_res = ops.ln_bwd(dy.contiguous(), z, stats, outm.LayerNorm.weight.data,
+                                a.atomic_target(outm.LayerNorm.weight), a.atomic_target(outm.LayerNorm.bias),
+                                a.atomic_target(outm.dense.bias), want_dres=True, p_pre=p_hid, rng=rt.rng,
+                                sid_pre=outm._sid + salt)
+        _wgrad(rt, d_h, c, outm.dense.weight)
+        d_c = ops.linear_dgrad(d_h, a.w(outm.dense.weight))
+        if self_att:
+            dqkv = torch.empty_like(qkv)
+            ops.attn_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], mask, d_c, dqkv[:, :H], dqkv[:, H:2 * H],
+                         dqkv[:, 2 * H:], B, heads, Sq, Sk, p_att, rt.rng, att._sid + salt)
+            _wgrad(rt, dqkv, xq, [wq, wk, wv])
+            _colsum(rt, dqkv, [bq, bk, bv])
+            dxq = ops.linear_dgrad(dqkv, a.fused([wq, wk, wv]), residual=d_res)
+            dxkv = None
+        else:
+            dq = torch.empty_like(qkv)
+            dkv = torch.empty_like(kv)
+            ops.attn_bwd(qkv, kv[:, :H], kv[:, H:], mask, d_c, dq, dkv[:, :H], dkv[:, H:], B, heads, Sq, Sk, p_att,
+                         rt.rng, att._sid + salt)
+            _wgrad(rt, dq, xq, wq)
+            _colsum(rt, dq, bq)
+            _wgrad(rt, dkv, xkv, [wk, wv])
+            _colsum(rt, dkv, [bk, bv])
+            dxq = ops.linear_dgrad(dq, a.w(wq), residual=d_res)
+            dxkv = ops.linear_dgrad(dkv, a.fused([wk, wv]))
+        return (None, None, None, dxq, dxkv, None, None, None, None, None) + (None,) * ctx.np
+
+
+class FFNFn(Function):
+    """BertIntermediate + BertOutput (src/lxrt/modeling.py:428-445):
+    y = LN(dropout(W_2 gelu(W_1 x + b_1) + b_2) + x)."""
+
+    @staticmethod
+    def forward(ctx, rt, inter, outm, x, *params):
+        ctx.np = len(params)
+        a = rt.arena
+        act, u = ops.linear_fwd(x, a.w(inter.dense.weight), inter.dense.bias.data, act=ops.ACT_GELU,
+                                want_preact=True)
+        h, _ = ops.linear_fwd(act, a.w(outm.dense.weight), None)
+        p_hid = rt.p(rt.p_hidden)
+        y, z, stats = ops.ln_fwd(h, outm.dense.bias.data, x, outm.LayerNorm.weight.data, outm.LayerNorm.bias.data,
+                                 1e-12, p_pre=p_hid, rng=rt.rng, sid_pre=outm._sid)
+        ctx.rt, ctx.inter, ctx.outm, ctx.p = rt, inter, outm, p_hid
+        ctx.saved = (x, u, act, z, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        rt, inter, outm = ctx.rt, ctx.inter, ctx.outm
+        x, u, act, z, stats = ctx.saved
+        a = rt.arena
+        d_h, d_res = ops.ln_bwd(dy.contiguous(), z, stats, outm.LayerNorm.weight.data,
+                                a.atomic_target(outm.LayerNorm.weight), a.atomic_target(outm.LayerNorm.bias),
+                                a.atomic_target(outm.dense.bias), want_dres=True, p_pre=ctx.p, rng=rt.rng,
+                                sid_pre=outm._sid)
+        _wgrad(rt, d_h, act, outm.dense.weight)
+        d_u = ops.linear_dgrad(d_h, a.w(outm.dense.weight), gelu_aux=u)
+        _wgrad(rt, d_u, x, inter.dense.weight)
+        _colsum(rt, d_u, inter.dense.bias)
+        dx = ops.linear_dgrad(d_u, a.w(inter.dense.weight), residual=d_res)
+        return (None, None, None, dx) + (None,) * ctx.np
+
+
+# --------------------------------------------------------------------------------- heads
+class LinearActFn(Function):
+    """Linear followed by none / tanh / sigmoid.  ``out_f32`` keeps the result in fp32
+    (answer logits, encoder_adj probabilities)."""
+
+    @staticmethod
+    def forward(ctx, rt, lin, x, act, out_f32, *params):
+        ctx.np = len(params)
+        a = rt.arena
+        x2 = x if x.dim() == 2 else x.reshape(-1, x.shape[-1])
+        bias = lin.bias.data if lin.bias is not None else None
+        y, _ = ops.linear_fwd(x2, a.w(lin.weight), bias, act=act, out_f32=out_f32)
+        ctx.rt, ctx.lin, ctx.act, ctx.out_f32 = rt, lin, act, out_f32
+        ctx.saved = (x2, y)
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], y.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        rt, lin, act = ctx.rt, ctx.lin, ctx.act
+        x2, y = ctx.saved
+        a = rt.arena
+        dy = dy.reshape(y.shape).contiguous()
+        dt = x2.dtype
+        if act == ops.ACT_SIGMOID:
+            g = ops.sigmoid_bwd(dy if dy.dtype == F32 else dy.float(), y if y.dtype == F32 else y.float(), dt)
+        elif act == ops.ACT_TANH:
+            g = ops.tanh_bwd(dy, y)
+        else:
+            g = ops.cast_from_f32(dy, dt) if dy.dtype == F32 and dt != F32 else dy
+        _wgrad(rt, g, x2, lin.weight)
+        if lin.bias is not None:
+            _colsum(rt, g, lin.bias)
+        dx = ops.linear_dgrad(g, a.w(lin.weight)) if ctx.needs_input_grad[2] else None
+        if dx is not None:
+            dx = dx.view(ctx.xshape)
+        return (None, None, dx, None, None) + (None,) * ctx.np
+
+
+class MLPFn(Function):
+    """``Sequential(Linear, GeLU, LayerNorm)`` (node_fc / fusion_fc / first half of logit_fc,
+    src/vqa/vqacpv2_model.py:63-105)."""
+
+    @staticmethod
+    def forward(ctx, rt, lin, ln, eps, x, *params):
+        ctx.np = len(params)
+        a = rt.arena
+        x2 = x if x.dim() == 2 else x.reshape(-1, x.shape[-1])
+        act, u = ops.linear_fwd(x2, a.w(lin.weight), lin.bias.data, act=ops.ACT_GELU, want_preact=True)
+        y, z, stats = ops.ln_fwd(act, None, None, ln.weight.data, ln.bias.data, eps)
+        ctx.rt, ctx.lin, ctx.ln = rt, lin, ln
+        ctx.saved = (x2, u, z, stats)
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], y.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        rt, lin, ln = ctx.rt, ctx.lin, ctx.ln
+        x2, u, z, stats = ctx.saved
+        a = rt.arena
+        d_u, _ = ops.ln_bwd(dy.reshape(z.shape).contiguous(), z, stats, ln.weight.data, a.atomic_target(ln.weight),
+                            a.atomic_target(ln.bias), a.atomic_target(lin.bias), gelu_aux=u)
+        _wgrad(rt, d_u, x2, lin.weight)
+        dx = ops.linear_dgrad(d_u, a.w(lin.weight)).view(ctx.xshape) if ctx.needs_input_grad[4] else None
+        return (None, None, None, None, dx) + (None,) * ctx.np
+
+
+# --------------------------------------------------------------------------------- graph blocks
+class GCNFn(Function):
+    """GCN.forward (src/module/gcn.py:64-77): two GCNConv (LN(x + W (adj @ x)), gcn.py:22-29)
+    and the jump-knowledge sum of three read-outs dropout_.5(LN(GeLU(W_k h_k + b_k)))."""
+
+    @staticmethod
+    def forward(ctx, rt, gcn, x, adj, *params):
+        ctx.np = len(params)
+        a = rt.arena
+        B, N, H = x.shape
+        hs = [x.contiguous()]
+        convs = []
+        for conv in gcn.gnn_layers:
+            agg = ops.aggregate(adj, hs[-1])
+            t, _ = ops.linear_fwd(agg.view(B * N, H), a.w(conv.ctx_layer.weight), None)
+            h, z, stats = ops.ln_fwd(t, None, hs[-1].view(B * N, H), conv.layer_norm.weight.data,
+                                     conv.layer_norm.bias.data, 1e-5)
+            convs.append((agg, z, stats))
+            hs.append(h.view(B, N, H))
+        p_ro = rt.p(gcn.dropout_p)
+        ret = torch.empty((B * N, H), device=x.device, dtype=x.dtype)
+        reads = []
+        for k, (mlp, h) in enumerate(zip(gcn.linear_prediction, hs)):
+            act, u = ops.linear_fwd(h.view(B * N, H), a.w(mlp[0].weight), mlp[0].bias.data, act=ops.ACT_GELU,
+                                    want_preact=True)
+            _, z, stats = ops.ln_fwd(act, None, None, mlp[2].weight.data, mlp[2].bias.data, 1e-5, p_post=p_ro,
+                                     rng=rt.rng, sid_post=gcn._sid + k, out=ret, accumulate=k > 0)
+            reads.append((u, z, stats))
+        ctx.rt, ctx.gcn, ctx.p = rt, gcn, p_ro
+        ctx.saved = (adj, hs, convs, reads)
+        return ret.view(B, N, H)
+
+    @staticmethod
+    def backward(ctx, d_ret):
+        rt, gcn = ctx.rt, ctx.gcn
+        adj, hs, convs, reads = ctx.saved
+        a = rt.arena
+        B, N, H = hs[0].shape
+        d_ret = d_ret.contiguous().view(B * N, H)
+        dh = []
+        for k, (mlp, h) in enumerate(zip(gcn.linear_prediction, hs)):
+            u, z, stats = reads[k]
+            d_u, _ = ops.ln_bwd(d_ret, z, stats, mlp[2].weight.data, a.atomic_target(mlp[2].weight),
+                                a.atomic_target(mlp[2].bias), a.atomic_target(mlp[0].bias), p_post=ctx.p, rng=rt.rng,
+                                sid_post=gcn._sid + k, gelu_aux=u)
+            _wgrad(rt, d_u, h.view(B * N, H), mlp[0].weight)
+            dh.append(ops.linear_dgrad(d_u, a.w(mlp[0].weight)))
+        d_adj = None
+        for k in reversed(range(len(gcn.gnn_layers))):
+            conv = gcn.gnn_layers[k]
+            agg, z, stats = convs[k]
+            # dh[k+1] is complete here; its residual branch adds into dh[k]
+            d_t, _ = ops.ln_bwd(dh[k + 1], z, stats, conv.layer_norm.weight.data,
+                                a.atomic_target(conv.layer_norm.weight), a.atomic_target(conv.layer_norm.bias), None,
+                                d_res=dh[k])
+            _wgrad(rt, d_t, agg.view(B * N, H), conv.ctx_layer.weight)
+            d_agg = ops.linear_dgrad(d_t, a.w(conv.ctx_layer.weight)).view(B, N, H)
+            ops.aggregate(adj, d_agg, mode=ops.AGG_TRANSPOSE, out=dh[k].view(B, N, H))
+            if ctx.needs_input_grad[3]:
+                g = ops.bmm_nt(d_agg, hs[k])
+                d_adj = g if d_adj is None else d_adj.add_(g)
+        dx = dh[0].view(B, N, H) if ctx.needs_input_grad[2] else None
+        return (None, None, dx, d_adj) + (None,) * ctx.np
+
+
+class GINFn(Function):
+    """GIN.forward with n_layers=1 (src/module/gin.py:68-87): conv = LN(GeLU(W (x + (1+eps) A x) + b)),
+    two read-outs on [x, conv]."""
+
+    @staticmethod
+    def forward(ctx, rt, gin, x, adj, *params):
+        ctx.np = len(params)
+        a = rt.arena
+        B, N, H = x.shape
+        x = x.contiguous()
+        conv = gin.gnn_convs[0]
+        eps = conv.eps.data
+        hin = ops.aggregate(adj, x, scale_ptr=eps, self_w=1.0)
+        act, u = ops.linear_fwd(hin.view(B * N, H), a.w(conv.linear[0].weight), conv.linear[0].bias.data,
+                                act=ops.ACT_GELU, want_preact=True)
+        h1, z1, st1 = ops.ln_fwd(act, None, None, conv.linear[2].weight.data, conv.linear[2].bias.data, 1e-5)
+        hs = [x, h1.view(B, N, H)]
+        p_ro = rt.p(gin.dropout_p)
+        ret = torch.empty((B * N, H), device=x.device, dtype=x.dtype)
+        reads = []
+        for k, (mlp, h) in enumerate(zip(gin.linear_prediction, hs)):
+            ak, uk = ops.linear_fwd(h.view(B * N, H), a.w(mlp[0].weight), mlp[0].bias.data, act=ops.ACT_GELU,
+                                    want_preact=True)
+            _, zk, sk = ops.ln_fwd(ak, None, None, mlp[2].weight.data, mlp[2].bias.data, 1e-5, p_post=p_ro,
+                                   rng=rt.rng, sid_post=gin._sid + k, out=ret, accumulate=k > 0)
+            reads.append((uk, zk, sk))
+        ctx.rt, ctx.gin, ctx.p = rt, gin, p_ro
+        ctx.saved = (adj, hs, hin, u, z1, st1, reads)
+        return ret.view(B, N, H)
+
+    @staticmethod
+    def backward(ctx, d_ret):
+        rt, gin = ctx.rt, ctx.gin
+        adj, hs, hin, u, z1, st1, reads = ctx.saved
+        a = rt.arena
+        B, N, H = hs[0].shape
+        conv = gin.gnn_convs[0]
+        d_ret = d_ret.contiguous().view(B * N, H)
+        dh = []
+        for k, (mlp, h) in enumerate(zip(gin.linear_prediction, hs)):
+            uk, zk, sk = reads[k]
+            d_u, _ = ops.ln_bwd(d_ret, zk, sk, mlp[2].weight.data, a.atomic_target(mlp[2].weight),
+                                a.atomic_target(mlp[2].bias), a.atomic_target(mlp[0].bias), p_post=ctx.p, rng=rt.rng,
+                                sid_post=gin._sid + k, gelu_aux=uk)
+            _wgrad(rt, d_u, h.view(B * N, H), mlp[0].weight)
+            dh.append(ops.linear_dgrad(d_u, a.w(mlp[0].weight)))
+        d_u, _ = ops.ln_bwd(dh[1], z1, st1, conv.linear[2].weight.data, a.atomic_target(conv.linear[2].weight),
+                            a.atomic_target(conv.linear[2].bias), a.atomic_target(conv.linear[0].bias), gelu_aux=u)
+        _wgrad(rt, d_u, hin.view(B * N, H), conv.linear[0].weight)
+        d_hin = ops.linear_dgrad(d_u, a.w(conv.linear[0].weight)).view(B, N, H)
+        # hin = x + (1+eps) A x
+        ops.agg_dot(adj, hs[0], d_hin, a.atomic_target(conv.eps))
+        dx = dh[0].view(B, N, H)
+        ops.aggregate(adj, d_hin, mode=ops.AGG_TRANSPOSE, scale_ptr=conv.eps.data, self_w=1.0, out=dx)
+        d_adj = None
+        if ctx.needs_input_grad[3]:
+            d_adj = ops.bmm_nt(ops.scale(d_hin, 1.0, conv.eps.data), hs[0])
+        return (None, None, dx if ctx.needs_input_grad[2] else None, d_adj) + (None,) * ctx.np
+
+
+class RegenFn(Function):
+    """adjacency regeneration (src/module/graph_generative_modeling.py:225-228)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        S = ops.bmm_nt(x, x)
+        adj, colmax, argmax = ops.adj_regen_fwd(S)
+        ctx.saved = (x, S, adj, colmax, argmax)
+        return adj
+
+    @staticmethod
+    def backward(ctx, d_adj):
+        x, S, adj, colmax, argmax = ctx.saved
+        dS = ops.adj_regen_bwd(d_adj.contiguous(), S, adj, colmax, argmax)
+        return ops.aggregate(dS, x, mode=ops.AGG_SYMMETRIZE)
+
+
+class AdjInitFn(Function):
+    """scatter + symmetrise + Gaussian edge noise (src/vqa/vqacpv2.py:195-202,
+    src/module/graph_utils.py:162-168).  Returns (adj_noisy, grad_log_noise)."""
+
+    @staticmethod
+    def forward(ctx, e, N, sigma, randn, rng, sid):
+        adj, g = ops.adj_init_fwd(e.contiguous(), N, sigma, randn=randn, rng=rng, sid=sid)
+        ctx.mark_non_differentiable(g)
+        return adj, g
+
+    @staticmethod
+    def backward(ctx, d_adj, _):
+        return ops.adj_init_bwd(d_adj.contiguous()), None, None, None, None, None
+
+
+class FeatureNoiseFn(Function):
+    """add_feature_noise_v2 (src/module/graph_utils.py:144-149)."""
+
+    @staticmethod
+    def forward(ctx, x, sigma, randn, rng, sid):
+        out, g = ops.feature_noise(x.contiguous(), sigma, randn=randn, rng=rng, sid=sid)
+        ctx.mark_non_differentiable(g)
+        return out, g
+
+    @staticmethod
+    def backward(ctx, d_out, _):
+        return d_out, None, None, None, None
+
+
+class PoolConcatFn(Function):
+    """cat([x, tanh(nodes.mean(1))], -1) (src/vqa/vqacpv2.py:216-218)."""
+
+    @staticmethod
+    def forward(ctx, x, nodes):
+        out = ops.pool_concat_fwd(x.contiguous(), nodes.contiguous())
+        ctx.saved = (out, nodes.shape[1])
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        out, N = ctx.saved
+        return ops.pool_concat_bwd(d_out.contiguous(), out, N)
+
+
+class BcastRowsFn(Function):
+    """x.unsqueeze(1).repeat(1, N, 1) (src/vqa/vqacpv2.py:228)."""
+
+    @staticmethod
+    def forward(ctx, x, N):
+        return ops.bcast_rows(x.contiguous(), N)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.sum_rows(g.contiguous()), None
+
+
+# --------------------------------------------------------------------------------- losses
+class DSMFn(Function):
+    """loss_func (src/vqa/vqacpv2.py:48-51)."""
+
+    @staticmethod
+    def forward(ctx, score, g, sigma):
+        score = score.contiguous()
+        coef = 0.5 * sigma ** 2 / score.numel()  # 0.5 s^2 / (d1 d2) * mean over the batch
+        ctx.saved = (score, g, coef)
+        return ops.dsm_fwd(score, g.contiguous(), coef)
+
+    @staticmethod
+    def backward(ctx, gout):
+        score, g, coef = ctx.saved
+        return ops.dsm_bwd(score, g, gout.contiguous(), coef), None, None
+
+
+class SymKLFn(Function):
+    """compute_kl_loss (src/vqa/vqacpv2.py:54-61)."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        x, y = x.contiguous(), y.contiguous()
+        coef = 1.0 / x.numel()
+        ctx.saved = (x, y, coef)
+        return ops.symkl_fwd(x, y, coef)
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, y, coef = ctx.saved
+        return ops.symkl_bwd(x, y, gout.contiguous(), coef, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+
+
+class BCEFn(Function):
+    """nn.BCEWithLogitsLoss()(logit, target) (mean).  fp32 logits."""
+
+    @staticmethod
+    def forward(ctx, logit, target):
+        logit, target = logit.contiguous(), target.contiguous()
+        coef = 1.0 / logit.numel()
+        ctx.saved = (logit, target, coef)
+        return ops.bce_fwd(logit, target, coef)
+
+    @staticmethod
+    def backward(ctx, gout):
+        logit, target, coef = ctx.saved
+        return ops.bce_bwd(logit, target, gout.contiguous(), coef, F32), None

@@ -1,0 +1,439 @@
+"""LXMERT encoder with the reference's module tree, state_dict keys and forward signatures
+(src/lxrt/modeling.py of jingjing12110/X-GGM), executed by the HIP blocks of
+``xggm_amd.functional``.
+
+The nn.Modules below only HOLD parameters under the reference's names
+(``bert.encoder.layer.0.attention.self.query.weight`` ...); none of their arithmetic runs in
+PyTorch.  Activations travel as 2-D [batch*seq, hidden] tensors in the compute dtype.
+"""
+import copy
+import json
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import functional as XF
+from .. import ops
+from ..runtime import runtime_of, bind_root
+
+BertLayerNorm = nn.LayerNorm
+
+
+class GeLU(nn.Module):
+    """parameter-free marker kept so ``nn.Sequential(Linear, GeLU(), LayerNorm)`` heads have
+    the reference's indices (0, 2[, 3]); the activation itself is fused into the GEMM epilogue
+    (ref: src/lxrt/modeling.py:127-140)."""
+
+    def forward(self, x):
+        raise RuntimeError("GeLU is fused into the preceding Linear; call the owning head module")
+
+
+class VisualConfig(object):
+    """ref: src/lxrt/modeling.py:150-179"""
+    VISUAL_LOSSES = ['obj', 'attr', 'feat']
+
+    def __init__(self, l_layers=12, x_layers=5, r_layers=0):
+        self.l_layers = l_layers
+        self.x_layers = x_layers
+        self.r_layers = r_layers
+        self.visual_feat_dim = 2048
+        self.visual_pos_dim = 4
+        self.obj_id_num = 1600
+        self.attr_id_num = 400
+        self.visual_losses = self.VISUAL_LOSSES
+
+    def set_visual_dims(self, feat_dim, pos_dim):
+        self.visual_feat_dim = feat_dim
+        self.visual_pos_dim = pos_dim
+
+
+VISUAL_CONFIG = VisualConfig()
+
+
+class BertConfig(object):
+    """ref: src/lxrt/modeling.py:182-272"""
+
+    def __init__(self, vocab_size_or_config_json_file, hidden_size=768, num_hidden_layers=12,
+                 num_attention_heads=12, intermediate_size=3072, hidden_act="gelu",
+                 hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,
+                 max_position_embeddings=512, type_vocab_size=2, initializer_range=0.02):
+        if isinstance(vocab_size_or_config_json_file, str):
+            with open(vocab_size_or_config_json_file, "r", encoding='utf-8') as reader:
+                for key, value in json.loads(reader.read()).items():
+                    self.__dict__[key] = value
+        elif isinstance(vocab_size_or_config_json_file, int):
+            self.vocab_size = vocab_size_or_config_json_file
+            self.hidden_size = hidden_size
+            self.num_hidden_layers = num_hidden_layers
+            self.num_attention_heads = num_attention_heads
+            self.hidden_act = hidden_act
+            self.intermediate_size = intermediate_size
+            self.hidden_dropout_prob = hidden_dropout_prob
+            self.attention_probs_dropout_prob = attention_probs_dropout_prob
+            self.max_position_embeddings = max_position_embeddings
+            self.type_vocab_size = type_vocab_size
+            self.initializer_range = initializer_range
+        else:
+            raise ValueError("First argument must be either a vocabulary size (int) or the path to a "
+                             "pretrained model config file (str)")
+        if self.hidden_act != "gelu":
+            raise NotImplementedError("only the erf-GELU of the reference scripts is implemented in HIP")
+
+    @classmethod
+    def from_dict(cls, json_object):
+        config = BertConfig(vocab_size_or_config_json_file=-1)
+        for key, value in json_object.items():
+            config.__dict__[key] = value
+        return config
+
+    @classmethod
+    def from_json_file(cls, json_file):
+        with open(json_file, "r", encoding='utf-8') as reader:
+            return cls.from_dict(json.loads(reader.read()))
+
+    def to_dict(self):
+        return copy.deepcopy(self.__dict__)
+
+    def to_json_string(self):
+        return json.dumps(self.to_dict(), indent=2, sort_keys=True) + "\n"
+
+
+def _2d(x):
+    return x if x.dim() == 2 else x.reshape(-1, x.shape[-1])
+
+
+def _mask2d(mask, B, S):
+    """[B,1,1,S] additive mask of the reference (or None) -> contiguous fp32 [B,S]."""
+    if mask is None:
+        return None
+    return mask.reshape(B, S).to(torch.float32).contiguous()
+
+
+class BertEmbeddings(nn.Module):
+    """ref: src/lxrt/modeling.py:278-313"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(config.vocab_size, config.hidden_size, padding_idx=0)
+        self.position_embeddings = nn.Embedding(config.max_position_embeddings, config.hidden_size, padding_idx=0)
+        self.token_type_embeddings = nn.Embedding(config.type_vocab_size, config.hidden_size, padding_idx=0)
+        self.LayerNorm = BertLayerNorm(config.hidden_size, eps=1e-12)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+    def forward(self, input_ids, token_type_ids=None):
+        rt = runtime_of(self)
+        B, T = input_ids.shape
+        out = XF.EmbedFn.apply(rt, self, input_ids.contiguous(),
+                               None if token_type_ids is None else token_type_ids.contiguous(),
+                               *self.parameters())
+        return out.view(B, T, -1)
+
+
+class BertAttention(nn.Module):
+    """parameter holder, ref: src/lxrt/modeling.py:316-343 (its forward lives in AttnBlockFn)"""
+
+    def __init__(self, config, ctx_dim=None):
+        super().__init__()
+        if config.hidden_size % config.num_attention_heads != 0:
+            raise ValueError("The hidden size (%d) is not a multiple of the number of attention heads (%d)"
+                             % (config.hidden_size, config.num_attention_heads))
+        self.num_attention_heads = config.num_attention_heads
+        self.attention_head_size = int(config.hidden_size / config.num_attention_heads)
+        self.all_head_size = self.num_attention_heads * self.attention_head_size
+        if self.attention_head_size != 64:
+            raise NotImplementedError("the HIP attention core is built for head size 64 (got %d)"
+                                      % self.attention_head_size)
+        if ctx_dim is None:
+            ctx_dim = config.hidden_size
+        self.query = nn.Linear(config.hidden_size, self.all_head_size)
+        self.key = nn.Linear(ctx_dim, self.all_head_size)
+        self.value = nn.Linear(ctx_dim, self.all_head_size)
+        self.dropout = nn.Dropout(config.attention_probs_dropout_prob)
+
+
+class BertAttOutput(nn.Module):
+    """ref: src/lxrt/modeling.py:377-388"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.hidden_size)
+        self.LayerNorm = BertLayerNorm(config.hidden_size, eps=1e-12)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+
+def _attn_block(att, outm, x, ctx, mask, salt=0):
+    """x [B,Sq,H]; ctx None (self) or [B,Sk,H]; mask additive broadcastable to [B,Sk] or None."""
+    rt = runtime_of(att)
+    B, Sq, H = x.shape
+    Sk = Sq if ctx is None else ctx.shape[1]
+    y = XF.AttnBlockFn.apply(rt, att, outm, _2d(x), None if ctx is None else _2d(ctx), _mask2d(mask, B, Sk), B, Sq,
+                             Sk, salt, *att.parameters(), *outm.parameters())
+    return y.view(B, Sq, H)
+
+
+class BertCrossattLayer(nn.Module):
+    """ref: src/lxrt/modeling.py:391-400"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.att = BertAttention(config)
+        self.output = BertAttOutput(config)
+
+    def forward(self, input_tensor, ctx_tensor, ctx_att_mask=None, salt=1):
+        return _attn_block(self.att, self.output, input_tensor, ctx_tensor, ctx_att_mask, salt)
+
+
+class BertSelfattLayer(nn.Module):
+    """ref: src/lxrt/modeling.py:403-414"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.self = BertAttention(config)
+        self.output = BertAttOutput(config)
+
+    def forward(self, input_tensor, attention_mask):
+        return _attn_block(self.self, self.output, input_tensor, None, attention_mask)
+
+
+class BertIntermediate(nn.Module):
+    """ref: src/lxrt/modeling.py:417-431"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.intermediate_size)
+
+
+class BertOutput(nn.Module):
+    """ref: src/lxrt/modeling.py:434-445"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.intermediate_size, config.hidden_size)
+        self.LayerNorm = BertLayerNorm(config.hidden_size, eps=1e-12)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+
+def _ffn_block(inter, outm, x):
+    rt = runtime_of(inter)
+    shape = x.shape
+    y = XF.FFNFn.apply(rt, inter, outm, _2d(x), *inter.parameters(), *outm.parameters())
+    return y.view(shape)
+
+
+class BertLayer(nn.Module):
+    """ref: src/lxrt/modeling.py:448-459"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.attention = BertSelfattLayer(config)
+        self.intermediate = BertIntermediate(config)
+        self.output = BertOutput(config)
+
+    def forward(self, hidden_states, attention_mask):
+        attention_output = self.attention(hidden_states, attention_mask)
+        return _ffn_block(self.intermediate, self.output, attention_output)
+
+
+class LXRTXLayer(nn.Module):
+    """ref: src/lxrt/modeling.py:469-527"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.visual_attention = BertCrossattLayer(config)
+        self.lang_self_att = BertSelfattLayer(config)
+        self.visn_self_att = BertSelfattLayer(config)
+        self.lang_inter = BertIntermediate(config)
+        self.lang_output = BertOutput(config)
+        self.visn_inter = BertIntermediate(config)
+        self.visn_output = BertOutput(config)
+
+    def cross_att(self, lang_input, lang_attention_mask, visn_input, visn_attention_mask):
+        lang_att_output = self.visual_attention(lang_input, visn_input, ctx_att_mask=visn_attention_mask, salt=1)
+        visn_att_output = self.visual_attention(visn_input, lang_input, ctx_att_mask=lang_attention_mask, salt=2)
+        return lang_att_output, visn_att_output
+
+    def self_att(self, lang_input, lang_attention_mask, visn_input, visn_attention_mask):
+        return (self.lang_self_att(lang_input, lang_attention_mask),
+                self.visn_self_att(visn_input, visn_attention_mask))
+
+    def output_fc(self, lang_input, visn_input):
+        return (_ffn_block(self.lang_inter, self.lang_output, lang_input),
+                _ffn_block(self.visn_inter, self.visn_output, visn_input))
+
+    def forward(self, lang_feats, lang_attention_mask, visn_feats, visn_attention_mask):
+        lang_att_output, visn_att_output = self.cross_att(lang_feats, lang_attention_mask, visn_feats,
+                                                          visn_attention_mask)
+        lang_att_output, visn_att_output = self.self_att(lang_att_output, lang_attention_mask, visn_att_output,
+                                                         visn_attention_mask)
+        return self.output_fc(lang_att_output, visn_att_output)
+
+
+class VisualFeatEncoder(nn.Module):
+    """ref: src/lxrt/modeling.py:530-556"""
+
+    def __init__(self, config):
+        super().__init__()
+        feat_dim = VISUAL_CONFIG.visual_feat_dim
+        pos_dim = VISUAL_CONFIG.visual_pos_dim
+        if pos_dim != 4:
+            raise NotImplementedError("the HIP visual embedding is built for 4-d boxes")
+        self.visn_fc = nn.Linear(feat_dim, config.hidden_size)
+        self.visn_layer_norm = BertLayerNorm(config.hidden_size, eps=1e-12)
+        self.box_fc = nn.Linear(pos_dim, config.hidden_size)
+        self.box_layer_norm = BertLayerNorm(config.hidden_size, eps=1e-12)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+    def forward(self, visn_input):
+        feats, boxes = visn_input
+        rt = runtime_of(self)
+        B, N, F = feats.shape
+        dt = rt.arena.compute_dtype
+        f2 = feats.reshape(B * N, F)
+        b2 = boxes.reshape(B * N, 4)
+        f2 = ops.cast_from_f32(f2.contiguous(), dt) if f2.dtype == torch.float32 else f2.contiguous()
+        b2 = ops.cast_from_f32(b2.contiguous(), dt) if b2.dtype == torch.float32 else b2.contiguous()
+        out = XF.VisnEmbedFn.apply(rt, self, f2, b2, *self.parameters())
+        return out.view(B, N, -1)
+
+
+class LXRTEncoder(nn.Module):
+    """ref: src/lxrt/modeling.py:559-605"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.visn_fc = VisualFeatEncoder(config)
+        self.num_l_layers = VISUAL_CONFIG.l_layers
+        self.num_x_layers = VISUAL_CONFIG.x_layers
+        self.num_r_layers = VISUAL_CONFIG.r_layers
+        print("LXRT encoder with %d l_layers, %d x_layers, and %d r_layers."
+              % (self.num_l_layers, self.num_x_layers, self.num_r_layers))
+        self.layer = nn.ModuleList([BertLayer(config) for _ in range(self.num_l_layers)])
+        self.x_layers = nn.ModuleList([LXRTXLayer(config) for _ in range(self.num_x_layers)])
+        self.r_layers = nn.ModuleList([BertLayer(config) for _ in range(self.num_r_layers)])
+
+    def forward(self, lang_feats, lang_attention_mask, visn_feats, visn_attention_mask=None):
+        visn_feats = self.visn_fc(visn_feats)
+        for layer_module in self.layer:
+            lang_feats = layer_module(lang_feats, lang_attention_mask)
+        for layer_module in self.r_layers:
+            visn_feats = layer_module(visn_feats, visn_attention_mask)
+        for layer_module in self.x_layers:
+            lang_feats, visn_feats = layer_module(lang_feats, lang_attention_mask, visn_feats, visn_attention_mask)
+        return lang_feats, visn_feats
+
+
+class BertPooler(nn.Module):
+    """ref: src/lxrt/modeling.py:608-620"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.hidden_size)
+        self.activation = nn.Tanh()
+
+    def forward(self, hidden_states):
+        rt = runtime_of(self)
+        first_token_tensor = hidden_states[:, 0]  # strided rows, read in place by the GEMM
+        return XF.LinearActFn.apply(rt, self.dense, first_token_tensor, ops.ACT_TANH, False, *self.dense.parameters())
+
+
+class BertPreTrainedModel(nn.Module):
+    """ref: src/lxrt/modeling.py:717-747.  ``from_pretrained`` of the reference downloads
+    ``bert-base-uncased`` from S3; offline it can only read a local directory / state dict."""
+
+    def __init__(self, config, *inputs, **kwargs):
+        super().__init__()
+        if not isinstance(config, BertConfig):
+            raise ValueError("Parameter config in `{}(config)` should be an instance of class `BertConfig`."
+                             .format(self.__class__.__name__))
+        self.config = config
+
+    def init_bert_weights(self, module):
+        if isinstance(module, (nn.Linear, nn.Embedding)):
+            module.weight.data.normal_(mean=0.0, std=self.config.initializer_range)
+        elif isinstance(module, BertLayerNorm):
+            module.bias.data.zero_()
+            module.weight.data.fill_(1.0)
+        if isinstance(module, nn.Linear) and module.bias is not None:
+            module.bias.data.zero_()
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, state_dict=None, cache_dir=None, from_tf=False,
+                        *inputs, **kwargs):
+        import os
+        if not os.path.isdir(str(pretrained_model_name_or_path)):
+            raise FileNotFoundError(
+                "xggm_amd runs offline: '%s' is not a local directory holding bert_config.json "
+                "(+ pytorch_model.bin).  Build the model from a BertConfig instead."
+                % pretrained_model_name_or_path)
+        config = BertConfig.from_json_file(os.path.join(pretrained_model_name_or_path, "bert_config.json"))
+        model = cls(config, *inputs, **kwargs)
+        weights = os.path.join(pretrained_model_name_or_path, "pytorch_model.bin")
+        if state_dict is None and os.path.exists(weights):
+            state_dict = torch.load(weights, map_location="cpu", weights_only=True)
+        if state_dict is not None:
+            sd = {}
+            for key, value in state_dict.items():  # same key surgery as modeling.py:848-858
+                new_key = key.replace('gamma', 'weight') if 'gamma' in key else key
+                new_key = new_key.replace('beta', 'bias') if 'beta' in new_key else new_key
+                sd[new_key] = value
+            prefix = '' if any(k.startswith('bert.') for k in sd) or not hasattr(model, 'bert') else 'bert.'
+            missing, unexpected = model.load_state_dict({prefix + k: v for k, v in sd.items()}, strict=False)
+            if missing:
+                print("Weights of {} not initialized from pretrained model: {}".format(cls.__name__, missing))
+        return model
+
+
+class LXRTModel(BertPreTrainedModel):
+    """ref: src/lxrt/modeling.py:894-952"""
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.embeddings = BertEmbeddings(config)
+        self.encoder = LXRTEncoder(config)
+        self.pooler = BertPooler(config)
+        self.apply(self.init_bert_weights)
+
+    def forward(self, input_ids, token_type_ids=None, attention_mask=None, visual_feats=None,
+                visual_attention_mask=None):
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        if token_type_ids is None:
+            token_type_ids = torch.zeros_like(input_ids)
+        # additive masks (1 - m) * -10000, [B,1,1,S] as in the reference (:919-939)
+        extended_attention_mask = (1.0 - attention_mask.unsqueeze(1).unsqueeze(2).to(torch.float32)) * -10000.0
+        if visual_attention_mask is not None:
+            extended_visual_attention_mask = (1.0 - visual_attention_mask.unsqueeze(1).unsqueeze(2).to(
+                torch.float32)) * -10000.0
+        else:
+            extended_visual_attention_mask = None
+        embedding_output = self.embeddings(input_ids, token_type_ids)
+        lang_feats, visn_feats = self.encoder(embedding_output, extended_attention_mask, visn_feats=visual_feats,
+                                              visn_attention_mask=extended_visual_attention_mask)
+        pooled_output = self.pooler(lang_feats)
+        return (lang_feats, visn_feats), pooled_output
+
+
+class LXRTFeatureExtraction(BertPreTrainedModel):
+    """ref: src/lxrt/modeling.py:1064-1093"""
+
+    def __init__(self, config, mode='lxr'):
+        super().__init__(config)
+        self.bert = LXRTModel(config)
+        self.mode = mode
+        self.apply(self.init_bert_weights)
+        bind_root(self)
+
+    def forward(self, input_ids, token_type_ids=None, attention_mask=None, visual_feats=None,
+                visual_attention_mask=None):
+        feat_seq, pooled_output = self.bert(input_ids, token_type_ids, attention_mask, visual_feats=visual_feats,
+                                            visual_attention_mask=visual_attention_mask)
+        if 'x' == self.mode:
+            return pooled_output
+        elif 'x' in self.mode and ('l' in self.mode or 'r' in self.mode):
+            return feat_seq, pooled_output
+        elif 'l' in self.mode or 'r' in self.mode:
+            return feat_seq
+
+
+VisualBertForLXRFeature = LXRTFeatureExtraction  # name used by src/lxrt/entry.py:26

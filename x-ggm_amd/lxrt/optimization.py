@@ -1,0 +1,143 @@
+"""BertAdam with the reference's constructor and semantics (src/lxrt/optimization.py:58-203)
+running as ONE fused HIP pass per contiguous parameter range: clip scale, moment update,
+weight decay, scheduled step and the bf16 shadow-weight write.
+
+State lives in the model's flat arena (``next_m``/``next_v`` = arena.m / arena.v); the
+per-parameter ``state['step']`` of the reference becomes one device-resident counter per
+arena group (all parameters of a group always step together), from which
+``warmup_linear`` is evaluated on the device -- no host synchronisation, graph replayable.
+"""
+import math
+
+import torch
+from torch.optim import Optimizer
+
+from .. import ops
+
+
+def warmup_cosine(x, warmup=0.002):
+    if x < warmup:
+        return x / warmup
+    return 0.5 * (1.0 + math.cos(math.pi * x))
+
+
+def warmup_constant(x, warmup=0.002):
+    if x < warmup:
+        return x / warmup
+    return 1.0
+
+
+def warmup_linear(x, warmup=0.002):
+    if x < warmup:
+        return x / warmup
+    return max((x - 1.) / (warmup - 1.), 0)
+
+
+SCHEDULES = {'warmup_cosine': warmup_cosine, 'warmup_constant': warmup_constant, 'warmup_linear': warmup_linear}
+
+
+def _arena_of_params(params):
+    for p in params:
+        xg = getattr(p, "_xg", None)
+        if xg is not None:
+            return xg[0]
+    return None
+
+
+def clip_grad_norm_(parameters, max_norm):
+    """fused replacement of ``nn.utils.clip_grad_norm_(model.parameters(), 5.)``
+    (src/vqa/vqacpv2.py:175): one sum-of-squares reduction per active arena range; the scale
+    min(1, max_norm/(norm+1e-6)) is applied INSIDE the following BertAdam.step (the gradients
+    in memory stay unscaled).  Returns the total norm as a device scalar."""
+    params = [p for p in parameters]
+    arena = _arena_of_params(params)
+    if arena is None:
+        raise RuntimeError("clip_grad_norm_: parameters are not arena-managed; run a forward first")
+    arena.sqnorm.zero_()
+    for g in arena.active_groups():
+        G = arena.groups[g]
+        ops.sqnorm(arena.grads[G.start:G.end], arena.sqnorm)
+    arena.pending_clip = float(max_norm)
+    return arena.sqnorm.sqrt()
+
+
+class BertAdam(Optimizer):
+    """ref: src/lxrt/optimization.py:58-203 (no bias correction; decoupled weight decay on
+    every parameter; gradient clipping is done outside, as LXMERT does)."""
+
+    def __init__(self, params, lr, warmup=-1, t_total=-1, schedule='warmup_linear', b1=0.9, b2=0.999, e=1e-6,
+                 weight_decay=0.01, max_grad_norm=1.0):
+        if lr < 0.0:
+            raise ValueError("Invalid learning rate: {} - should be >= 0.0".format(lr))
+        if schedule not in SCHEDULES:
+            raise ValueError("Invalid schedule parameter: {}".format(schedule))
+        if schedule != 'warmup_linear' and t_total != -1:
+            raise NotImplementedError("only warmup_linear (the reference trainers' schedule) runs on the device")
+        if not 0.0 <= warmup < 1.0 and not warmup == -1:
+            raise ValueError("Invalid warmup: {} - should be in [0.0, 1.0[ or -1".format(warmup))
+        if not 0.0 <= b1 < 1.0:
+            raise ValueError("Invalid b1 parameter: {} - should be in [0.0, 1.0[".format(b1))
+        if not 0.0 <= b2 < 1.0:
+            raise ValueError("Invalid b2 parameter: {} - should be in [0.0, 1.0[".format(b2))
+        if not e >= 0.0:
+            raise ValueError("Invalid epsilon value: {} - should be >= 0.0".format(e))
+        defaults = dict(lr=lr, schedule=schedule, warmup=warmup, t_total=t_total, b1=b1, b2=b2, e=e,
+                        weight_decay=weight_decay, max_grad_norm=max_grad_norm)
+        super().__init__(params, defaults)
+
+    def _hyper_of_group(self, arena, gname):
+        """the optimiser param_group that holds (all) parameters of arena group ``gname``."""
+        first = arena.groups[gname].params[0]
+        for pg in self.param_groups:
+            if any(p is first for p in pg['params']):
+                return pg
+        return None
+
+    def get_lr(self):
+        arena = _arena_of_params(p for pg in self.param_groups for p in pg['params'])
+        if arena is None:
+            return [0]
+        steps = arena.steps.tolist()
+        lr = []
+        for g, G in arena.groups.items():
+            pg = self._hyper_of_group(arena, g)
+            if pg is None:
+                continue
+            s = steps[arena.group_index[g]]
+            if pg['t_total'] != -1:
+                sc = SCHEDULES[pg['schedule']](s / pg['t_total'], pg['warmup'])
+            else:
+                sc = 1.0
+            lr.extend([pg['lr'] * sc] * len(G.params))
+        return lr
+
+    def zero_grad(self, set_to_none=True):
+        super().zero_grad(set_to_none=True)
+        arena = _arena_of_params(p for pg in self.param_groups for p in pg['params'])
+        if arena is not None:
+            arena.begin_pass()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        arena = _arena_of_params(p for pg in self.param_groups for p in pg['params'])
+        if arena is None:
+            raise RuntimeError("BertAdam.step: parameters are not arena-managed; run a forward/backward first")
+        sq = arena.sqnorm if arena.pending_clip is not None else None
+        max_norm = arena.pending_clip if arena.pending_clip is not None else 0.0
+        for g in arena.active_groups():
+            G = arena.groups[g]
+            pg = self._hyper_of_group(arena, g)
+            if pg is None:
+                continue  # parameters not handed to this optimiser
+            if any(p.grad is None for p in G.params):
+                raise RuntimeError("arena group '%s' received gradients for only part of its parameters" % g)
+            gi = arena.group_index[g]
+            step_t, scale_t = arena.steps[gi:gi + 1], arena.lr_scale[gi:gi + 1]
+            ops.sched_step(step_t, scale_t, pg['t_total'], pg['warmup'])
+            sl = slice(G.start, G.end)
+            ops.bertadam(arena.params[sl], arena.grads[sl], arena.m[sl], arena.v[sl],
+                         None if arena.shadow is None else arena.shadow[sl], sq, max_norm, pg['lr'], scale_t,
+                         pg['b1'], pg['b2'], pg['e'], pg['weight_decay'])
+        arena.pending_clip = None
+        return loss

@@ -180,9 +180,10 @@ def ln_fwd(x, bias, residual, gamma, beta, eps, p_pre=0.0, p_post=0.0, rng=None,
 
 
 def ln_bwd(dy, z, stats, gamma, dgamma, dbeta, dbias, want_din=True, want_dres=False, d_res=None,
-           p_pre=0.0, p_post=0.0, rng=None, sid_pre=0, sid_post=0, out_scale=1.0):
+           p_pre=0.0, p_post=0.0, rng=None, sid_pre=0, sid_post=0, out_scale=1.0, gelu_aux=None):
     """Returns (d_in, d_res).  dgamma/dbeta/dbias (fp32, may be None) are accumulated.
-    If ``d_res`` is given the residual gradient is ADDED into it."""
+    If ``d_res`` is given the residual gradient is ADDED into it.  ``gelu_aux`` = the
+    pre-activation u when the LN input was gelu(u): d_in/dbias become grads of u."""
     _c(dy), _c(z, dy.dtype)
     M, H = dy.shape
     assert z.shape == dy.shape and tuple(stats.shape) == (M, 2)
@@ -198,7 +199,7 @@ def ln_bwd(dy, z, stats, gamma, dgamma, dbeta, dbias, want_din=True, want_dres=F
         assert d_res.shape == dy.shape and d_res.dtype == dy.dtype and d_res.is_contiguous()
     call("xggm_ln_bwd_" + sfx(dy.dtype), ptr(dy), ptr(z), ptr(stats), ptr(gamma), ptr(d_in), ptr(d_res),
          ptr(dgamma), ptr(dbeta), ptr(dbias), M, H, float(p_pre), float(p_post), ptr(rng), sid_pre, sid_post,
-         float(out_scale), int(acc), stream())
+         float(out_scale), int(acc), ptr(gelu_aux), stream())
     return d_in, d_res
 
 
@@ -306,7 +307,7 @@ def adj_init_fwd(e, N, sigma, randn=None, rng=None, sid=0, B=None, want_gradlog=
         _c(e, F32, "encoder_adj output")
         B = e.shape[0]
         assert e.shape[1] == N * (N - 1) // 2, "encoder_adj width %d != N(N-1)/2" % e.shape[1]
-    dev = e.device if e is not None else randn.device
+    dev = e.device if e is not None else (randn.device if randn is not None else rng.device)
     if randn is not None:
         _c(randn, F32, "randn")
         assert tuple(randn.shape) == (B, N, N)
@@ -443,6 +444,38 @@ def sched_step(step, lr_scale, t_total, warmup):
 
 def rng_advance(rng, by=1):
     call("xggm_rng_advance", ptr(rng), int(by), stream())
+
+
+def scale(x, s=1.0, scale_ptr=None):
+    """s * (1 + *scale_ptr) * x"""
+    _c(x)
+    out = torch.empty_like(x)
+    call("xggm_scale_" + sfx(x.dtype), ptr(x), ptr(out), x.numel(), float(s), ptr(scale_ptr), stream())
+    return out
+
+
+def sigmoid_bwd(dy, y, dt):
+    _c(dy, F32), _c(y, F32)
+    out = torch.empty(y.shape, device=y.device, dtype=dt)
+    call("xggm_sigmoid_bwd_" + sfx(dt), ptr(dy), ptr(y), ptr(out), y.numel(), stream())
+    return out
+
+
+def tanh_bwd(dy, y):
+    _c(dy), _c(y, dy.dtype)
+    out = torch.empty_like(y)
+    call("xggm_tanh_bwd_" + sfx(y.dtype), ptr(dy), ptr(y), ptr(out), y.numel(), stream())
+    return out
+
+
+def cast_from_f32(x, dt):
+    """fp32 -> T copy (identity copy for T = fp32 is skipped)."""
+    _c(x, F32)
+    if dt == F32:
+        return x
+    out = torch.empty(x.shape, device=x.device, dtype=dt)
+    call("xggm_cast_from_f32_" + sfx(dt), ptr(x), ptr(out), x.numel(), stream())
+    return out
 
 
 def cast_bf16(x, out):

@@ -1,0 +1,137 @@
+"""The VQA-CP v2 training iteration (src/vqa/vqacpv2.py:164-254) on the HIP blocks.
+
+``loss_func`` / ``compute_kl_loss`` keep the reference names and signatures
+(src/vqa/vqacpv2.py:48-61).  ``plain_pass`` / ``ggm_pass`` are the two optimiser passes of
+one iteration; ``train_iteration`` strings them together in the VQA order (plain first) or
+the GQA order (GGM first, src/gqa/gqa_ood.py:165-292).  The only PyTorch arithmetic left is
+scalar glue on 0-dim loss tensors and the removal of the adjacency diagonal of the INPUT.
+"""
+import random
+
+import torch
+import torch.nn as nn
+
+from .. import functional as XF
+from ..lxrt.optimization import clip_grad_norm_
+from ..runtime import runtime_of
+
+
+def loss_func(score, grad_log_q_noise, sigma=0.2):
+    """0.5 sigma^2 mean_b sum_ij (score - g)^2 / (d1 d2).  ref: src/vqa/vqacpv2.py:48-51"""
+    return XF.DSMFn.apply(score, grad_log_q_noise, sigma)
+
+
+def compute_kl_loss(x, y):
+    """symmetric KL of the last-dim softmaxes, mean over all elements.
+    ref: src/vqa/vqacpv2.py:54-61"""
+    if x.dtype != y.dtype:
+        x, y = x.float(), y.float()
+    return XF.SymKLFn.apply(x, y)
+
+
+class BCEWithLogitsLoss(nn.Module):
+    """nn.BCEWithLogitsLoss() of src/vqa/vqacpv2.py:131 on fp32 logits."""
+
+    def forward(self, logit, target):
+        return XF.BCEFn.apply(logit.float(), target.float())
+
+
+def remove_diagonal(adj_true):
+    """adj_true.triu(1) + adj_true.tril(-1)   (src/vqa/vqacpv2.py:188): input preparation"""
+    return adj_true.triu(1) + adj_true.tril(-1)
+
+
+def plain_pass(model, optim, bce_loss, feats, boxes, sent, target, clip=5.0):
+    """step A: src/vqa/vqacpv2.py:170-177"""
+    model.zero_grad()
+    _, _, x = model(feats, boxes, sent)
+    logit = model.logit_fc(x)
+    loss = bce_loss(logit, target) * target.size(1)
+    loss.backward()
+    clip_grad_norm_(model.parameters(), clip)
+    optim.step()
+    optim.zero_grad()
+    return loss.detach(), logit.detach()
+
+
+def ggm_pass(model, optim, bce_loss, feats, boxes, sent, target, adj_true, branch, sigma=1.0, kl_weight=8.0,
+             randn=None, clip=5.0):
+    """step B: relation generation (branch 'rel', src/vqa/vqacpv2.py:195-225) or
+    representation generation ('node', :228-254).  ``randn`` injects the Gaussian draw
+    (parity tests); None = in-kernel Philox."""
+    model.zero_grad()
+    rt = runtime_of(model)
+    feat_seq, _, x = model(feats, boxes, sent)
+    adj_true = remove_diagonal(adj_true.float())
+    N = feat_seq[1].shape[1]
+    A = target.size(1)
+    if branch == "rel":
+        e = model.encoder_adj(x)
+        adj_noise, grad_log_noise = XF.AdjInitFn.apply(e, N, sigma, randn, None if randn is not None else rt.rng, 9001)
+        node_feats, adj_noise = model.generator(feat_seq[1], adj_noise)
+        loss_grad = loss_func(adj_noise, grad_log_noise, sigma=sigma)
+        d_loss = compute_kl_loss(adj_true, adj_noise) * A
+        loss_sm = kl_weight * d_loss + loss_grad
+        w_sm = 6
+    elif branch == "node":
+        node_feats = XF.BcastRowsFn.apply(model.node_fc(x), N)  # == node_fc(x.unsqueeze(1).repeat(1, N, 1))
+        node_feats, feat_grad = XF.FeatureNoiseFn.apply(node_feats, sigma, randn,
+                                                        None if randn is not None else rt.rng, 9002)
+        node_feats, _ = model.generator(node_feats, adj_true)
+        d_loss = compute_kl_loss(node_feats, feat_seq[1]) * A
+        loss_grad = loss_func(node_feats, feat_grad, sigma=sigma)
+        loss_sm = 0.15 * d_loss + 6 * loss_grad
+        w_sm = 1.1
+    else:
+        raise ValueError(branch)
+    x_gen = model.fusion_fc(XF.PoolConcatFn.apply(x, node_feats))
+    logit = model.logit_fc(x_gen)
+    loss = bce_loss(logit, target) * A
+    loss = loss + w_sm * loss_sm
+    loss.backward()
+    clip_grad_norm_(model.parameters(), clip)
+    optim.step()
+    optim.zero_grad()
+    return loss.detach(), logit.detach(), dict(d_loss=d_loss.detach(), loss_grad=loss_grad.detach())
+
+
+def pick_branch(delta, rng=random):
+    """random.randint(1, 10) <= args.delta -> relation generation (src/vqa/vqacpv2.py:192-193)"""
+    return "rel" if rng.randint(1, 10) <= delta else "node"
+
+
+def train_iteration(model, optim, bce_loss, batch, delta=5, sigma=1.0, order="vqa", branch=None, clip=5.0):
+    """one iteration = two fwd+bwd+clip+BertAdam passes.  ``batch``: dict with feats, boxes,
+    sent, target, adj_true (device tensors).  order 'vqa': plain then GGM (KL weight 8);
+    'gqa': GGM then plain (KL weight 12, src/gqa/gqa_ood.py:197)."""
+    rt = runtime_of(model)
+    model.train()
+    if branch is None:
+        branch = pick_branch(delta)
+    args = (batch["feats"], batch["boxes"], batch["sent"], batch["target"])
+    out = {}
+    if order == "vqa":
+        out["loss_plain"], out["logit"] = plain_pass(model, optim, bce_loss, *args, clip=clip)
+        rt.advance()
+        out["loss_ggm"], _, ex = ggm_pass(model, optim, bce_loss, *args, batch["adj_true"], branch, sigma, 8.0,
+                                          clip=clip)
+        rt.advance()
+    else:
+        out["loss_ggm"], _, ex = ggm_pass(model, optim, bce_loss, *args, batch["adj_true"], branch, sigma, 12.0,
+                                          clip=clip)
+        rt.advance()
+        out["loss_plain"], out["logit"] = plain_pass(model, optim, bce_loss, *args, clip=clip)
+        rt.advance()
+    out.update(ex)
+    out["branch"] = branch
+    return out
+
+
+def make_optimizer(model, lr, t_total, warmup=0.1):
+    """the two parameter groups of src/vqa/vqacpv2.py:113-128: heads/generator at 4*lr,
+    encoder at lr; BertAdam(warmup=0.1, t_total=2*iters)."""
+    from ..lxrt.optimization import BertAdam
+    lxrt_ids = set(map(id, model.lxrt_encoder.parameters()))
+    base_params = [p for p in model.parameters() if id(p) not in lxrt_ids]
+    groups = [{"params": base_params, "lr": lr * 4}, {"params": list(model.lxrt_encoder.parameters())}]
+    return BertAdam(groups, lr=lr, warmup=warmup, t_total=t_total)
