@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""Benchmark of the X-GGM training iteration on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one training iteration of the reference loop (src/vqa/vqacpv2.py:164-254): a
+plain-VQA pass and a graph-generative pass, EACH a full forward + backward + grad-norm clip +
+BertAdam update of the 220.8 M-parameter LXMERT(9/5/5) + GCNx2 generator + heads model, on a
+synthetic VQA-CP-v2-shaped batch of 32 samples per GPU (36 objects x 2048-d, 20 tokens,
+A = 2274), bf16 storage / fp32 accumulate, dropout on.  Weak scaling: 32 samples per rank,
+gradients averaged over RCCL.  Prints ONE JSON line (rank 0).
+
+Extra objects on the line:
+  roofline     the dominant kernel family of the step, timed live with HIP events on the
+               launch stream in an instrumented (un-captured) iteration
+  cpu_baseline the CPU oracle (oracle/xggm_oracle.py, torch fp32) timed on this box's host cores
+               on one iteration of the same workload (N = 1 only)
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--batch", type=int, default=32, help="samples per GPU")
+    p.add_argument("--answers", type=int, default=2274)
+    p.add_argument("--delta", type=int, default=5, help="relation-branch probability delta/10")
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-kernel-timing", action="store_true")
+    p.add_argument("--wire", default="bf16", choices=["bf16", "f32"], help="gradient all-reduce dtype")
+    p.add_argument("--seed", type=int, default=9595)
+    return p.parse_args()
+
+
+def build(args, device):
+    from xggm_amd import param, synth
+    from xggm_amd.lxrt.modeling import BertConfig, VISUAL_CONFIG
+    from xggm_amd.vqa.vqacpv2_model import VQAModel
+    from xggm_amd.vqa.vqacpv2 import make_optimizer
+    VISUAL_CONFIG.set_visual_dims(2048, 4)
+    a = param.parse_args(["--llayers", "9", "--xlayers", "5", "--rlayers", "5"])
+    torch.manual_seed(args.seed)
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model = VQAModel(args.answers, gnn="GCN", n_layers=2, args=a, config=BertConfig(30522), compute_dtype=dt)
+    model.seed = args.seed
+    model = model.to(device)
+    rank = int(os.environ.get("RANK", 0))
+    b = synth.vqa_batch(args.batch, A=args.answers, seed=1000 + rank)
+    batch = {k: torch.from_numpy(v).to(device) for k, v in b.items() if k != "randn_adj"}
+    n_iters = args.steps + args.warmup + 16
+    optim = make_optimizer(model, 1e-6, 2 * n_iters)  # lr of script/vqacpv2.sh:26, t_total = 2 * iterations
+    return model, optim, batch
+
+
+def kernel_timing(trainer, branches):
+    """time every C-ABI launch of one un-captured iteration per branch with HIP events recorded
+    on the launch stream; a long sleep kernel is queued first so the host runs ahead and the
+    events bracket back-to-back GPU execution, not Python latency."""
+    from xggm_amd import _lib
+    rec = []
+    orig = _lib.call
+
+    def timed(name, *a):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig(name, *a)
+        e1.record()
+        rec.append((name, a, e0, e1))
+
+    import xggm_amd.ops as ops_mod
+    for kind in ["plain"] + list(branches):
+        torch.cuda.synchronize()
+        torch.cuda._sleep(int(4e8))  # ~0.2 s head start for the host
+        ops_mod.call = timed
+        try:
+            trainer._eager_pass(kind)
+        finally:
+            ops_mod.call = orig
+        torch.cuda.synchronize()
+    fam = {}
+    for name, a, e0, e1 in rec:
+        ms = e0.elapsed_time(e1)
+        f = fam.setdefault(name, dict(ms=0.0, n=0, flops=0.0, bytes=0.0))
+        f["ms"] += ms
+        f["n"] += 1
+        if name.startswith("xggm_gemm_"):
+            M, N, K, batch = a[3], a[4], a[5], a[11]
+            f["flops"] += 2.0 * M * N * K * batch
+        elif name == "xggm_bertadam_f32":
+            f["bytes"] += a[5] * (16 + 12 + (2 if a[4] else 0))
+        elif name == "xggm_sqnorm_f32":
+            f["bytes"] += a[1] * 4
+    return fam
+
+
+def cpu_baseline(args):
+    """the CPU oracle on ONE iteration (plain + relation pass, each fwd+bwd+clip+BertAdam) of the
+    same workload; weights are random (values do not affect the timing)."""
+    from oracle import shapes, xggm_oracle as O
+    from xggm_amd import synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = shapes.FULL
+    g = torch.Generator().manual_seed(0)
+    P = {}
+    for k, s in shapes.model_shapes(cfg, args.answers).items():
+        t = torch.randn(s, generator=g) * 0.02
+        if len(s) == 1 and k.endswith("weight"):
+            t = t + 1.0
+        P[k] = t
+    M = {k: torch.zeros_like(v) for k, v in P.items()}
+    V = {k: torch.zeros_like(v) for k, v in P.items()}
+    step = {k: 0 for k in P}
+    b = synth.vqa_batch(args.batch, A=args.answers, seed=1000)
+    b["randn_node"] = synth.randn_nodes(args.batch, 36, 768, 0)
+    b = {k: torch.from_numpy(v) for k, v in b.items()}
+    t0 = time.perf_counter()
+    O.train_pass(P, M, V, step, b, cfg, "plain", 1e-6, 100)
+    O.train_pass(P, M, V, step, b, cfg, "rel", 1e-6, 100, sigma=1.0, kl_weight=8.0, gnn="GCN")
+    dt = time.perf_counter() - t0
+    return {"value": round(args.batch / dt, 3), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "1 iteration (plain pass + relation-generation pass, each fwd+bwd+clip+BertAdam) at %d "
+                      "samples, fp32, full 9/5/5 model, torch CPU oracle, %.1f s" % (args.batch, dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    from xggm_amd.engine import CapturedTrainer
+    from xggm_amd.runtime import runtime_of
+
+    model, optim, batch = build(args, device)
+    # first forward creates the arena; data parallel hooks need it
+    rt = runtime_of(model)
+    if world > 1:
+        from xggm_amd.vqa.vqacpv2 import enable_data_parallel
+        enable_data_parallel(model, wire_dtype=torch.bfloat16 if args.wire == "bf16" else None)
+    trainer = CapturedTrainer(model, optim, batch, sigma=1.0, order="vqa", use_graph=not args.no_graph)
+    pyrng = random.Random(args.seed)  # identical draws on every rank (src/vqa/vqacpv2.py:192)
+
+    def branch():
+        return "rel" if pyrng.randint(1, 10) <= args.delta else "node"
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.iteration(branch())
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.iteration(branch())
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_step = 1000.0 * dt / args.steps
+    value = args.batch * world * args.steps / dt
+
+    # per-branch step time (diagnostic; not part of the timed region)
+    per_branch = {}
+    if rank == 0 or world > 1:
+        for br in ("rel", "node"):
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                trainer.iteration(br)
+            barrier()
+            per_branch[br] = round(1000.0 * (time.perf_counter() - t1) / 5, 3)
+
+    roofline, kernels = None, None
+    if rank == 0 and not args.no_kernel_timing:
+        fam = kernel_timing(trainer, ["rel", "node"])
+        tot = sum(f["ms"] for f in fam.values())
+        kernels = {k: {"ms": round(f["ms"], 3), "launches": f["n"], "share": round(f["ms"] / tot, 4)}
+                   for k, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])[:8]}
+        dom = max(fam, key=lambda k: fam[k]["ms"])
+        f = fam[dom]
+        if dom.startswith("xggm_gemm_"):
+            ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
+            roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                        "launches": f["n"], "avg_us": round(1000 * f["ms"] / f["n"], 2)}
+        else:
+            ach = f["bytes"] / (f["ms"] * 1e-3) / 1e9 if f["bytes"] else 0.0
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
+                        "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
+                        "launches": f["n"], "avg_us": round(1000 * f["ms"] / f["n"], 2)}
+        # the optimiser is the HBM-bound half of the step: always report it too
+        if "xggm_bertadam_f32" in fam and fam["xggm_bertadam_f32"]["ms"] > 0:
+            fo = fam["xggm_bertadam_f32"]
+            kernels["xggm_bertadam_f32"]["GB/s"] = round(fo["bytes"] / (fo["ms"] * 1e-3) / 1e9, 1)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args)
+
+    if rank == 0:
+        line = {
+            "metric": "train samples/sec (36-obj VQA batch); one step = plain + GGM pass, each fwd+bwd+clip+BertAdam",
+            "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "1xMI355X bf16: VQA-CP-v2-shaped synthetic batch=%d/GPU, 36 objects x 2048, "
+                                   "20 tokens, A=%d, LXMERT 9/5/5 + GCNx2, full fwd+bwd+clip+BertAdam x2 passes, "
+                                   "dropout on, delta=%d branch mix" % (args.batch, args.answers, args.delta),
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                       "hip_graph": not args.no_graph, "grad_wire": args.wire if world > 1 else None},
+            "ms_per_step_by_branch": per_branch,
+            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,122 @@
+"""Graph-captured training iteration.
+
+Eager execution of one pass issues ~700 kernel launches through Python; at 32 samples per GPU
+each kernel runs for microseconds, so the host would be the bottleneck.  ``CapturedTrainer``
+records each pass ONCE into a hipGraph (torch.cuda.CUDAGraph: every kernel here is launched on
+torch's current stream, so stream capture sees them all, forward, backward, clip and BertAdam
+alike) and replays it per step -- "HIP graphs instead of a tracing compiler".  Everything a
+replay needs to differ from the previous one lives in device memory: the batch (static input
+buffers), the Philox offset, the per-group step counters and schedule values.
+
+With data parallelism each pass is captured as two graphs (forward+backward | clip+update)
+and the gradient all-reduce runs between them on the live RCCL communicator.
+"""
+import torch
+
+from .runtime import runtime_of
+from .vqa.vqacpv2 import (forward_backward_plain, forward_backward_ggm, clip_and_step, _sync_grads,
+                          BCEWithLogitsLoss)
+
+
+class CapturedTrainer:
+    def __init__(self, model, optim, batch, sigma=1.0, order="vqa", clip=5.0, use_graph=True, warmup_iters=2):
+        """``batch``: dict of DEVICE tensors feats, boxes, input_ids, input_mask, segment_ids,
+        target, adj_true; they become the static input buffers (``load_batch`` copies into them)."""
+        self.model, self.optim = model, optim
+        self.rt = runtime_of(model)
+        self.static = {k: v.clone() for k, v in batch.items() if torch.is_tensor(v)}
+        self.sigma, self.clip = sigma, clip
+        self.kl_weight = 8.0 if order == "vqa" else 12.0
+        self.order = order
+        self.bce = BCEWithLogitsLoss()
+        self.use_graph = use_graph
+        self.graphs = {}
+        self.outputs = {}
+        self.split = getattr(model, "_grad_sync", None) is not None
+        model.train()
+        if use_graph:
+            self._capture(warmup_iters)
+
+    # ------------------------------------------------------------------ the two halves of a pass
+    def _fwd_bwd(self, kind):
+        s = self.static
+        sent = (s["input_ids"], s["input_mask"], s["segment_ids"])
+        if kind == "plain":
+            loss, logit = forward_backward_plain(self.model, self.bce, s["feats"], s["boxes"], sent, s["target"])
+        else:
+            loss, logit, _ = forward_backward_ggm(self.model, self.bce, s["feats"], s["boxes"], sent, s["target"],
+                                                  s["adj_true"], kind, self.sigma, self.kl_weight)
+        return loss, logit
+
+    def _update(self):
+        total = clip_and_step(self.model, self.optim, self.clip)
+        self.rt.advance()
+        return total
+
+    def _eager_pass(self, kind):
+        loss, logit = self._fwd_bwd(kind)
+        _sync_grads(self.model)
+        total = self._update()
+        return loss, logit, total
+
+    # ------------------------------------------------------------------ capture
+    def _capture(self, warmup_iters):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup_iters):
+                for kind in ("plain", "rel", "node"):
+                    self._eager_pass(kind)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        pool = None
+        for kind in ("plain", "rel", "node"):
+            if not self.split:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    out = self._eager_pass(kind)
+                pool = g.pool()
+                self.graphs[kind] = (g,)
+                self.outputs[kind] = out
+            else:
+                g1 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1, pool=pool):
+                    loss, logit = self._fwd_bwd(kind)
+                pool = g1.pool()
+                ranges = None
+                from .dist import active_ranges
+                ranges = active_ranges(self.rt.arena)
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, pool=pool):
+                    total = self._update()
+                self.graphs[kind] = (g1, g2, ranges)
+                self.outputs[kind] = (loss, logit, total)
+        torch.cuda.synchronize()
+
+    # ------------------------------------------------------------------ run
+    def load_batch(self, batch):
+        for k, v in batch.items():
+            if k in self.static:
+                self.static[k].copy_(v, non_blocking=True)
+
+    def run_pass(self, kind):
+        if not self.use_graph:
+            return self._eager_pass(kind)
+        gs = self.graphs[kind]
+        if len(gs) == 1:
+            gs[0].replay()
+        else:
+            gs[0].replay()
+            self.model._grad_sync.sync(gs[2])
+            gs[1].replay()
+        return self.outputs[kind]
+
+    def iteration(self, branch):
+        """one training iteration: VQA order = plain then GGM; GQA order = GGM then plain."""
+        if self.order == "vqa":
+            a = self.run_pass("plain")
+            b = self.run_pass(branch)
+        else:
+            b = self.run_pass(branch)
+            a = self.run_pass("plain")
+        return a, b

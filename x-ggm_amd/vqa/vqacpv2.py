@@ -41,23 +41,37 @@ def remove_diagonal(adj_true):
     return adj_true.triu(1) + adj_true.tril(-1)
 
 
-def plain_pass(model, optim, bce_loss, feats, boxes, sent, target, clip=5.0):
-    """step A: src/vqa/vqacpv2.py:170-177"""
+def enable_data_parallel(model, group=None, wire_dtype=None):
+    """one process per GPU: average the flat gradient arena over ``group`` between backward and
+    the fused clip + BertAdam of every pass (xggm_amd.dist.GradSync); replicas start equal."""
+    from ..dist import GradSync, broadcast_params
+    arena = runtime_of(model).arena
+    broadcast_params(arena, group)
+    object.__setattr__(model, "_grad_sync", GradSync(arena.grads, group, wire_dtype))
+    return model
+
+
+def _sync_grads(model):
+    gs = getattr(model, "_grad_sync", None)
+    if gs is not None:
+        from ..dist import active_ranges
+        gs.sync(active_ranges(runtime_of(model).arena))
+
+
+def forward_backward_plain(model, bce_loss, feats, boxes, sent, target):
+    """step A up to backward: src/vqa/vqacpv2.py:170-174"""
     model.zero_grad()
     _, _, x = model(feats, boxes, sent)
     logit = model.logit_fc(x)
     loss = bce_loss(logit, target) * target.size(1)
     loss.backward()
-    clip_grad_norm_(model.parameters(), clip)
-    optim.step()
-    optim.zero_grad()
     return loss.detach(), logit.detach()
 
 
-def ggm_pass(model, optim, bce_loss, feats, boxes, sent, target, adj_true, branch, sigma=1.0, kl_weight=8.0,
-             randn=None, clip=5.0):
-    """step B: relation generation (branch 'rel', src/vqa/vqacpv2.py:195-225) or
-    representation generation ('node', :228-254).  ``randn`` injects the Gaussian draw
+def forward_backward_ggm(model, bce_loss, feats, boxes, sent, target, adj_true, branch, sigma=1.0, kl_weight=8.0,
+                         randn=None):
+    """step B up to backward: relation generation (branch 'rel', src/vqa/vqacpv2.py:195-222) or
+    representation generation ('node', :228-251).  ``randn`` injects the Gaussian draw
     (parity tests); None = in-kernel Philox."""
     model.zero_grad()
     rt = runtime_of(model)
@@ -89,10 +103,31 @@ def ggm_pass(model, optim, bce_loss, feats, boxes, sent, target, adj_true, branc
     loss = bce_loss(logit, target) * A
     loss = loss + w_sm * loss_sm
     loss.backward()
-    clip_grad_norm_(model.parameters(), clip)
+    return loss.detach(), logit.detach(), dict(d_loss=d_loss.detach(), loss_grad=loss_grad.detach())
+
+
+def clip_and_step(model, optim, clip=5.0):
+    """nn.utils.clip_grad_norm_(params, 5.) + optim.step() + optim.zero_grad()
+    (src/vqa/vqacpv2.py:175-177), fused: one norm reduction, one update pass."""
+    total = clip_grad_norm_(model.parameters(), clip)
     optim.step()
     optim.zero_grad()
-    return loss.detach(), logit.detach(), dict(d_loss=d_loss.detach(), loss_grad=loss_grad.detach())
+    return total
+
+
+def plain_pass(model, optim, bce_loss, feats, boxes, sent, target, clip=5.0):
+    out = forward_backward_plain(model, bce_loss, feats, boxes, sent, target)
+    _sync_grads(model)
+    clip_and_step(model, optim, clip)
+    return out
+
+
+def ggm_pass(model, optim, bce_loss, feats, boxes, sent, target, adj_true, branch, sigma=1.0, kl_weight=8.0,
+             randn=None, clip=5.0):
+    out = forward_backward_ggm(model, bce_loss, feats, boxes, sent, target, adj_true, branch, sigma, kl_weight, randn)
+    _sync_grads(model)
+    clip_and_step(model, optim, clip)
+    return out
 
 
 def pick_branch(delta, rng=random):
