@@ -89,7 +89,7 @@ def kernel_timing(trainer, branches):
     import xggm_amd.ops as ops_mod
     for kind in ["plain"] + list(branches):
         torch.cuda.synchronize()
-        torch.cuda._sleep(int(4e8))  # ~0.2 s head start for the host
+        torch.cuda._sleep(int(5e7))  # head start for the host: launches queue up behind it
         ops_mod.call = timed
         try:
             trainer._eager_pass(kind)
@@ -117,7 +117,8 @@ def cpu_baseline(args):
     same workload; weights are random (values do not affect the timing)."""
     from oracle import shapes, xggm_oracle as O
     from xggm_amd import synth
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU a 16-core CPU share; more threads than that only thrash
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
     torch.set_num_threads(cores)
     cfg = shapes.FULL
     g = torch.Generator().manual_seed(0)
@@ -142,6 +143,14 @@ def cpu_baseline(args):
                       "samples, fp32, full 9/5/5 model, torch CPU oracle, %.1f s" % (args.batch, dt)}
 
 
+def log(msg):
+    """progress on stderr (the JSON line is the only thing on stdout)"""
+    print("[bench %6.1fs] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
+
+
+T_START = time.perf_counter()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -158,13 +167,16 @@ def main():
     from xggm_amd.engine import CapturedTrainer
     from xggm_amd.runtime import runtime_of
 
+    log("building the model (rank %d/%d)" % (rank, world))
     model, optim, batch = build(args, device)
+    log("model on %s" % device)
     # first forward creates the arena; data parallel hooks need it
     rt = runtime_of(model)
     if world > 1:
         from xggm_amd.vqa.vqacpv2 import enable_data_parallel
         enable_data_parallel(model, wire_dtype=torch.bfloat16 if args.wire == "bf16" else None)
     trainer = CapturedTrainer(model, optim, batch, sigma=1.0, order="vqa", use_graph=not args.no_graph)
+    log("trainer ready (hip_graph=%s)" % (not args.no_graph))
     pyrng = random.Random(args.seed)  # identical draws on every rank (src/vqa/vqacpv2.py:192)
 
     def branch():
@@ -179,6 +191,7 @@ def main():
     for _ in range(args.warmup):
         trainer.iteration(branch())
     barrier()
+    log("warmup done")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         trainer.iteration(branch())
@@ -191,6 +204,7 @@ def main():
         dt = float(t.item())
     ms_step = 1000.0 * dt / args.steps
     value = args.batch * world * args.steps / dt
+    log("timed region: %.3f ms/step, %.1f samples/s" % (ms_step, value))
 
     # per-branch step time (diagnostic; not part of the timed region)
     per_branch = {}
@@ -205,6 +219,7 @@ def main():
 
     roofline, kernels = None, None
     if rank == 0 and not args.no_kernel_timing:
+        log("kernel timing pass")
         fam = kernel_timing(trainer, ["rel", "node"])
         tot = sum(f["ms"] for f in fam.values())
         kernels = {k: {"ms": round(f["ms"], 3), "launches": f["n"], "share": round(f["ms"] / tot, 4)}
@@ -228,7 +243,9 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        log("cpu baseline (oracle, one iteration)")
         cpu = cpu_baseline(args)
+        log("cpu baseline done: %s" % cpu["value"])
 
     if rank == 0:
         line = {

@@ -195,6 +195,25 @@ int xggm_bcast_rows_bf16(const void* x, void* out, int B, int N, int H, xggm_str
 int xggm_sum_rows_f32(const void* g, void* out, int B, int N, int H, xggm_stream_t stream);
 int xggm_sum_rows_bf16(const void* g, void* out, int B, int N, int H, xggm_stream_t stream);
 
+/* ---- graph attention (GATConv, src/module/gat.py:25-49) ---------------------------------------
+ * s fp32 [B*N,2] = h [a1 a2] (from xggm_gemm, c_f32); att[i][j] = softmax_j(adj_ij == 0 ? -9e15 :
+ * LeakyReLU_alpha(s1_i + s2_j)).  backward: ds (T [B*N,2]) from d_att. */
+int xggm_gat_att_fwd(const float* s, const float* adj, float* att, int B, int N, float alpha, xggm_stream_t stream);
+int xggm_gat_att_bwd_f32(const float* d_att, const float* att, const float* s, const float* adj, void* ds, int B, int N,
+                         float alpha, xggm_stream_t stream);
+int xggm_gat_att_bwd_bf16(const float* d_att, const float* att, const float* s, const float* adj, void* ds, int B, int N,
+                          float alpha, xggm_stream_t stream);
+/* out[m*ld_out + c] = elu(x[m*D + c]) (head concat = column slice), and its backward from y */
+int xggm_elu_fwd_f32(const void* x, void* out, int M, int D, int64_t ld_out, xggm_stream_t stream);
+int xggm_elu_fwd_bf16(const void* x, void* out, int M, int D, int64_t ld_out, xggm_stream_t stream);
+int xggm_elu_bwd_f32(const void* dy, const void* y, void* dx, int M, int D, int64_t ld, xggm_stream_t stream);
+int xggm_elu_bwd_bf16(const void* dy, const void* y, void* dx, int M, int D, int64_t ld, xggm_stream_t stream);
+/* F.dropout(x, p) with the Philox mask of (rng, sid); applying it to a gradient is its backward */
+int xggm_dropout_f32(const void* x, void* out, int64_t n, float p, const uint64_t* rng, uint32_t sid,
+                     xggm_stream_t stream);
+int xggm_dropout_bf16(const void* x, void* out, int64_t n, float p, const uint64_t* rng, uint32_t sid,
+                      xggm_stream_t stream);
+
 /* ---- losses (scalars are device fp32; *loss must hold the running value, usually 0) ------
  * loss_func: src/vqa/vqacpv2.py:48-51.  *loss += coef * sum (s-g)^2; ds = gout*2*coef*(s-g) */
 int xggm_dsm_loss_fwd_f32(const void* s, const float* g, float* loss, int64_t n, float coef, xggm_stream_t stream);

@@ -117,3 +117,17 @@ def test_schedule_and_tokenised_features():
     assert f[0].input_ids[:5] == [101, 7, 7, 7, 102] and sum(f[0].input_mask) == 5 and len(f[0].input_ids) == 20
     assert f[1].input_ids[0] == 101 and f[1].input_ids[19] == 102 and sum(f[1].input_mask) == 20
     assert f[0].segment_ids == [0] * 20
+
+
+def test_wordpiece_tokenizer(tmp_path):
+    from xggm_amd.lxrt.tokenization import BertTokenizer
+    from xggm_amd.lxrt.entry import convert_sents_to_features
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", "what", "is", "the", "man", "hold", "##ing", "?", "un",
+             "##aff", "##able", ",", "cafe"]
+    f = tmp_path / "vocab.txt"
+    f.write_text("\n".join(vocab) + "\n")
+    tok = BertTokenizer(str(f), do_lower_case=True)
+    assert tok.tokenize("What is the man HOLDING?") == ["what", "is", "the", "man", "hold", "##ing", "?"]
+    assert tok.tokenize("unaffable, café zzz") == ["un", "##aff", "##able", ",", "cafe", "[UNK]"]
+    feats = convert_sents_to_features(["What is the man holding?"], 20, tok)
+    assert feats[0].input_ids[:9] == [2, 5, 6, 7, 8, 9, 10, 11, 3] and sum(feats[0].input_mask) == 9

@@ -525,3 +525,59 @@ class BCEFn(Function):
     def backward(ctx, gout):
         logit, target, coef = ctx.saved
         return ops.bce_bwd(logit, target, gout.contiguous(), coef, F32), None
+
+
+class GATFn(Function):
+    """GAT.forward (src/module/gat.py:72-79): dropout(.5) on the input, n_head GATConv
+    (gat.py:25-49) concatenated along the feature axis."""
+
+    @staticmethod
+    def forward(ctx, rt, gat, x, adj, *params):
+        ctx.np = len(params)
+        a = rt.arena
+        B, N, H = x.shape
+        x = x.contiguous()
+        p = rt.p(gat.dropout)
+        xd = ops.dropout(x, p, rt.rng, gat._sid) if p > 0 else x
+        x2 = xd.view(B * N, H)
+        heads = list(gat.gat_layers)
+        D = heads[0].dim_hidden
+        out = torch.empty((B * N, D * len(heads)), device=x.device, dtype=x.dtype)
+        saved = []
+        for k, conv in enumerate(heads):
+            h, _ = ops.linear_fwd(x2, a.w(conv.linear_layer.weight), None)
+            a2 = a.w(conv.attn_layer.weight).view(2, D)
+            s, _ = ops.linear_fwd(h, a2, None, out_f32=True)          # [B*N, 2]: a1.h_i, a2.h_j
+            att = ops.gat_att_fwd(s, adj, conv.alpha)
+            pre = ops.aggregate(att, h.view(B, N, D))
+            ops.elu_fwd(pre.view(B * N, D), out, k * D)
+            saved.append((h, s, att))
+        ctx.rt, ctx.gat, ctx.p = rt, gat, p
+        ctx.saved = (x2, adj, out, saved)
+        ctx.dims = (B, N, H, D)
+        return out.view(B, N, -1)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        rt, gat = ctx.rt, ctx.gat
+        x2, adj, out, saved = ctx.saved
+        B, N, H, D = ctx.dims
+        a = rt.arena
+        d_out = d_out.contiguous().view(B * N, -1)
+        dx = None
+        for k, conv in enumerate(gat.gat_layers):
+            h, s, att = saved[k]
+            d_pre = ops.elu_bwd(d_out, out, k * D, D)
+            d_att = ops.bmm_nt(d_pre.view(B, N, D), h.view(B, N, D))
+            d_h = ops.aggregate(att, d_pre.view(B, N, D), mode=ops.AGG_TRANSPOSE).view(B * N, D)
+            ds = ops.gat_att_bwd(d_att, att, s, adj, conv.alpha, h.dtype)
+            a2 = a.w(conv.attn_layer.weight).view(2, D)
+            ga, acc = a.target(conv.attn_layer.weight)
+            ops.linear_wgrad(ds, h, ga.view(2, D), acc)
+            d_h = ops.linear_dgrad(ds, a2, residual=d_h)
+            _wgrad(rt, d_h, x2, conv.linear_layer.weight)
+            g = ops.linear_dgrad(d_h, a.w(conv.linear_layer.weight), residual=dx)
+            dx = g
+        if ctx.p > 0:
+            dx = ops.dropout(dx, ctx.p, rt.rng, gat._sid)
+        return (None, None, dx.view(B, N, H) if ctx.needs_input_grad[2] else None, None) + (None,) * ctx.np

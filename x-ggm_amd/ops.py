@@ -506,3 +506,47 @@ def triu_index(k, N):
     i, j = ctypes.c_int(), ctypes.c_int()
     _lib.check(_lib.lib.xggm_triu_index(k, N, ctypes.byref(i), ctypes.byref(j)), "xggm_triu_index")
     return i.value, j.value
+
+
+# ----------------------------------------------------------------------------- graph attention
+def gat_att_fwd(s, adj, alpha):
+    _c(s, F32, "s"), _c(adj, F32, "adj")
+    B, N, _ = adj.shape
+    assert tuple(s.shape) == (B * N, 2)
+    att = torch.empty_like(adj)
+    call("xggm_gat_att_fwd", ptr(s), ptr(adj), ptr(att), B, N, float(alpha), stream())
+    return att
+
+
+def gat_att_bwd(d_att, att, s, adj, alpha, dt):
+    _c(d_att, F32), _c(att, F32), _c(s, F32), _c(adj, F32)
+    B, N, _ = adj.shape
+    ds = torch.empty((B * N, 2), device=adj.device, dtype=dt)
+    call("xggm_gat_att_bwd_" + sfx(dt), ptr(d_att), ptr(att), ptr(s), ptr(adj), ptr(ds), B, N, float(alpha), stream())
+    return ds
+
+
+def elu_fwd(x, out, col0):
+    """out[:, col0:col0+D] = elu(x) for contiguous x [M,D] and a contiguous wider out [M,ld]."""
+    _c(x), _c(out, x.dtype)
+    M, D = x.shape
+    ld = out.shape[1]
+    assert out.shape[0] == M and col0 + D <= ld
+    call("xggm_elu_fwd_" + sfx(x.dtype), ptr(x), out.data_ptr() + col0 * out.element_size(), M, D, ld, stream())
+
+
+def elu_bwd(dy, y, col0, D):
+    _c(dy), _c(y, dy.dtype)
+    M, ld = y.shape
+    assert dy.shape == y.shape and col0 + D <= ld
+    dx = torch.empty((M, D), device=y.device, dtype=y.dtype)
+    off = col0 * y.element_size()
+    call("xggm_elu_bwd_" + sfx(y.dtype), dy.data_ptr() + off, y.data_ptr() + off, ptr(dx), M, D, ld, stream())
+    return dx
+
+
+def dropout(x, p, rng, sid):
+    _c(x)
+    out = torch.empty_like(x)
+    call("xggm_dropout_" + sfx(x.dtype), ptr(x), ptr(out), x.numel(), float(p), ptr(rng), sid, stream())
+    return out

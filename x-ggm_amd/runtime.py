@@ -16,6 +16,15 @@ from .functional import Runtime
 DEFAULT_DTYPE = torch.bfloat16
 
 
+def _mark_shadow_dirty(module, incompatible_keys):
+    """load_state_dict post-hook (any sub-module): the bf16 shadow weights are refreshed lazily
+    at the next forward."""
+    ref = getattr(module, "_xg_root", None)
+    root = ref() if ref is not None else None
+    if root is not None:
+        object.__setattr__(root, "_xg_shadow_dirty", True)
+
+
 def bind_root(root, compute_dtype=None):
     """(re)bind all sub-modules of ``root``; the outermost model calls this last, so nested
     roots (an encoder inside a VQAModel) end up pointing at the outermost one."""
@@ -23,12 +32,16 @@ def bind_root(root, compute_dtype=None):
     for i, m in enumerate(root.modules()):
         object.__setattr__(m, "_xg_root", ref)
         object.__setattr__(m, "_sid", 16 * (i + 1))
+        if not getattr(m, "_xg_hooked", False):
+            m.register_load_state_dict_post_hook(_mark_shadow_dirty)
+            object.__setattr__(m, "_xg_hooked", True)
     if compute_dtype is not None:
         object.__setattr__(root, "compute_dtype", compute_dtype)
     elif not hasattr(root, "compute_dtype"):
         object.__setattr__(root, "compute_dtype", DEFAULT_DTYPE)
     object.__setattr__(root, "_xg_arena", None)
     object.__setattr__(root, "_xg_rt", None)
+    object.__setattr__(root, "_xg_shadow_dirty", False)
     return root
 
 
@@ -52,6 +65,9 @@ def runtime_of(module):
             rt.training = old.training
         object.__setattr__(root, "_xg_arena", arena)
         object.__setattr__(root, "_xg_rt", rt)
+    if getattr(root, "_xg_shadow_dirty", False):
+        rt.arena.sync_shadow()
+        object.__setattr__(root, "_xg_shadow_dirty", False)
     rt.training = root.training
     return rt
 
@@ -70,3 +86,4 @@ def sync_weights(model):
     root = root_of(model)
     if root._xg_rt is not None and root._xg_rt.arena.valid():
         root._xg_rt.arena.sync_shadow()
+        object.__setattr__(root, "_xg_shadow_dirty", False)
