@@ -68,9 +68,14 @@ int xggm_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, i
                    int64_t b_ks, int64_t ldc, int batch, int64_t a_bs, int64_t b_bs, int64_t c_bs, const float* bias,
                    const void* residual, void* preact, const void* aux, int act, int c_f32, int accumulate, float alpha,
                    xggm_stream_t stream);
+/* HOST: 1 = run bf16 GEMMs on the generic 64x64 kernel, 0 = tuned kernels (default); A/B tests */
+int xggm_gemm_set_generic(int on);
 /* out[n] += sum_m x[m*ld + n]  (bias gradients; `out` must hold the running value) */
-int xggm_colsum_f32(const void* x, float* out, int M, int N, int64_t ld, xggm_stream_t stream);
-int xggm_colsum_bf16(const void* x, float* out, int M, int N, int64_t ld, xggm_stream_t stream);
+int xggm_colsum_f32(const void* x, float* out, int M, int N, int64_t ld, float* ws, size_t ws_bytes,
+                    xggm_stream_t stream);
+int xggm_colsum_bf16(const void* x, float* out, int M, int N, int64_t ld, float* ws, size_t ws_bytes,
+                     xggm_stream_t stream);
+size_t xggm_colsum_workspace_bytes(int M, int N);
 
 /* ---- attention core: src/lxrt/modeling.py:355-373 (BertAttention.forward after the
  * projections).  q/k/v/out rows of sample b start at row b*S of a matrix with the given row
@@ -106,17 +111,21 @@ int xggm_ln_fwd_bf16(const void* in, const float* bias, const void* residual, co
                      const uint64_t* rng, uint32_t sid_pre, uint32_t sid_post, int accumulate, float out_scale,
                      xggm_stream_t stream);
 /* dy = grad of `out`.  d_in: grad of `in` (NULL ok); d_res: grad of `residual` (NULL ok,
- * accumulate_dres adds to it); dgamma/dbeta/dbias (NULL ok) are ACCUMULATED atomically.
+ * accumulate_dres adds to it); dgamma/dbeta/dbias (NULL ok) are ACCUMULATED (+=).
  * gelu_aux (T [M,H], NULL ok): `in` was gelu(u) of a Linear -> d_in (and dbias) are further
  * multiplied by gelu'(u), i.e. they become the gradients of u and of that Linear's bias. */
 int xggm_ln_bwd_f32(const void* dy, const void* z, const float* stats, const float* gamma, void* d_in, void* d_res,
                     float* dgamma, float* dbeta, float* dbias, int M, int H, float p_pre, float p_post, const uint64_t* rng,
                     uint32_t sid_pre, uint32_t sid_post, float out_scale, int accumulate_dres, const void* gelu_aux,
-                    xggm_stream_t stream);
+                    float* ws, size_t ws_bytes, xggm_stream_t stream);
 int xggm_ln_bwd_bf16(const void* dy, const void* z, const float* stats, const float* gamma, void* d_in, void* d_res,
                      float* dgamma, float* dbeta, float* dbias, int M, int H, float p_pre, float p_post,
                      const uint64_t* rng, uint32_t sid_pre, uint32_t sid_post, float out_scale, int accumulate_dres,
-                     const void* gelu_aux, xggm_stream_t stream);
+                     const void* gelu_aux, float* ws, size_t ws_bytes, xggm_stream_t stream);
+/* workspaces (bytes) of the backward row kernels: they hold one partial row per workgroup and
+ * reduced vector, summed by a second kernel instead of contended atomics */
+size_t xggm_ln_bwd_workspace_bytes(int M, int H);
+size_t xggm_visn_embed_bwd_workspace_bytes(int M, int H);
 /* BertEmbeddings: src/lxrt/modeling.py:298-313.  ids/seg: int64 [M] (M = B*Tlen), tables T.
  * backward scatter-adds into the fp32 table gradients; row 0 (padding_idx) gets none. */
 int xggm_embed_fwd_f32(const int64_t* ids, const int64_t* seg, const void* word, const void* pos, const void* type,
@@ -127,12 +136,12 @@ int xggm_embed_fwd_bf16(const int64_t* ids, const int64_t* seg, const void* word
                         float eps, float p, const uint64_t* rng, uint32_t sid, xggm_stream_t stream);
 int xggm_embed_bwd_f32(const int64_t* ids, const int64_t* seg, const void* dy, const void* z, const float* stats,
                        const float* gamma, void* dz_ws, float* dword, float* dpos, float* dtype, float* dgamma,
-                       float* dbeta, int M, int Tlen, int H, float p, const uint64_t* rng, uint32_t sid,
-                       xggm_stream_t stream);
+                       float* dbeta, int M, int Tlen, int H, float p, const uint64_t* rng, uint32_t sid, float* ws,
+                       size_t ws_bytes, xggm_stream_t stream);
 int xggm_embed_bwd_bf16(const int64_t* ids, const int64_t* seg, const void* dy, const void* z, const float* stats,
                         const float* gamma, void* dz_ws, float* dword, float* dpos, float* dtype, float* dgamma,
-                        float* dbeta, int M, int Tlen, int H, float p, const uint64_t* rng, uint32_t sid,
-                        xggm_stream_t stream);
+                        float* dbeta, int M, int Tlen, int H, float p, const uint64_t* rng, uint32_t sid, float* ws,
+                        size_t ws_bytes, xggm_stream_t stream);
 /* VisualFeatEncoder tail: src/lxrt/modeling.py:546-556.  u = feat @ W_f^T (T, from
  * xggm_gemm); boxes T [M,4]; W_b fp32 [H,4].  z1 may alias u.  stats [M,4]. */
 int xggm_visn_embed_fwd_f32(const void* u, const float* bf, const void* boxes, const float* Wb, const float* bb,
@@ -146,11 +155,11 @@ int xggm_visn_embed_fwd_bf16(const void* u, const float* bf, const void* boxes, 
 int xggm_visn_embed_bwd_f32(const void* dy, const void* z1, const void* z2, const float* stats, const void* boxes,
                             const float* g1, const float* g2, void* du, float* dbf, float* dg1, float* db1, float* dWb,
                             float* dbb, float* dg2, float* db2, int M, int H, float p, const uint64_t* rng, uint32_t sid,
-                            xggm_stream_t stream);
+                            float* ws, size_t ws_bytes, xggm_stream_t stream);
 int xggm_visn_embed_bwd_bf16(const void* dy, const void* z1, const void* z2, const float* stats, const void* boxes,
                              const float* g1, const float* g2, void* du, float* dbf, float* dg1, float* db1, float* dWb,
                              float* dbb, float* dg2, float* db2, int M, int H, float p, const uint64_t* rng, uint32_t sid,
-                             xggm_stream_t stream);
+                             float* ws, size_t ws_bytes, xggm_stream_t stream);
 
 /* ---- graph-generative kernels (adjacency tensors fp32 [B,N,N], N <= 64) -----------------
  * out = [out +] self_w * x + scale * (1 + *scale_ptr) * M' @ x; x/out T [B,N,H].

@@ -20,12 +20,15 @@ _CT = {
 }
 
 
+RESTYPE = {}
+
+
 def parse_header(path=HEADER_PATH):
     """``{symbol: [ctypes argtypes]}`` for every ``int xggm_*(...)`` declared in xggm.h."""
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
     out = {}
-    for m in re.finditer(r"\b(int|const char\*)\s+(xggm_\w+)\s*\(([^)]*)\)\s*;", src):
+    for m in re.finditer(r"\b(int|size_t|const char\*)\s+(xggm_\w+)\s*\(([^)]*)\)\s*;", src):
         name, args = m.group(2), m.group(3).strip()
         types = []
         if args and args != "void":
@@ -37,6 +40,7 @@ def parse_header(path=HEADER_PATH):
                     base = a.replace("const ", "").split()[0]
                     types.append(_CT[base])
         out[name] = types
+        RESTYPE[name] = {"int": ctypes.c_int, "size_t": ctypes.c_size_t, "const char*": ctypes.c_char_p}[m.group(1)]
     return out
 
 
@@ -49,7 +53,7 @@ def _load():
     for name, types in parse_header().items():
         fn = getattr(lib, name)  # AttributeError if the header declares a symbol the .so lacks
         fn.argtypes = types
-        fn.restype = ctypes.c_char_p if name == "xggm_last_error" else ctypes.c_int
+        fn.restype = RESTYPE[name]
     return lib
 
 

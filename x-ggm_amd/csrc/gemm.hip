@@ -52,6 +52,7 @@ template <> struct Tile<float> {
 };
 
 constexpr int BM = 64, BN = 64, NT = 256;
+bool g_force_generic = false;  // test hook: xggm_gemm_set_generic
 
 // stage a [64 rows][BK] operand tile into LDS (k contiguous).  elem(r,k) = base[r*rs + k*ks]
 template <typename T>
@@ -101,6 +102,37 @@ template <typename T> __device__ __forceinline__ float act_apply(int act, float 
         case XGGM_ACT_TANH: return tanhf(v);
         case XGGM_ACT_GELU_GRAD: return v * gelu_grad_f(aux);
         default: return v;
+    }
+}
+
+// one 16x16 accumulator tile -> C: lane holds column `col`, rows row0 .. row0+3
+template <typename T>
+__device__ __forceinline__ void epilogue_tile(const GemmArgs& g, const float4_t& acc, int row0, int col, int bz) {
+    if (col >= g.N) return;
+    const int64_t coff = (int64_t)bz * g.c_bs;
+    const float bias = g.bias ? g.bias[col] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = row0 + r;
+        if (row >= g.M) continue;
+        const int64_t idx = coff + (int64_t)row * g.ldc + col;
+        float v = g.alpha * acc[r] + bias;
+        if (g.preact) reinterpret_cast<T*>(g.preact)[idx] = from_f32<T>(v);
+        float aux = 0.0f;
+        if (g.act == XGGM_ACT_GELU_GRAD) aux = to_f32(reinterpret_cast<const T*>(g.aux)[idx]);
+        if (g.act != XGGM_ACT_NONE) {
+            // forward activations act on the value as stored (bf16-rounded pre-activation)
+            if (g.preact) v = round_to<T>(v);
+            v = act_apply<T>(g.act, v, aux);
+        }
+        if (g.residual) v += to_f32(reinterpret_cast<const T*>(g.residual)[idx]);
+        if (g.c_f32) {
+            float* c = reinterpret_cast<float*>(g.C) + idx;
+            *c = g.accumulate ? (*c + v) : v;
+        } else {
+            T* c = reinterpret_cast<T*>(g.C) + idx;
+            *c = from_f32<T>(g.accumulate ? (to_f32(*c) + v) : v);
+        }
     }
 }
 
@@ -163,38 +195,180 @@ template <typename T> __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs
     }
 
     // epilogue: C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg
-    const int64_t coff = (int64_t)bz * g.c_bs;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn + j * 16 + fr;
-            if (col >= g.N) continue;
-            const float bias = g.bias ? g.bias[col] : 0.0f;
+        for (int j = 0; j < 2; ++j) epilogue_tile<T>(g, acc[i][j], m0 + wm + i * 16 + fq * 4, n0 + wn + j * 16 + fr, bz);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fast bf16 path: BM x BN x 64 tiles, 4 waves (2x2), double-buffered LDS fed by a register
+// prefetch of the next k-tile (global loads of tile t+1 are in flight while tile t runs on the
+// matrix cores; one barrier per k-tile).  An operand whose reduction index is contiguous in
+// memory ("k-major": activations in forward, weights in forward) is stored [row][64] with an XOR
+// swizzle of its 16-byte chunks (chunk ^= (row >> 1) & 7: conflict-free ds_read_b128 for the
+// 16x16x32 fragment).  An operand whose ROW index is contiguous ("r-major": weights in dgrad, both
+// operands in wgrad) is stored as it arrives, [64 k][rows + 16 pad], and transposed by the LDS
+// itself on the way out with ds_read_b64_tr_b16 -- no scalar transposing writes.
+typedef __attribute__((ext_vector_type(4))) short short4_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
+template <int R, bool KMAJ> struct OpLds {
+    static constexpr int LD = KMAJ ? 64 : (R + 16);  // elements per LDS row
+    static constexpr int ELEMS = KMAJ ? R * 64 : 64 * (R + 16);
+    static constexpr int NCH = R / 32;  // 16-byte chunks per thread per k-tile
+};
+
+template <int R, bool KMAJ>
+__device__ __forceinline__ void fast_load(short8_t (&reg)[R / 32], const bf16* __restrict__ base, int64_t rs, int64_t ks,
+                                          int r0, int k0, int Rtot, int K, int tid) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm + i * 16 + fq * 4 + r;
-                if (row >= g.M) continue;
-                const int64_t idx = coff + (int64_t)row * g.ldc + col;
-                float v = g.alpha * acc[i][j][r] + bias;
-                if (g.preact) reinterpret_cast<T*>(g.preact)[idx] = from_f32<T>(v);
-                float aux = 0.0f;
-                if (g.act == XGGM_ACT_GELU_GRAD) aux = to_f32(reinterpret_cast<const T*>(g.aux)[idx]);
-                if (g.act != XGGM_ACT_NONE) {
-                    // forward activations act on the value as stored (bf16-rounded pre-activation)
-                    if (g.preact) v = round_to<T>(v);
-                    v = act_apply<T>(g.act, v, aux);
-                }
-                if (g.residual) v += to_f32(reinterpret_cast<const T*>(g.residual)[idx]);
-                if (g.c_f32) {
-                    float* c = reinterpret_cast<float*>(g.C) + idx;
-                    *c = g.accumulate ? (*c + v) : v;
-                } else {
-                    T* c = reinterpret_cast<T*>(g.C) + idx;
-                    *c = from_f32<T>(g.accumulate ? (to_f32(*c) + v) : v);
-                }
-            }
+    for (int i = 0; i < R / 32; ++i) {
+        const int c = tid + NT * i;
+        short8_t v = {};
+        if (KMAJ) {
+            const int row = c >> 3, kc = (c & 7) * 8;
+            if (r0 + row < Rtot && k0 + kc < K)
+                v = *reinterpret_cast<const short8_t*>(base + (int64_t)(r0 + row) * rs + k0 + kc);
+        } else {
+            const int kl = c / (R / 8), rc = (c % (R / 8)) * 8;
+            if (k0 + kl < K && r0 + rc < Rtot)
+                v = *reinterpret_cast<const short8_t*>(base + (int64_t)(k0 + kl) * ks + r0 + rc);
         }
+        reg[i] = v;
+    }
+}
+
+template <int R, bool KMAJ>
+__device__ __forceinline__ void fast_store(bf16* lds, const short8_t (&reg)[R / 32], int tid) {
+#pragma unroll
+    for (int i = 0; i < R / 32; ++i) {
+        const int c = tid + NT * i;
+        if (KMAJ) {
+            const int row = c >> 3, kc = c & 7;
+            *reinterpret_cast<short8_t*>(lds + row * 64 + ((kc ^ ((row >> 1) & 7)) << 3)) = reg[i];
+        } else {
+            const int kl = c / (R / 8), rc = (c % (R / 8)) * 8;
+            *reinterpret_cast<short8_t*>(lds + kl * (R + 16) + rc) = reg[i];
+        }
+    }
+}
+
+// fragment of the 16 rows starting at `row0` for k-step `ks` (0 or 32): lane (fr = lane & 15,
+// fq = lane >> 4) gets row row0 + fr, k = ks + 8 fq .. + 7
+template <int R, bool KMAJ>
+__device__ __forceinline__ bf16x8_t fast_frag(const bf16* lds, int row0, int ks, int lane) {
+    const int fr = lane & 15, fq = lane >> 4;
+    if (KMAJ) {
+        const int row = row0 + fr;
+        const int chunk = ((ks >> 3) + fq) ^ ((row >> 1) & 7);
+        return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(lds + row * 64 + (chunk << 3)));
+    } else {
+        // ds_read_b64_tr_b16: within a 16-lane group, lane 4q+p supplies the address of k-row q,
+        // columns 4p..4p+3 of a 4 x 16 block and receives column (lane & 15) of the 4 k-rows
+        const int q = fr >> 2, p = fr & 3;
+        const bf16* a0 = lds + (ks + 8 * fq + q) * (R + 16) + row0 + 4 * p;
+        const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) short4_t*)(a0));
+        const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) short4_t*)(a0 + 4 * (R + 16)));
+        short8_t v;
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+        v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        return __builtin_bit_cast(bf16x8_t, v);
+    }
+}
+
+template <int BM, int BN, bool AK, bool BKM>
+__global__ __launch_bounds__(NT) void gemm_fast_kernel(GemmArgs g) {
+    typedef OpLds<BM, AK> LA;
+    typedef OpLds<BN, BKM> LB;
+    constexpr int TM = BM / 32, TN = BN / 32;  // 16x16 tiles per wave (wave tile = BM/2 x BN/2)
+    extern __shared__ __attribute__((aligned(16))) bf16 fsm[];
+    constexpr int STAGE = LA::ELEMS + LB::ELEMS;  // buffer s: A at s*STAGE, B at s*STAGE + LA::ELEMS
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = (wid >> 1) * (BM / 2), wn = (wid & 1) * (BN / 2);
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, bz = blockIdx.z;
+    const bf16* A = reinterpret_cast<const bf16*>(g.A) + (int64_t)bz * g.a_bs;
+    const bf16* B = reinterpret_cast<const bf16*>(g.B) + (int64_t)bz * g.b_bs;
+
+    float4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    short8_t ra[LA::NCH], rb[LB::NCH];
+    fast_load<BM, AK>(ra, A, g.a_rs, g.a_ks, m0, 0, g.M, g.K, tid);
+    fast_load<BN, BKM>(rb, B, g.b_ns, g.b_ks, n0, 0, g.N, g.K, tid);
+    fast_store<BM, AK>(fsm, ra, tid);
+    fast_store<BN, BKM>(fsm + LA::ELEMS, rb, tid);
+    __syncthreads();
+    const int nk = (g.K + 63) / 64;
+    for (int t = 0; t < nk; ++t) {
+        const bf16* Ac = fsm + (t & 1) * STAGE;
+        const bf16* Bc = Ac + LA::ELEMS;
+        bf16* An = fsm + ((t + 1) & 1) * STAGE;
+        if (t + 1 < nk) {
+            fast_load<BM, AK>(ra, A, g.a_rs, g.a_ks, m0, (t + 1) * 64, g.M, g.K, tid);
+            fast_load<BN, BKM>(rb, B, g.b_ns, g.b_ks, n0, (t + 1) * 64, g.N, g.K, tid);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 64; ks += 32) {
+            bf16x8_t a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = fast_frag<BM, AK>(Ac, wm + i * 16, ks, lane);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = fast_frag<BN, BKM>(Bc, wn + j * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < nk) {
+            fast_store<BM, AK>(An, ra, tid);
+            fast_store<BN, BKM>(An + LA::ELEMS, rb, tid);
+        }
+        __syncthreads();
+    }
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            epilogue_tile<bf16>(g, acc[i][j], m0 + wm + i * 16 + fq * 4, n0 + wn + j * 16 + fr, bz);
+}
+
+template <int BM, int BN> int launch_fast_tile(const GemmArgs& g, int batch, hipStream_t stream) {
+    dim3 grid(ceil_div(g.N, BN), ceil_div(g.M, BM), batch);
+    const bool ak = g.a_mode == 1, bk = g.b_mode == 1;
+#define XGGM_FAST(AKv, BKv)                                                                                           \
+    do {                                                                                                              \
+        constexpr size_t lds = 2 * sizeof(bf16) * (OpLds<BM, AKv>::ELEMS + OpLds<BN, BKv>::ELEMS);                   \
+        static bool attr_set = false;                                                                                 \
+        if (lds > 48 * 1024 && !attr_set) {                                                                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<BM, BN, AKv, BKv>),             \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
+            attr_set = true;                                                                                          \
+        }                                                                                                             \
+        hipLaunchKernelGGL((gemm_fast_kernel<BM, BN, AKv, BKv>), grid, dim3(NT), lds, stream, g);                     \
+    } while (0)
+    if (ak && bk) XGGM_FAST(true, true);
+    else if (ak && !bk) XGGM_FAST(true, false);
+    else if (!ak && bk) XGGM_FAST(false, true);
+    else XGGM_FAST(false, false);
+#undef XGGM_FAST
+    return xggm_check_launch("xggm_gemm(fast)");
+}
+
+// tile choice: the largest tile that still yields >= 200 workgroups (256 CUs), else 64x64
+inline int launch_fast(const GemmArgs& g, int batch, hipStream_t stream) {
+    auto tiles = [&](int bm, int bn) { return (int64_t)ceil_div(g.M, bm) * ceil_div(g.N, bn) * batch; };
+    if (tiles(128, 128) >= 200) return launch_fast_tile<128, 128>(g, batch, stream);
+    if (tiles(128, 64) >= 200) return launch_fast_tile<128, 64>(g, batch, stream);
+    return launch_fast_tile<64, 64>(g, batch, stream);
 }
 
 template <typename T> int pick_mode(const void* base, int64_t rs, int64_t ks, int64_t bs, int R, int K) {
@@ -216,6 +390,9 @@ template <typename T> int launch(GemmArgs g, int batch, hipStream_t stream) {
     g.b_mode = pick_mode<T>(g.B, g.b_ns, g.b_ks, g.b_bs, g.N, g.K);
     dim3 grid(ceil_div(g.N, BN), ceil_div(g.M, BM), batch);
     XGGM_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "xggm_gemm: grid too large");
+    if constexpr (sizeof(T) == 2) {
+        if (g.a_mode != 0 && g.b_mode != 0 && !g_force_generic) return launch_fast(g, batch, stream);
+    }
     hipLaunchKernelGGL(gemm_kernel<T>, grid, dim3(NT), 0, stream, g);
     return xggm_check_launch("xggm_gemm");
 }
@@ -239,3 +416,9 @@ template <typename T> int launch(GemmArgs g, int batch, hipStream_t stream) {
 
 XGGM_GEMM_IMPL(xggm_gemm_f32, float)
 XGGM_GEMM_IMPL(xggm_gemm_bf16, bf16)
+
+// test/diagnostic hook: route bf16 GEMMs through the generic kernel (1) or the tuned one (0)
+extern "C" int xggm_gemm_set_generic(int on) {
+    g_force_generic = on != 0;
+    return XGGM_OK;
+}

@@ -27,6 +27,46 @@ __device__ __forceinline__ void rng_load(const uint64_t* rng, uint64_t& seed, ui
     off = rng ? rng[1] : 0;
 }
 
+
+// ---- cross-row reductions without contended atomics --------------------------------------------
+// Hundreds of waves adding into the SAME H addresses serialise in the memory-side atomic units
+// (measured: 80 us for an LN backward that needs 10).  Instead every workgroup reduces its 4
+// waves through LDS and stores one partial row per vector into a caller-provided workspace
+// ws[block][K][H]; a second tiny kernel sums the blocks and adds into the fp32 gradients
+// (one owner per address -> plain read-modify-write, deterministic order).
+template <int NV>
+__device__ __forceinline__ void block_store_partial(const float (&p)[NV][4], float* lds, float* dst, int H, int lane,
+                                                    int wid) {
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int c = (v * 64 + lane) * 4;
+        if (c < H) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lds[wid * H + c + i] = p[v][i];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += NT) dst[c] = lds[c] + lds[H + c] + lds[2 * H + c] + lds[3 * H + c];
+}
+
+struct ReduceTargets {
+    float* t[10];
+    int stride[10];  // element stride of the target (1, or 4 for the columns of box_fc.weight [H,4])
+};
+
+__global__ __launch_bounds__(NT) void partial_reduce_kernel(const float* __restrict__ ws, int nblk, int K, int H,
+                                                            ReduceTargets tg) {
+    const int idx = blockIdx.x * NT + threadIdx.x;
+    if (idx >= K * H) return;
+    const int k = idx / H, c = idx % H;
+    float* t = tg.t[k];
+    if (!t) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += ws[((int64_t)b * K + k) * H + c];
+    t[(int64_t)c * tg.stride[k]] += s;
+}
+
 // ------------------------------------------------------------------------------- LN fwd
 template <typename T, int NV>
 __global__ __launch_bounds__(NT) void ln_fwd_kernel(const T* in, const float* __restrict__ bias,
@@ -128,8 +168,8 @@ __global__ __launch_bounds__(NT) void ln_fwd_kernel(const T* in, const float* __
 template <typename T, int NV>
 __global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ z,
                                                     const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                    T* d_in, T* d_res, float* dgamma, float* dbeta, float* dbias, int M, int H,
-                                                    DropArgs d, float out_scale, int accumulate_dres,
+                                                    T* d_in, T* d_res, float* ws, int M, int H, DropArgs d,
+                                                    float out_scale, int accumulate_dres,
                                                     const T* __restrict__ gelu_aux) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     uint64_t seed, off;
@@ -212,18 +252,11 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ dy, co
             }
         }
     }
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        const int c = (v * 64 + lane) * 4;
-        if (c < H) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (dgamma) atomicAdd(dgamma + c + i, pg[v][i]);
-                if (dbeta) atomicAdd(dbeta + c + i, pb[v][i]);
-                if (dbias) atomicAdd(dbias + c + i, pbias[v][i]);
-            }
-        }
-    }
+    extern __shared__ __attribute__((aligned(16))) float red_lds[];
+    float* wsb = ws + (int64_t)blockIdx.x * 3 * H;
+    block_store_partial<NV>(pg, red_lds, wsb, H, lane, wid);
+    block_store_partial<NV>(pb, red_lds, wsb + H, H, lane, wid);
+    block_store_partial<NV>(pbias, red_lds, wsb + 2 * H, H, lane, wid);
 }
 
 // ------------------------------------------------------------------------------- embeddings
@@ -408,9 +441,8 @@ template <typename T, int NV>
 __global__ __launch_bounds__(NT) void visn_embed_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ z1,
                                                             const T* __restrict__ z2, const float* __restrict__ stats,
                                                             const T* __restrict__ boxes, const float* __restrict__ g1,
-                                                            const float* __restrict__ g2, T* du, float* dbf, float* dg1,
-                                                            float* db1, float* dWb, float* dbb, float* dg2, float* db2, int M,
-                                                            int H, DropArgs d) {
+                                                            const float* __restrict__ g2, T* du, float* ws, int M, int H,
+                                                            DropArgs d) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     uint64_t seed, off;
     rng_load(d.rng, seed, off);
@@ -490,36 +522,36 @@ __global__ __launch_bounds__(NT) void visn_embed_bwd_kernel(const T* __restrict_
             }
         }
     }
+    extern __shared__ __attribute__((aligned(16))) float red_lds[];
+    float* wsb = ws + (int64_t)blockIdx.x * 10 * H;
+    block_store_partial<NV>(pbf, red_lds, wsb, H, lane, wid);
+    block_store_partial<NV>(pg1, red_lds, wsb + H, H, lane, wid);
+    block_store_partial<NV>(pb1, red_lds, wsb + 2 * H, H, lane, wid);
+    block_store_partial<NV>(pbb, red_lds, wsb + 3 * H, H, lane, wid);
+    block_store_partial<NV>(pg2, red_lds, wsb + 4 * H, H, lane, wid);
+    block_store_partial<NV>(pb2, red_lds, wsb + 5 * H, H, lane, wid);
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        const int c = (v * 64 + lane) * 4;
-        if (c < H) {
+    for (int j = 0; j < 4; ++j) {
+        float pj[NV][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                atomicAdd(dg1 + c + i, pg1[v][i]);
-                atomicAdd(db1 + c + i, pb1[v][i]);
-                atomicAdd(dbf + c + i, pbf[v][i]);
-                atomicAdd(dg2 + c + i, pg2[v][i]);
-                atomicAdd(db2 + c + i, pb2[v][i]);
-                atomicAdd(dbb + c + i, pbb[v][i]);
+        for (int v = 0; v < NV; ++v)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) atomicAdd(dWb + (int64_t)(c + i) * 4 + j, pW[v][i][j]);
-            }
-        }
+            for (int i = 0; i < 4; ++i) pj[v][i] = pW[v][i][j];
+        block_store_partial<NV>(pj, red_lds, wsb + (6 + j) * H, H, lane, wid);
     }
 }
 
 // ------------------------------------------------------------------------------- column sum
 // out[n] (+)= sum_m x[m, n]  (bias gradients).  One thread per column pair of rows-chunk.
 template <typename T>
-__global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ x, float* out, int M, int N, int64_t ld,
+__global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ x, float* ws, int M, int N, int64_t ld,
                                                     int rows_per_block) {
     const int col = blockIdx.x * NT + threadIdx.x;
     if (col >= N) return;
     const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
     float s = 0.f;
     for (int r = r0; r < r1; ++r) s += to_f32(x[(int64_t)r * ld + col]);
-    atomicAdd(out + col, s);
+    ws[(int64_t)blockIdx.y * N + col] = s;
 }
 
 inline int rows_grid(int M, int cap) { return std::min(ceil_div(M, WPB), cap); }
@@ -556,18 +588,35 @@ int ln_fwd(const void* in, const float* bias, const void* residual, const float*
     return xggm_check_launch("xggm_ln_fwd");
 }
 
+inline size_t bwd_ws_bytes(int M, int H, int K) { return sizeof(float) * (size_t)rows_grid(M, 128) * K * H; }
+
+inline void launch_reduce(const float* ws, int nblk, int K, int H, const ReduceTargets& tg, hipStream_t st) {
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3(ceil_div(K * H, NT)), dim3(NT), 0, st, ws, nblk, K, H, tg);
+}
+
 template <typename T>
 int ln_bwd(const void* dy, const void* z, const float* stats, const float* gamma, void* d_in, void* d_res, float* dgamma,
            float* dbeta, float* dbias, int M, int H, float p_pre, float p_post, const uint64_t* rng, uint32_t s_pre,
-           uint32_t s_post, float out_scale, int accumulate_dres, const void* gelu_aux, hipStream_t st) {
+           uint32_t s_post, float out_scale, int accumulate_dres, const void* gelu_aux, float* ws, size_t ws_bytes,
+           hipStream_t st) {
     if (int e = check_row_shape("xggm_ln_bwd", M, H)) return e;
     XGGM_REQUIRE(dy && z && stats && gamma, "xggm_ln_bwd: null pointer");
     XGGM_REQUIRE((p_pre == 0.f && p_post == 0.f) || rng, "xggm_ln_bwd: dropout needs an rng state");
+    XGGM_REQUIRE(ws && ws_bytes >= bwd_ws_bytes(M, H, 3), "xggm_ln_bwd: workspace of %zu bytes needed, got %zu",
+                 bwd_ws_bytes(M, H, 3), ws_bytes);
     DropArgs d{p_pre, p_post, rng, s_pre, s_post};
-    DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), dim3(rows_grid(M, 128)), dim3(NT), 0, st, (const T*)dy,
-                                       (const T*)z, stats, gamma, (T*)d_in, (T*)d_res, dgamma, dbeta, dbias, M, H, d,
+    const int grid = rows_grid(M, 128);
+    DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), dim3(grid), dim3(NT), sizeof(float) * WPB * H, st,
+                                       (const T*)dy, (const T*)z, stats, gamma, (T*)d_in, (T*)d_res, ws, M, H, d,
                                        out_scale, accumulate_dres, (const T*)gelu_aux));
-    return xggm_check_launch("xggm_ln_bwd");
+    if (int e = xggm_check_launch("xggm_ln_bwd")) return e;
+    if (dgamma || dbeta || dbias) {
+        ReduceTargets tg{};
+        tg.t[0] = dgamma; tg.t[1] = dbeta; tg.t[2] = dbias;
+        tg.stride[0] = tg.stride[1] = tg.stride[2] = 1;
+        launch_reduce(ws, grid, 3, H, tg, st);
+    }
+    return xggm_check_launch("xggm_ln_bwd(reduce)");
 }
 
 template <typename T>
@@ -588,14 +637,12 @@ int embed_fwd(const int64_t* ids, const int64_t* seg, const void* word, const vo
 template <typename T>
 int embed_bwd(const int64_t* ids, const int64_t* seg, const void* dy, const void* z, const float* stats, const float* gamma,
               void* dz_ws, float* dword, float* dpos, float* dtype, float* dgamma, float* dbeta, int M, int Tlen, int H,
-              float p, const uint64_t* rng, uint32_t sid, hipStream_t st) {
+              float p, const uint64_t* rng, uint32_t sid, float* ws, size_t ws_bytes, hipStream_t st) {
     if (int e = check_row_shape("xggm_embed_bwd", M, H)) return e;
     XGGM_REQUIRE(ids && dy && z && stats && gamma && dz_ws && dword && dpos && dtype, "xggm_embed_bwd: null pointer");
-    DropArgs d{0.f, p, rng, 0, sid};
-    DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), dim3(rows_grid(M, 128)), dim3(NT), 0, st, (const T*)dy,
-                                       (const T*)z, stats, gamma, (T*)dz_ws, (T*)nullptr, dgamma, dbeta, (float*)nullptr, M,
-                                       H, d, 1.0f, 0, (const T*)nullptr));
-    if (int e = xggm_check_launch("xggm_embed_bwd(ln)")) return e;
+    if (int e = ln_bwd<T>(dy, z, stats, gamma, dz_ws, nullptr, dgamma, dbeta, nullptr, M, H, 0.f, p, rng, 0, sid, 1.0f, 0,
+                          nullptr, ws, ws_bytes, st))
+        return e;
     hipLaunchKernelGGL((embed_scatter_kernel<T>), dim3(rows_grid(M, 1024)), dim3(NT), 0, st, ids, seg, (const T*)dz_ws,
                        dword, dpos, dtype, M, Tlen, H);
     return xggm_check_launch("xggm_embed_bwd(scatter)");
@@ -619,37 +666,56 @@ int visn_fwd(const void* u, const float* bf, const void* boxes, const float* Wb,
 template <typename T>
 int visn_bwd(const void* dy, const void* z1, const void* z2, const float* stats, const void* boxes, const float* g1,
              const float* g2, void* du, float* dbf, float* dg1, float* db1, float* dWb, float* dbb, float* dg2, float* db2,
-             int M, int H, float p, const uint64_t* rng, uint32_t sid, hipStream_t st) {
+             int M, int H, float p, const uint64_t* rng, uint32_t sid, float* ws, size_t ws_bytes, hipStream_t st) {
     if (int e = check_row_shape("xggm_visn_embed_bwd", M, H)) return e;
     XGGM_REQUIRE(dy && z1 && z2 && stats && boxes && g1 && g2 && du && dbf && dg1 && db1 && dWb && dbb && dg2 && db2,
                  "xggm_visn_embed_bwd: null pointer");
     XGGM_REQUIRE(H <= 1024, "xggm_visn_embed_bwd: H=%d > 1024", H);
+    XGGM_REQUIRE(ws && ws_bytes >= bwd_ws_bytes(M, H, 10), "xggm_visn_embed_bwd: workspace of %zu bytes needed, got %zu",
+                 bwd_ws_bytes(M, H, 10), ws_bytes);
     DropArgs d{0.f, p, rng, 0, sid};
     const int nv_ = ceil_div(H, 256);
+    const int grid = rows_grid(M, 128);
+    const size_t lds = sizeof(float) * WPB * H;
     if (nv_ <= 1) {
-        hipLaunchKernelGGL((visn_embed_bwd_kernel<T, 1>), dim3(rows_grid(M, 128)), dim3(NT), 0, st, (const T*)dy,
-                           (const T*)z1, (const T*)z2, stats, (const T*)boxes, g1, g2, (T*)du, dbf, dg1, db1, dWb, dbb, dg2,
-                           db2, M, H, d);
+        hipLaunchKernelGGL((visn_embed_bwd_kernel<T, 1>), dim3(grid), dim3(NT), lds, st, (const T*)dy, (const T*)z1,
+                           (const T*)z2, stats, (const T*)boxes, g1, g2, (T*)du, ws, M, H, d);
     } else if (nv_ <= 3) {
-        hipLaunchKernelGGL((visn_embed_bwd_kernel<T, 3>), dim3(rows_grid(M, 128)), dim3(NT), 0, st, (const T*)dy,
-                           (const T*)z1, (const T*)z2, stats, (const T*)boxes, g1, g2, (T*)du, dbf, dg1, db1, dWb, dbb, dg2,
-                           db2, M, H, d);
+        hipLaunchKernelGGL((visn_embed_bwd_kernel<T, 3>), dim3(grid), dim3(NT), lds, st, (const T*)dy, (const T*)z1,
+                           (const T*)z2, stats, (const T*)boxes, g1, g2, (T*)du, ws, M, H, d);
     } else {
-        hipLaunchKernelGGL((visn_embed_bwd_kernel<T, 4>), dim3(rows_grid(M, 128)), dim3(NT), 0, st, (const T*)dy,
-                           (const T*)z1, (const T*)z2, stats, (const T*)boxes, g1, g2, (T*)du, dbf, dg1, db1, dWb, dbb, dg2,
-                           db2, M, H, d);
+        hipLaunchKernelGGL((visn_embed_bwd_kernel<T, 4>), dim3(grid), dim3(NT), lds, st, (const T*)dy, (const T*)z1,
+                           (const T*)z2, stats, (const T*)boxes, g1, g2, (T*)du, ws, M, H, d);
     }
-    return xggm_check_launch("xggm_visn_embed_bwd");
+    if (int e = xggm_check_launch("xggm_visn_embed_bwd")) return e;
+    ReduceTargets tg{};
+    float* t[6] = {dbf, dg1, db1, dbb, dg2, db2};
+    for (int k = 0; k < 6; ++k) { tg.t[k] = t[k]; tg.stride[k] = 1; }
+    for (int j = 0; j < 4; ++j) { tg.t[6 + j] = dWb + j; tg.stride[6 + j] = 4; }
+    launch_reduce(ws, grid, 10, H, tg, st);
+    return xggm_check_launch("xggm_visn_embed_bwd(reduce)");
 }
 
-template <typename T> int colsum(const void* x, float* out, int M, int N, int64_t ld, hipStream_t st) {
+constexpr int CS_ROWS = 64;
+template <typename T> int colsum(const void* x, float* out, int M, int N, int64_t ld, float* ws, size_t ws_bytes,
+                                 hipStream_t st) {
     XGGM_REQUIRE(x && out && M > 0 && N > 0 && ld >= N, "xggm_colsum: bad arguments M=%d N=%d", M, N);
-    const int rpb = 64;
-    hipLaunchKernelGGL((colsum_kernel<T>), dim3(ceil_div(N, NT), ceil_div(M, rpb)), dim3(NT), 0, st, (const T*)x, out, M, N,
-                       ld, rpb);
-    return xggm_check_launch("xggm_colsum");
+    const int chunks = ceil_div(M, CS_ROWS);
+    XGGM_REQUIRE(ws && ws_bytes >= sizeof(float) * (size_t)chunks * N, "xggm_colsum: workspace of %zu bytes needed, got %zu",
+                 sizeof(float) * (size_t)chunks * N, ws_bytes);
+    hipLaunchKernelGGL((colsum_kernel<T>), dim3(ceil_div(N, NT), chunks), dim3(NT), 0, st, (const T*)x, ws, M, N, ld,
+                       CS_ROWS);
+    if (int e = xggm_check_launch("xggm_colsum")) return e;
+    ReduceTargets tg{};
+    tg.t[0] = out;
+    tg.stride[0] = 1;
+    launch_reduce(ws, chunks, 1, N, tg, st);
+    return xggm_check_launch("xggm_colsum(reduce)");
 }
 
+size_t ws_ln(int M, int H) { return bwd_ws_bytes(M, H, 3); }
+size_t ws_visn(int M, int H) { return bwd_ws_bytes(M, H, 10); }
+size_t ws_colsum(int M, int N) { return sizeof(float) * (size_t)ceil_div(M, CS_ROWS) * N; }
 }  // namespace
 
 #define ROW_API(SUF, T)                                                                                                     \
@@ -663,9 +729,10 @@ template <typename T> int colsum(const void* x, float* out, int M, int N, int64_
     extern "C" int xggm_ln_bwd_##SUF(const void* dy, const void* z, const float* stats, const float* gamma, void* d_in,    \
                                      void* d_res, float* dgamma, float* dbeta, float* dbias, int M, int H, float p_pre,    \
                                      float p_post, const uint64_t* rng, uint32_t s_pre, uint32_t s_post, float out_scale,  \
-                                     int accumulate_dres, const void* gelu_aux, hipStream_t st) {                         \
+                                     int accumulate_dres, const void* gelu_aux, float* ws, size_t ws_bytes,               \
+                                     hipStream_t st) {                                                                    \
         return ln_bwd<T>(dy, z, stats, gamma, d_in, d_res, dgamma, dbeta, dbias, M, H, p_pre, p_post, rng, s_pre, s_post,  \
-                         out_scale, accumulate_dres, gelu_aux, st);                                                        \
+                         out_scale, accumulate_dres, gelu_aux, ws, ws_bytes, st);                                          \
     }                                                                                                                       \
     extern "C" int xggm_embed_fwd_##SUF(const int64_t* ids, const int64_t* seg, const void* word, const void* pos,         \
                                         const void* type, const float* gamma, const float* beta, void* out, void* z_out,   \
@@ -676,9 +743,9 @@ template <typename T> int colsum(const void* x, float* out, int M, int N, int64_
     extern "C" int xggm_embed_bwd_##SUF(const int64_t* ids, const int64_t* seg, const void* dy, const void* z,             \
                                         const float* stats, const float* gamma, void* dz_ws, float* dword, float* dpos,    \
                                         float* dtype, float* dgamma, float* dbeta, int M, int Tlen, int H, float p,        \
-                                        const uint64_t* rng, uint32_t sid, hipStream_t st) {                              \
+                                        const uint64_t* rng, uint32_t sid, float* ws, size_t ws_bytes, hipStream_t st) {  \
         return embed_bwd<T>(ids, seg, dy, z, stats, gamma, dz_ws, dword, dpos, dtype, dgamma, dbeta, M, Tlen, H, p, rng,   \
-                            sid, st);                                                                                      \
+                            sid, ws, ws_bytes, st);                                                                        \
     }                                                                                                                       \
     extern "C" int xggm_visn_embed_fwd_##SUF(const void* u, const float* bf, const void* boxes, const float* Wb,           \
                                              const float* bb, const float* g1, const float* b1, const float* g2,           \
@@ -689,12 +756,20 @@ template <typename T> int colsum(const void* x, float* out, int M, int N, int64_
     extern "C" int xggm_visn_embed_bwd_##SUF(const void* dy, const void* z1, const void* z2, const float* stats,           \
                                              const void* boxes, const float* g1, const float* g2, void* du, float* dbf,    \
                                              float* dg1, float* db1, float* dWb, float* dbb, float* dg2, float* db2, int M,\
-                                             int H, float p, const uint64_t* rng, uint32_t sid, hipStream_t st) {         \
-        return visn_bwd<T>(dy, z1, z2, stats, boxes, g1, g2, du, dbf, dg1, db1, dWb, dbb, dg2, db2, M, H, p, rng, sid, st);\
+                                             int H, float p, const uint64_t* rng, uint32_t sid, float* ws,                \
+                                             size_t ws_bytes, hipStream_t st) {                                           \
+        return visn_bwd<T>(dy, z1, z2, stats, boxes, g1, g2, du, dbf, dg1, db1, dWb, dbb, dg2, db2, M, H, p, rng, sid, ws, \
+                           ws_bytes, st);                                                                                  \
     }                                                                                                                       \
-    extern "C" int xggm_colsum_##SUF(const void* x, float* out, int M, int N, int64_t ld, hipStream_t st) {                \
-        return colsum<T>(x, out, M, N, ld, st);                                                                            \
+    extern "C" int xggm_colsum_##SUF(const void* x, float* out, int M, int N, int64_t ld, float* ws, size_t ws_bytes,      \
+                                     hipStream_t st) {                                                                    \
+        return colsum<T>(x, out, M, N, ld, ws, ws_bytes, st);                                                              \
     }
 
 ROW_API(f32, float)
 ROW_API(bf16, bf16)
+
+// workspace sizes (bytes) of the backward row kernels: K partial rows per workgroup
+extern "C" size_t xggm_ln_bwd_workspace_bytes(int M, int H) { return ws_ln(M, H); }
+extern "C" size_t xggm_visn_embed_bwd_workspace_bytes(int M, int H) { return ws_visn(M, H); }
+extern "C" size_t xggm_colsum_workspace_bytes(int M, int N) { return ws_colsum(M, N); }

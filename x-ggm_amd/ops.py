@@ -101,12 +101,18 @@ def linear_wgrad(dy, x, gw, accumulate):
     gemm_raw(dy.dtype, dy, x, gw, N, K, M, 1, dy_rs, 1, x_rs, K, c_f32=True, accumulate=accumulate)
 
 
+def _ws(nbytes, device):
+    """scratch for the two-stage reductions (caller-owned, as the C ABI requires)."""
+    return torch.empty((nbytes + 3) // 4, device=device, dtype=F32), nbytes
+
+
 def colsum(x, out):
     """out[n] += sum_m x[m, n]  (fp32 accumulator)."""
     M, N, ld = _rows(_chk(x))
     _c(out, F32, "colsum out")
     assert out.numel() == N
-    call("xggm_colsum_" + sfx(x.dtype), ptr(x), ptr(out), M, N, ld, stream())
+    ws, nb = _ws(_lib.lib.xggm_colsum_workspace_bytes(M, N), x.device)
+    call("xggm_colsum_" + sfx(x.dtype), ptr(x), ptr(out), M, N, ld, ptr(ws), nb, stream())
 
 
 def bmm_nt(a, b, out_f32=True):
@@ -197,9 +203,10 @@ def ln_bwd(dy, z, stats, gamma, dgamma, dbeta, dbias, want_din=True, want_dres=F
         d_res = torch.empty_like(dy)
     if d_res is not None:
         assert d_res.shape == dy.shape and d_res.dtype == dy.dtype and d_res.is_contiguous()
+    ws, nb = _ws(_lib.lib.xggm_ln_bwd_workspace_bytes(M, H), dy.device)
     call("xggm_ln_bwd_" + sfx(dy.dtype), ptr(dy), ptr(z), ptr(stats), ptr(gamma), ptr(d_in), ptr(d_res),
          ptr(dgamma), ptr(dbeta), ptr(dbias), M, H, float(p_pre), float(p_post), ptr(rng), sid_pre, sid_post,
-         float(out_scale), int(acc), ptr(gelu_aux), stream())
+         float(out_scale), int(acc), ptr(gelu_aux), ptr(ws), nb, stream())
     return d_in, d_res
 
 
@@ -228,10 +235,11 @@ def embed_bwd(ids, seg, dy, z, stats, gamma, dword, dpos, dtyp, dgamma, dbeta, p
     _c(dy), _c(z, dy.dtype)
     for t in (dword, dpos, dtyp, dgamma, dbeta):
         _c(t, F32, "embedding grad")
-    ws = torch.empty_like(dy)
+    dz = torch.empty_like(dy)
+    ws, nb = _ws(_lib.lib.xggm_ln_bwd_workspace_bytes(M, H), dy.device)
     call("xggm_embed_bwd_" + sfx(dy.dtype), ptr(ids), ptr(seg), ptr(dy), ptr(z), ptr(stats), ptr(gamma),
-         ptr(ws), ptr(dword), ptr(dpos), ptr(dtyp), ptr(dgamma), ptr(dbeta), M, T, H, float(p), ptr(rng), sid,
-         stream())
+         ptr(dz), ptr(dword), ptr(dpos), ptr(dtyp), ptr(dgamma), ptr(dbeta), M, T, H, float(p), ptr(rng), sid,
+         ptr(ws), nb, stream())
 
 
 def visn_embed_fwd(u, bf, boxes, Wb, bb, g1, b1, g2, b2, eps, p, rng, sid):
@@ -254,9 +262,11 @@ def visn_embed_bwd(dy, z1, z2, stats, boxes, g1, g2, grads, p, rng, sid):
     _c(dy)
     M, H = dy.shape
     du = torch.empty_like(dy)
+    ws, nb = _ws(_lib.lib.xggm_visn_embed_bwd_workspace_bytes(M, H), dy.device)
     call("xggm_visn_embed_bwd_" + sfx(dy.dtype), ptr(dy), ptr(z1), ptr(z2), ptr(stats), ptr(boxes), ptr(g1),
          ptr(g2), ptr(du), ptr(grads["dbf"]), ptr(grads["dg1"]), ptr(grads["db1"]), ptr(grads["dWb"]),
-         ptr(grads["dbb"]), ptr(grads["dg2"]), ptr(grads["db2"]), M, H, float(p), ptr(rng), sid, stream())
+         ptr(grads["dbb"]), ptr(grads["dg2"]), ptr(grads["db2"]), M, H, float(p), ptr(rng), sid, ptr(ws), nb,
+         stream())
     return du
 
 
