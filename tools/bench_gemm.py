@@ -11,22 +11,30 @@ shapes = [  # (M tokens, N out, K in)
     (640, 2304, 768), (640, 768, 768), (640, 3072, 768), (640, 768, 3072), (32, 2274, 1536)]
 
 
-def timeit(fn, n=30):
-    for _ in range(5):
+def timeit(fn, n=20):
+    """GPU time per call: n calls captured into one hipGraph (no host launch latency inside)."""
+    for _ in range(3):
         fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n):
+            fn()
+    g.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(n):
-        fn()
+    for _ in range(3):
+        g.replay()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n * 1e-3
+    return e0.elapsed_time(e1) / (3 * n) * 1e-3
 
 
-tot = {0: 0.0, 1: 0.0}
+VARS = ["generic", "64x64d2", "64x64d4", "128x64d2", "128x64d3", "128x128d2", "auto"]
+tot = {v: 0.0 for v in VARS}
 flops_tot = 0.0
-print("%-28s %10s %10s %10s" % ("shape (M,N,K) form", "tuned TF", "generic TF", "us tuned"))
+print("%-26s " % "shape (M,N,K) form" + " ".join("%9s" % v for v in VARS) + "   (TFLOP/s)")
 for M, N, K in shapes:
     x = torch.randn(M, K, device=dev).bfloat16()
     w = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
@@ -35,16 +43,16 @@ for M, N, K in shapes:
     forms = {"fwd": lambda: ops.linear_fwd(x, w, None), "dgrad": lambda: ops.linear_dgrad(dy, w),
              "wgrad": lambda: ops.linear_wgrad(dy, x, gw, False)}
     for name, fn in forms.items():
-        res = {}
-        for generic in (0, 1):
-            _lib.lib.xggm_gemm_set_generic(generic)
-            res[generic] = timeit(fn)
-        _lib.lib.xggm_gemm_set_generic(0)
         fl = 2.0 * M * N * K
-        weight = 1
-        tot[0] += res[0] * weight
-        tot[1] += res[1] * weight
+        row = []
+        for vi, v in enumerate(VARS):
+            _lib.lib.xggm_gemm_set_generic(1 if v == "generic" else 0)
+            _lib.lib.xggm_gemm_set_tile(0 if v in ("generic", "auto") else vi)
+            t = timeit(fn)
+            tot[v] += t
+            row.append(fl / t / 1e12)
         flops_tot += fl
-        print("%-28s %10.1f %10.1f %10.1f" % ("(%d,%d,%d) %s" % (M, N, K, name), fl / res[0] / 1e12, fl / res[1] / 1e12,
-                                              res[0] * 1e6))
-print("aggregate: tuned %.1f TF, generic %.1f TF" % (flops_tot / tot[0] / 1e12, flops_tot / tot[1] / 1e12))
+        print("%-26s " % ("(%d,%d,%d) %s" % (M, N, K, name)) + " ".join("%9.1f" % r for r in row))
+_lib.lib.xggm_gemm_set_generic(0)
+_lib.lib.xggm_gemm_set_tile(0)
+print("%-26s " % "aggregate" + " ".join("%9.1f" % (flops_tot / tot[v] / 1e12) for v in VARS))

@@ -219,23 +219,29 @@ template <int R, bool KMAJ> struct OpLds {
     static constexpr int NCH = R / 32;  // 16-byte chunks per thread per k-tile
 };
 
+// Branch-free tile load: addresses are clamped into the operand (rows beyond the edge re-read
+// the last valid row: they only feed output rows/columns the epilogue never stores) and
+// chunks beyond K are zeroed by a select.  No control flow around the loads, so the compiler
+// can keep them in flight behind counted s_waitcnt vmcnt(N) instead of vmcnt(0).
 template <int R, bool KMAJ>
 __device__ __forceinline__ void fast_load(short8_t (&reg)[R / 32], const bf16* __restrict__ base, int64_t rs, int64_t ks,
                                           int r0, int k0, int Rtot, int K, int tid) {
 #pragma unroll
     for (int i = 0; i < R / 32; ++i) {
         const int c = tid + NT * i;
-        short8_t v = {};
+        short8_t v;
+        bool kvalid;
         if (KMAJ) {
-            const int row = c >> 3, kc = (c & 7) * 8;
-            if (r0 + row < Rtot && k0 + kc < K)
-                v = *reinterpret_cast<const short8_t*>(base + (int64_t)(r0 + row) * rs + k0 + kc);
+            const int row = min(r0 + (c >> 3), Rtot - 1), kc = k0 + (c & 7) * 8;
+            kvalid = kc < K;
+            v = *reinterpret_cast<const short8_t*>(base + (int64_t)row * rs + (kvalid ? kc : 0));
         } else {
-            const int kl = c / (R / 8), rc = (c % (R / 8)) * 8;
-            if (k0 + kl < K && r0 + rc < Rtot)
-                v = *reinterpret_cast<const short8_t*>(base + (int64_t)(k0 + kl) * ks + r0 + rc);
+            const int kl = k0 + c / (R / 8), rc = min(r0 + (c % (R / 8)) * 8, Rtot - 8);
+            kvalid = kl < K;
+            v = *reinterpret_cast<const short8_t*>(base + (int64_t)(kvalid ? kl : 0) * ks + rc);
         }
-        reg[i] = v;
+        const short8_t zero = {};
+        reg[i] = kvalid ? v : zero;
     }
 }
 
@@ -279,13 +285,25 @@ __device__ __forceinline__ bf16x8_t fast_frag(const bf16* lds, int row0, int ks,
     }
 }
 
-template <int BM, int BN, bool AK, bool BKM>
+// workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also waits
+// vmcnt(0), i.e. for the global prefetches that are supposed to stay in flight across it.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int BM, int BN, bool AK, bool BKM, int D>
 __global__ __launch_bounds__(NT) void gemm_fast_kernel(GemmArgs g) {
+    // D = prefetch depth: D k-tiles of both operands are in flight in registers while one tile
+    // is consumed from LDS.  These GEMMs are skinny (one k-chain per CU), so the k-loop would
+    // otherwise run at one L2/HBM round trip per iteration.
     typedef OpLds<BM, AK> LA;
     typedef OpLds<BN, BKM> LB;
     constexpr int TM = BM / 32, TN = BN / 32;  // 16x16 tiles per wave (wave tile = BM/2 x BN/2)
+    constexpr int STAGE = LA::ELEMS + LB::ELEMS;  // LDS buffer s: A at s*STAGE, B at s*STAGE + LA::ELEMS
+    constexpr int UNR = (D % 2 == 0) ? D : 2 * D;  // unroll so that stage (t % D) and buffer (t & 1) are static
     extern __shared__ __attribute__((aligned(16))) bf16 fsm[];
-    constexpr int STAGE = LA::ELEMS + LB::ELEMS;  // buffer s: A at s*STAGE, B at s*STAGE + LA::ELEMS
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = (wid >> 1) * (BM / 2), wn = (wid & 1) * (BN / 2);
@@ -299,39 +317,44 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
-    short8_t ra[LA::NCH], rb[LB::NCH];
-    fast_load<BM, AK>(ra, A, g.a_rs, g.a_ks, m0, 0, g.M, g.K, tid);
-    fast_load<BN, BKM>(rb, B, g.b_ns, g.b_ks, n0, 0, g.N, g.K, tid);
-    fast_store<BM, AK>(fsm, ra, tid);
-    fast_store<BN, BKM>(fsm + LA::ELEMS, rb, tid);
-    __syncthreads();
-    const int nk = (g.K + 63) / 64;
-    for (int t = 0; t < nk; ++t) {
-        const bf16* Ac = fsm + (t & 1) * STAGE;
-        const bf16* Bc = Ac + LA::ELEMS;
-        bf16* An = fsm + ((t + 1) & 1) * STAGE;
-        if (t + 1 < nk) {
-            fast_load<BM, AK>(ra, A, g.a_rs, g.a_ks, m0, (t + 1) * 64, g.M, g.K, tid);
-            fast_load<BN, BKM>(rb, B, g.b_ns, g.b_ks, n0, (t + 1) * 64, g.N, g.K, tid);
+    short8_t ra[D][LA::NCH], rb[D][LB::NCH];
+    // the k-loop runs a multiple of UNR tiles; tiles past K load zeros (see fast_load)
+    const int nk = ((g.K + 63) / 64 + UNR - 1) / UNR * UNR;
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+        fast_load<BM, AK>(ra[s], A, g.a_rs, g.a_ks, m0, s * 64, g.M, g.K, tid);
+        fast_load<BN, BKM>(rb[s], B, g.b_ns, g.b_ks, n0, s * 64, g.N, g.K, tid);
+    }
+    fast_store<BM, AK>(fsm, ra[0], tid);
+    fast_store<BN, BKM>(fsm + LA::ELEMS, rb[0], tid);
+    lds_barrier();
+    for (int t0 = 0; t0 < nk; t0 += UNR) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int t = t0 + u;
+            const bf16* Ac = fsm + (u & 1) * STAGE;
+            const bf16* Bc = Ac + LA::ELEMS;
+            bf16* An = fsm + ((u + 1) & 1) * STAGE;
+            // stage (t % D) was copied to LDS one step ago: refill it with tile t + D
+            fast_load<BM, AK>(ra[u % D], A, g.a_rs, g.a_ks, m0, (t + D) * 64, g.M, g.K, tid);
+            fast_load<BN, BKM>(rb[u % D], B, g.b_ns, g.b_ks, n0, (t + D) * 64, g.N, g.K, tid);
+#pragma unroll
+            for (int ks = 0; ks < 64; ks += 32) {
+                bf16x8_t a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = fast_frag<BM, AK>(Ac, wm + i * 16, ks, lane);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = fast_frag<BN, BKM>(Bc, wn + j * 16, ks, lane);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            fast_store<BM, AK>(An, ra[(u + 1) % D], tid);
+            fast_store<BN, BKM>(An + LA::ELEMS, rb[(u + 1) % D], tid);
+            lds_barrier();
         }
-#pragma unroll
-        for (int ks = 0; ks < 64; ks += 32) {
-            bf16x8_t a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = fast_frag<BM, AK>(Ac, wm + i * 16, ks, lane);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = fast_frag<BN, BKM>(Bc, wn + j * 16, ks, lane);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        if (t + 1 < nk) {
-            fast_store<BM, AK>(An, ra, tid);
-            fast_store<BN, BKM>(An + LA::ELEMS, rb, tid);
-        }
-        __syncthreads();
     }
     const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
@@ -341,7 +364,7 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(GemmArgs g) {
             epilogue_tile<bf16>(g, acc[i][j], m0 + wm + i * 16 + fq * 4, n0 + wn + j * 16 + fr, bz);
 }
 
-template <int BM, int BN> int launch_fast_tile(const GemmArgs& g, int batch, hipStream_t stream) {
+template <int BM, int BN, int D> int launch_fast_tile(const GemmArgs& g, int batch, hipStream_t stream) {
     dim3 grid(ceil_div(g.N, BN), ceil_div(g.M, BM), batch);
     const bool ak = g.a_mode == 1, bk = g.b_mode == 1;
 #define XGGM_FAST(AKv, BKv)                                                                                           \
@@ -349,11 +372,11 @@ template <int BM, int BN> int launch_fast_tile(const GemmArgs& g, int batch, hip
         constexpr size_t lds = 2 * sizeof(bf16) * (OpLds<BM, AKv>::ELEMS + OpLds<BN, BKv>::ELEMS);                   \
         static bool attr_set = false;                                                                                 \
         if (lds > 48 * 1024 && !attr_set) {                                                                           \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<BM, BN, AKv, BKv>),             \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<BM, BN, AKv, BKv, D>),          \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
             attr_set = true;                                                                                          \
         }                                                                                                             \
-        hipLaunchKernelGGL((gemm_fast_kernel<BM, BN, AKv, BKv>), grid, dim3(NT), lds, stream, g);                     \
+        hipLaunchKernelGGL((gemm_fast_kernel<BM, BN, AKv, BKv, D>), grid, dim3(NT), lds, stream, g);                  \
     } while (0)
     if (ak && bk) XGGM_FAST(true, true);
     else if (ak && !bk) XGGM_FAST(true, false);
@@ -363,12 +386,26 @@ template <int BM, int BN> int launch_fast_tile(const GemmArgs& g, int batch, hip
     return xggm_check_launch("xggm_gemm(fast)");
 }
 
-// tile choice: the largest tile that still yields >= 200 workgroups (256 CUs), else 64x64
+// tile / depth choice.  g_tile_override (xggm_gemm_set_tile) pins one variant for A/B tests:
+// 1 = 64x64 D2, 2 = 64x64 D4, 3 = 128x64 D2, 4 = 128x64 D3, 5 = 128x128 D2; 0 = heuristic.
+int g_tile_override = 0;
 inline int launch_fast(const GemmArgs& g, int batch, hipStream_t stream) {
     auto tiles = [&](int bm, int bn) { return (int64_t)ceil_div(g.M, bm) * ceil_div(g.N, bn) * batch; };
-    if (tiles(128, 128) >= 200) return launch_fast_tile<128, 128>(g, batch, stream);
-    if (tiles(128, 64) >= 200) return launch_fast_tile<128, 64>(g, batch, stream);
-    return launch_fast_tile<64, 64>(g, batch, stream);
+    int v = g_tile_override;
+    if (v == 0) {
+        // measured on MI355X at the step's shapes (tools/bench_gemm.py): 64x64 tiles win everywhere
+        // (these GEMMs need many workgroups more than big tiles); depth 4 helps when an operand is
+        // k-major, depth 2 is better for the all-transposed wgrad form
+        (void)tiles;
+        v = (g.a_mode == 2 && g.b_mode == 2) ? 1 : 2;
+    }
+    switch (v) {
+        case 1: return launch_fast_tile<64, 64, 2>(g, batch, stream);
+        case 2: return launch_fast_tile<64, 64, 4>(g, batch, stream);
+        case 3: return launch_fast_tile<128, 64, 2>(g, batch, stream);
+        case 4: return launch_fast_tile<128, 64, 3>(g, batch, stream);
+        default: return launch_fast_tile<128, 128, 2>(g, batch, stream);
+    }
 }
 
 template <typename T> int pick_mode(const void* base, int64_t rs, int64_t ks, int64_t bs, int R, int K) {
@@ -420,5 +457,10 @@ XGGM_GEMM_IMPL(xggm_gemm_bf16, bf16)
 // test/diagnostic hook: route bf16 GEMMs through the generic kernel (1) or the tuned one (0)
 extern "C" int xggm_gemm_set_generic(int on) {
     g_force_generic = on != 0;
+    return XGGM_OK;
+}
+
+extern "C" int xggm_gemm_set_tile(int variant) {
+    g_tile_override = variant;
     return XGGM_OK;
 }
