@@ -71,7 +71,8 @@ int xggm_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, i
 /* HOST: 1 = run bf16 GEMMs on the generic 64x64 kernel, 0 = tuned kernels (default); A/B tests */
 int xggm_gemm_set_generic(int on);
 /* HOST: pin the tuned bf16 kernel variant (1: 64x64 depth 2, 2: 64x64 depth 4, 3: 128x64 depth 2,
- * 4: 128x64 depth 3, 5: 128x128 depth 2; 0: heuristic) */
+ * 4: 128x64 depth 3, 5: 128x128 depth 2, 6: 32x64 depth 4, 7: 32x32 depth 4; 0: heuristic;
+ * | 0x100 turns the XCD-aware tile order off) */
 int xggm_gemm_set_tile(int variant);
 /* out[n] += sum_m x[m*ld + n]  (bias gradients; `out` must hold the running value) */
 int xggm_colsum_f32(const void* x, float* out, int M, int N, int64_t ld, float* ws, size_t ws_bytes,

@@ -272,5 +272,5 @@ def test_dropout_training_mode_runs_and_is_reproducible():
         assert all(np.isfinite(traj))
         runs.append(traj)
     # same seed -> same masks; fp32 atomics make the last bits run-dependent, nothing more
-    assert np.allclose(runs[0], runs[1], rtol=1e-5)
-    assert not np.allclose(runs[0], runs[2], rtol=1e-4)
+    assert np.allclose(runs[0], runs[1], rtol=1e-4)
+    assert not np.allclose(runs[0], runs[2], rtol=1e-3)

@@ -31,7 +31,8 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) / (3 * n) * 1e-3
 
 
-VARS = ["generic", "64x64d2", "64x64d4", "128x64d2", "128x64d3", "128x128d2", "auto"]
+VARS = ["64x64d2", "64x64d4", "64d4noswz", "32x64d4", "32x32d4", "auto"]
+CODE = {"64x64d2": 1, "64x64d4": 2, "64d4noswz": 2 | 0x100, "32x64d4": 6, "32x32d4": 7, "auto": 0}
 tot = {v: 0.0 for v in VARS}
 flops_tot = 0.0
 print("%-26s " % "shape (M,N,K) form" + " ".join("%9s" % v for v in VARS) + "   (TFLOP/s)")
@@ -46,8 +47,7 @@ for M, N, K in shapes:
         fl = 2.0 * M * N * K
         row = []
         for vi, v in enumerate(VARS):
-            _lib.lib.xggm_gemm_set_generic(1 if v == "generic" else 0)
-            _lib.lib.xggm_gemm_set_tile(0 if v in ("generic", "auto") else vi)
+            _lib.lib.xggm_gemm_set_tile(CODE[v])
             t = timeit(fn)
             tot[v] += t
             row.append(fl / t / 1e12)

@@ -37,6 +37,7 @@ struct GemmArgs {
     int accumulate;    // C += result
     float alpha;
     int a_mode, b_mode;  // 0 scalar, 1 vector along k, 2 vector along rows
+    int xcd_swizzle;
 };
 
 template <typename T> struct Tile;
@@ -53,6 +54,7 @@ template <> struct Tile<float> {
 
 constexpr int BM = 64, BN = 64, NT = 256;
 bool g_force_generic = false;  // test hook: xggm_gemm_set_generic
+int g_xcd_swizzle = 1;         // test hook: xggm_gemm_set_tile(variant | 0x100) disables it
 
 // stage a [64 rows][BK] operand tile into LDS (k contiguous).  elem(r,k) = base[r*rs + k*ks]
 template <typename T>
@@ -307,7 +309,19 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(GemmArgs g) {
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = (wid >> 1) * (BM / 2), wn = (wid & 1) * (BN / 2);
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, bz = blockIdx.z;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its
+    // own 4 MiB L2.  Give every XCD a CONTIGUOUS run of tiles (row-major), so the tiles that share
+    // an A row-panel run on one L2 instead of pulling every panel into all eight.  Placement only
+    // changes speed, never results.
+    int tile_m = blockIdx.y, tile_n = blockIdx.x;
+    if (g.xcd_swizzle) {
+        const int nb = gridDim.x * gridDim.y, L = blockIdx.y * gridDim.x + blockIdx.x;
+        const int q = nb >> 3, r = nb & 7, xcd = L & 7, idx = L >> 3;
+        const int nl = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        tile_m = nl / gridDim.x;
+        tile_n = nl % gridDim.x;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN, bz = blockIdx.z;
     const bf16* A = reinterpret_cast<const bf16*>(g.A) + (int64_t)bz * g.a_bs;
     const bf16* B = reinterpret_cast<const bf16*>(g.B) + (int64_t)bz * g.b_bs;
 
@@ -400,6 +414,8 @@ inline int launch_fast(const GemmArgs& g, int batch, hipStream_t stream) {
         v = (g.a_mode == 2 && g.b_mode == 2) ? 1 : 2;
     }
     switch (v) {
+        case 6: return launch_fast_tile<32, 64, 4>(g, batch, stream);
+        case 7: return launch_fast_tile<32, 32, 4>(g, batch, stream);
         case 1: return launch_fast_tile<64, 64, 2>(g, batch, stream);
         case 2: return launch_fast_tile<64, 64, 4>(g, batch, stream);
         case 3: return launch_fast_tile<128, 64, 2>(g, batch, stream);
@@ -447,7 +463,7 @@ template <typename T> int launch(GemmArgs g, int batch, hipStream_t stream) {
         g.a_bs = a_bs; g.b_bs = b_bs; g.c_bs = c_bs;                                                                   \
         g.bias = bias; g.residual = residual; g.preact = preact; g.aux = aux;                                         \
         g.act = act; g.c_f32 = c_f32; g.accumulate = accumulate; g.alpha = alpha;                                     \
-        g.a_mode = g.b_mode = 0;                                                                                       \
+        g.a_mode = g.b_mode = 0; g.xcd_swizzle = g_xcd_swizzle;                                                        \
         return launch<T>(g, batch, stream);                                                                            \
     }
 
@@ -461,6 +477,7 @@ extern "C" int xggm_gemm_set_generic(int on) {
 }
 
 extern "C" int xggm_gemm_set_tile(int variant) {
-    g_tile_override = variant;
+    g_tile_override = variant & 0xff;
+    g_xcd_swizzle = (variant & 0x100) ? 0 : 1;
     return XGGM_OK;
 }

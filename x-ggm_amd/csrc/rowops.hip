@@ -57,14 +57,34 @@ struct ReduceTargets {
 
 __global__ __launch_bounds__(NT) void partial_reduce_kernel(const float* __restrict__ ws, int nblk, int K, int H,
                                                             ReduceTargets tg) {
-    const int idx = blockIdx.x * NT + threadIdx.x;
-    if (idx >= K * H) return;
-    const int k = idx / H, c = idx % H;
-    float* t = tg.t[k];
-    if (!t) return;
+    // 64 (vector, column) pairs per workgroup, 4 slices of the block range each: the loads of a
+    // slice are independent and unrolled, so they pipeline instead of paying one L2 round trip each
+    __shared__ float red[4][64];
+    const int ci = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + ci;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += ws[((int64_t)b * K + k) * H + c];
-    t[(int64_t)c * tg.stride[k]] += s;
+    if (idx < K * H) {
+        const int k = idx / H, c = idx % H;
+        const float* p = ws + (int64_t)k * H + c;
+        const int64_t stride = (int64_t)K * H;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int b = sl;
+        for (; b + 12 < nblk; b += 16) {
+            a0 += p[(int64_t)b * stride];
+            a1 += p[(int64_t)(b + 4) * stride];
+            a2 += p[(int64_t)(b + 8) * stride];
+            a3 += p[(int64_t)(b + 12) * stride];
+        }
+        for (; b < nblk; b += 4) a0 += p[(int64_t)b * stride];
+        s = (a0 + a1) + (a2 + a3);
+    }
+    red[sl][ci] = s;
+    __syncthreads();
+    if (sl == 0 && idx < K * H) {
+        const int k = idx / H, c = idx % H;
+        float* t = tg.t[k];
+        if (t) t[(int64_t)c * tg.stride[k]] += (red[0][ci] + red[1][ci]) + (red[2][ci] + red[3][ci]);
+    }
 }
 
 // ------------------------------------------------------------------------------- LN fwd
@@ -542,16 +562,28 @@ __global__ __launch_bounds__(NT) void visn_embed_bwd_kernel(const T* __restrict_
 }
 
 // ------------------------------------------------------------------------------- column sum
-// out[n] (+)= sum_m x[m, n]  (bias gradients).  One thread per column pair of rows-chunk.
+// partial column sums (bias gradients): workgroup = 64 columns x 4 row lanes over a 64-row chunk
 template <typename T>
 __global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ x, float* ws, int M, int N, int64_t ld,
                                                     int rows_per_block) {
-    const int col = blockIdx.x * NT + threadIdx.x;
-    if (col >= N) return;
+    __shared__ float red[4][64];
+    const int ci = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + ci;
     const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
-    float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += to_f32(x[(int64_t)r * ld + col]);
-    ws[(int64_t)blockIdx.y * N + col] = s;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (col < N) {
+        int r = r0 + sl;
+        for (; r + 12 < r1; r += 16) {
+            a0 += to_f32(x[(int64_t)r * ld + col]);
+            a1 += to_f32(x[(int64_t)(r + 4) * ld + col]);
+            a2 += to_f32(x[(int64_t)(r + 8) * ld + col]);
+            a3 += to_f32(x[(int64_t)(r + 12) * ld + col]);
+        }
+        for (; r < r1; r += 4) a0 += to_f32(x[(int64_t)r * ld + col]);
+    }
+    red[sl][ci] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (sl == 0 && col < N) ws[(int64_t)blockIdx.y * N + col] = (red[0][ci] + red[1][ci]) + (red[2][ci] + red[3][ci]);
 }
 
 inline int rows_grid(int M, int cap) { return std::min(ceil_div(M, WPB), cap); }
@@ -591,7 +623,7 @@ int ln_fwd(const void* in, const float* bias, const void* residual, const float*
 inline size_t bwd_ws_bytes(int M, int H, int K) { return sizeof(float) * (size_t)rows_grid(M, 128) * K * H; }
 
 inline void launch_reduce(const float* ws, int nblk, int K, int H, const ReduceTargets& tg, hipStream_t st) {
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3(ceil_div(K * H, NT)), dim3(NT), 0, st, ws, nblk, K, H, tg);
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3(ceil_div(K * H, 64)), dim3(NT), 0, st, ws, nblk, K, H, tg);
 }
 
 template <typename T>
@@ -703,7 +735,7 @@ template <typename T> int colsum(const void* x, float* out, int M, int N, int64_
     const int chunks = ceil_div(M, CS_ROWS);
     XGGM_REQUIRE(ws && ws_bytes >= sizeof(float) * (size_t)chunks * N, "xggm_colsum: workspace of %zu bytes needed, got %zu",
                  sizeof(float) * (size_t)chunks * N, ws_bytes);
-    hipLaunchKernelGGL((colsum_kernel<T>), dim3(ceil_div(N, NT), chunks), dim3(NT), 0, st, (const T*)x, ws, M, N, ld,
+    hipLaunchKernelGGL((colsum_kernel<T>), dim3(ceil_div(N, 64), chunks), dim3(NT), 0, st, (const T*)x, ws, M, N, ld,
                        CS_ROWS);
     if (int e = xggm_check_launch("xggm_colsum")) return e;
     ReduceTargets tg{};
