@@ -68,6 +68,29 @@ int xggm_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, i
                    int64_t b_ks, int64_t ldc, int batch, int64_t a_bs, int64_t b_bs, int64_t c_bs, const float* bias,
                    const void* residual, void* preact, const void* aux, int act, int c_f32, int accumulate, float alpha,
                    xggm_stream_t stream);
+/* Up to 4 independent products in ONE launch (forward of both modalities, dgrad + wgrad of a layer):
+ * skinny problems that cannot fill 256 CUs alone share a grid.  `probs` is a HOST array; fields as
+ * the arguments of xggm_gemm_*.  Falls back to one launch per problem for shapes the tuned kernel
+ * does not take (unaligned strides, fp32). */
+typedef struct xggm_gemm_problem {
+    const void* A;
+    const void* B;
+    void* C;
+    int M, N, K;
+    int64_t a_rs, a_ks, b_ns, b_ks, ldc;
+    int batch;
+    int64_t a_bs, b_bs, c_bs;
+    const float* bias;
+    const void* residual;
+    void* preact;
+    const void* aux;
+    int act, c_f32, accumulate;
+    float alpha;
+} xggm_gemm_problem;
+int xggm_gemm_grouped_f32(const xggm_gemm_problem* probs, int n, xggm_stream_t stream);
+int xggm_gemm_grouped_bf16(const xggm_gemm_problem* probs, int n, xggm_stream_t stream);
+/* HOST: tile of grouped launches (0 heuristic, 1: 64x64, 2: 128x64, 3: 128x128) */
+int xggm_gemm_set_group_tile(int v);
 /* HOST: 1 = run bf16 GEMMs on the generic 64x64 kernel, 0 = tuned kernels (default); A/B tests */
 int xggm_gemm_set_generic(int on);
 /* HOST: pin the tuned bf16 kernel variant (1: 64x64 depth 2, 2: 64x64 depth 4, 3: 128x64 depth 2,

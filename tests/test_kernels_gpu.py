@@ -78,6 +78,43 @@ def test_linear_fwd_dgrad_wgrad(ops, dt, M, N, K):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("group_tile", [0, 1, 2, 3])
+def test_grouped_gemm(ops, dt, group_tile):
+    """forward (two modalities) + dgrad + wgrad in ONE launch == the four products done alone"""
+    from xggm_amd import _lib
+    _lib.lib.xggm_gemm_set_group_tile(group_tile)
+    try:
+        xl, xlr = rnd((640, 768), dt, 1)
+        xv, xvr = rnd((1152, 768), dt, 2)
+        w1, w1r = rnd((3072, 768), dt, 3, 0.05)
+        w2, w2r = rnd((768, 768), dt, 4, 0.05)
+        b1 = torch.randn(3072, generator=torch.Generator().manual_seed(5)).to(DEV)
+        dy, dyr = rnd((1152, 768), dt, 6)
+        res, resr = rnd((1152, 768), dt, 7)
+        gw = torch.full((768, 768), 3.0, device=DEV)
+        p1, y1, pre1 = ops.p_fwd(xl, w1, b1, act=ops.ACT_GELU, want_preact=True)
+        p2, y2, _ = ops.p_fwd(xv, w2, None)
+        p3, dx = ops.p_dgrad(dy, w2, residual=res)
+        p4 = ops.p_wgrad(dy, xv, gw, accumulate=True)
+        ops.gemm_group(dt, [p1, p2, p3, p4])
+        pr = pre1.double().cpu()
+        assert rel_err(pre1, xlr @ w1r.t() + b1.double().cpu()) < tol(dt)
+        assert rel_err(y1, pr * 0.5 * (1 + torch.erf(pr / math.sqrt(2)))) < tol(dt)
+        assert rel_err(y2, xvr @ w2r.t()) < tol(dt)
+        assert rel_err(dx, dyr @ w2r + resr) < tol(dt)
+        assert rel_err(gw, 3.0 + dyr.t() @ xvr) < tol(dt, 2e-5, 1e-4)
+        # odd shapes fall back to single launches and still agree
+        xo, xor_ = rnd((37, 100), dt, 8)
+        wo, wor = rnd((50, 100), dt, 9, 0.1)
+        p5, y5, _ = ops.p_fwd(xo, wo, None)
+        p6, y6, _ = ops.p_fwd(xv, w2, None)
+        ops.gemm_group(dt, [p5, p6])
+        assert rel_err(y5, xor_ @ wor.t()) < tol(dt) and rel_err(y6, xvr @ w2r.t()) < tol(dt)
+    finally:
+        _lib.lib.xggm_gemm_set_group_tile(0)
+
+
+@pytest.mark.parametrize("dt", DTS)
 def test_linear_strided_rows(ops, dt):
     """pooler input lang[:, 0]: rows strided by T*H"""
     B, T, H = 5, 20, 128

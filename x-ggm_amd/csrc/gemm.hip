@@ -38,6 +38,7 @@ struct GemmArgs {
     float alpha;
     int a_mode, b_mode;  // 0 scalar, 1 vector along k, 2 vector along rows
     int xcd_swizzle;
+    int batch;
 };
 
 template <typename T> struct Tile;
@@ -55,6 +56,7 @@ template <> struct Tile<float> {
 constexpr int BM = 64, BN = 64, NT = 256;
 bool g_force_generic = false;  // test hook: xggm_gemm_set_generic
 int g_xcd_swizzle = 1;         // test hook: xggm_gemm_set_tile(variant | 0x100) disables it
+int g_group_tile = 0;          // test hook: 0 heuristic, 1: 64x64, 2: 128x64, 3: 128x128
 
 // stage a [64 rows][BK] operand tile into LDS (k contiguous).  elem(r,k) = base[r*rs + k*ks]
 template <typename T>
@@ -296,7 +298,7 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 template <int BM, int BN, bool AK, bool BKM, int D>
-__global__ __launch_bounds__(NT) void gemm_fast_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile_m, int tile_n, int bz, bf16* fsm) {
     // D = prefetch depth: D k-tiles of both operands are in flight in registers while one tile
     // is consumed from LDS.  These GEMMs are skinny (one k-chain per CU), so the k-loop would
     // otherwise run at one L2/HBM round trip per iteration.
@@ -305,23 +307,10 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(GemmArgs g) {
     constexpr int TM = BM / 32, TN = BN / 32;  // 16x16 tiles per wave (wave tile = BM/2 x BN/2)
     constexpr int STAGE = LA::ELEMS + LB::ELEMS;  // LDS buffer s: A at s*STAGE, B at s*STAGE + LA::ELEMS
     constexpr int UNR = (D % 2 == 0) ? D : 2 * D;  // unroll so that stage (t % D) and buffer (t & 1) are static
-    extern __shared__ __attribute__((aligned(16))) bf16 fsm[];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = (wid >> 1) * (BM / 2), wn = (wid & 1) * (BN / 2);
-    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its
-    // own 4 MiB L2.  Give every XCD a CONTIGUOUS run of tiles (row-major), so the tiles that share
-    // an A row-panel run on one L2 instead of pulling every panel into all eight.  Placement only
-    // changes speed, never results.
-    int tile_m = blockIdx.y, tile_n = blockIdx.x;
-    if (g.xcd_swizzle) {
-        const int nb = gridDim.x * gridDim.y, L = blockIdx.y * gridDim.x + blockIdx.x;
-        const int q = nb >> 3, r = nb & 7, xcd = L & 7, idx = L >> 3;
-        const int nl = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        tile_m = nl / gridDim.x;
-        tile_n = nl % gridDim.x;
-    }
-    const int m0 = tile_m * BM, n0 = tile_n * BN, bz = blockIdx.z;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const bf16* A = reinterpret_cast<const bf16*>(g.A) + (int64_t)bz * g.a_bs;
     const bf16* B = reinterpret_cast<const bf16*>(g.B) + (int64_t)bz * g.b_bs;
 
@@ -376,6 +365,77 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
             epilogue_tile<bf16>(g, acc[i][j], m0 + wm + i * 16 + fq * 4, n0 + wn + j * 16 + fr, bz);
+}
+
+
+// XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its own
+// 4 MiB L2.  Give every XCD a CONTIGUOUS run of tiles (row-major), so tiles sharing an A row-panel
+// run on one L2 instead of pulling every panel into all eight.  Placement changes speed only.
+__device__ __forceinline__ int xcd_remap(int L, int nb) {
+    const int q = nb >> 3, r = nb & 7, xcd = L & 7, idx = L >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <int BM, int BN, bool AK, bool BKM, int D>
+__global__ __launch_bounds__(NT) void gemm_fast_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) bf16 fsm[];
+    int tile_m = blockIdx.y, tile_n = blockIdx.x;
+    if (g.xcd_swizzle) {
+        const int nl = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+        tile_m = nl / gridDim.x;
+        tile_n = nl % gridDim.x;
+    }
+    gemm_tile<BM, BN, AK, BKM, D>(g, tile_m, tile_n, blockIdx.z, fsm);
+}
+
+// ---- grouped launch: up to 4 independent GEMMs (forward of both modalities, dgrad + wgrad of one
+// layer, ...) share ONE grid, so skinny problems that cannot fill 256 CUs alone fill them together
+// and the per-launch latency is paid once.  Every workgroup looks up its problem from the tile
+// prefix sums and runs the layout-specialised tile routine.
+constexpr int MAX_GROUP = 4;
+struct GroupArgs {
+    GemmArgs p[MAX_GROUP];
+    int tile_start[MAX_GROUP + 1];
+    int nprob;
+};
+
+template <int BM, int BN> __global__ __launch_bounds__(NT) void gemm_grouped_kernel(GroupArgs ga) {
+    extern __shared__ __attribute__((aligned(16))) bf16 fsm[];
+    int b = blockIdx.x;
+    if (ga.p[0].xcd_swizzle) b = xcd_remap(b, gridDim.x);
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < MAX_GROUP; ++k)
+        if (k < ga.nprob && b >= ga.tile_start[k]) i = k;
+    const GemmArgs& g = ga.p[i];
+    const int local = b - ga.tile_start[i];
+    const int gx = (g.N + BN - 1) / BN, gy = (g.M + BM - 1) / BM;
+    const int tile_n = local % gx, tile_m = (local / gx) % gy, bz = local / (gx * gy);
+    if (g.a_mode == 1) {
+        if (g.b_mode == 1) gemm_tile<BM, BN, true, true, 3>(g, tile_m, tile_n, bz, fsm);
+        else gemm_tile<BM, BN, true, false, 3>(g, tile_m, tile_n, bz, fsm);
+    } else {
+        if (g.b_mode == 1) gemm_tile<BM, BN, false, true, 3>(g, tile_m, tile_n, bz, fsm);
+        else gemm_tile<BM, BN, false, false, 2>(g, tile_m, tile_n, bz, fsm);
+    }
+}
+
+template <int BM, int BN> int launch_grouped_tile(GroupArgs& ga, hipStream_t stream) {
+    int total = 0;
+    for (int i = 0; i < ga.nprob; ++i) {
+        ga.tile_start[i] = total;
+        total += ceil_div(ga.p[i].M, BM) * ceil_div(ga.p[i].N, BN) * ga.p[i].batch;
+    }
+    ga.tile_start[ga.nprob] = total;
+    constexpr size_t lds = 2 * sizeof(bf16) * (OpLds<BM, false>::ELEMS + OpLds<BN, false>::ELEMS);
+    static bool attr_set = false;
+    if (lds > 48 * 1024 && !attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_grouped_kernel<BM, BN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_grouped_kernel<BM, BN>), dim3(total), dim3(NT), lds, stream, ga);
+    return xggm_check_launch("xggm_gemm_grouped");
 }
 
 template <int BM, int BN, int D> int launch_fast_tile(const GemmArgs& g, int batch, hipStream_t stream) {
@@ -463,7 +523,7 @@ template <typename T> int launch(GemmArgs g, int batch, hipStream_t stream) {
         g.a_bs = a_bs; g.b_bs = b_bs; g.c_bs = c_bs;                                                                   \
         g.bias = bias; g.residual = residual; g.preact = preact; g.aux = aux;                                         \
         g.act = act; g.c_f32 = c_f32; g.accumulate = accumulate; g.alpha = alpha;                                     \
-        g.a_mode = g.b_mode = 0; g.xcd_swizzle = g_xcd_swizzle;                                                        \
+        g.a_mode = g.b_mode = 0; g.xcd_swizzle = g_xcd_swizzle; g.batch = batch;                                       \
         return launch<T>(g, batch, stream);                                                                            \
     }
 
@@ -479,5 +539,60 @@ extern "C" int xggm_gemm_set_generic(int on) {
 extern "C" int xggm_gemm_set_tile(int variant) {
     g_tile_override = variant & 0xff;
     g_xcd_swizzle = (variant & 0x100) ? 0 : 1;
+    return XGGM_OK;
+}
+
+// ---- grouped entry point -------------------------------------------------------------------------
+namespace {
+GemmArgs from_problem(const xggm_gemm_problem& p) {
+    GemmArgs g;
+    g.A = p.A; g.B = p.B; g.C = p.C; g.M = p.M; g.N = p.N; g.K = p.K;
+    g.a_rs = p.a_rs; g.a_ks = p.a_ks; g.b_ns = p.b_ns; g.b_ks = p.b_ks; g.ldc = p.ldc;
+    g.a_bs = p.a_bs; g.b_bs = p.b_bs; g.c_bs = p.c_bs;
+    g.bias = p.bias; g.residual = p.residual; g.preact = p.preact; g.aux = p.aux;
+    g.act = p.act; g.c_f32 = p.c_f32; g.accumulate = p.accumulate; g.alpha = p.alpha;
+    g.a_mode = g.b_mode = 0; g.xcd_swizzle = g_xcd_swizzle; g.batch = p.batch;
+    return g;
+}
+
+template <typename T> int grouped(const xggm_gemm_problem* probs, int n, hipStream_t stream) {
+    XGGM_REQUIRE(probs && n > 0, "xggm_gemm_grouped: no problems");
+    bool fast = sizeof(T) == 2 && !g_force_generic && n <= MAX_GROUP;
+    GroupArgs ga;
+    ga.nprob = n;
+    for (int i = 0; i < n && fast; ++i) {
+        GemmArgs g = from_problem(probs[i]);
+        if (!(g.M > 0 && g.N > 0 && g.K > 0 && g.batch > 0 && g.A && g.B && g.C)) fast = false;
+        g.a_mode = pick_mode<T>(g.A, g.a_rs, g.a_ks, g.a_bs, g.M, g.K);
+        g.b_mode = pick_mode<T>(g.B, g.b_ns, g.b_ks, g.b_bs, g.N, g.K);
+        if (g.a_mode == 0 || g.b_mode == 0) fast = false;
+        ga.p[i] = g;
+    }
+    if (!fast || n == 1) {  // odd shapes, fp32 mode or a single problem: one launch each
+        for (int i = 0; i < n; ++i)
+            if (int e = launch<T>(from_problem(probs[i]), probs[i].batch, stream)) return e;
+        return XGGM_OK;
+    }
+    int64_t t128 = 0, t12864 = 0;
+    for (int i = 0; i < n; ++i) {
+        t128 += (int64_t)ceil_div(ga.p[i].M, 128) * ceil_div(ga.p[i].N, 128) * ga.p[i].batch;
+        t12864 += (int64_t)ceil_div(ga.p[i].M, 128) * ceil_div(ga.p[i].N, 64) * ga.p[i].batch;
+    }
+    int v = g_group_tile;
+    if (v == 0) v = t128 >= 240 ? 3 : (t12864 >= 240 ? 2 : 1);
+    if (v == 3) return launch_grouped_tile<128, 128>(ga, stream);
+    if (v == 2) return launch_grouped_tile<128, 64>(ga, stream);
+    return launch_grouped_tile<64, 64>(ga, stream);
+}
+}  // namespace
+
+extern "C" int xggm_gemm_grouped_bf16(const xggm_gemm_problem* probs, int n, hipStream_t stream) {
+    return grouped<bf16>(probs, n, stream);
+}
+extern "C" int xggm_gemm_grouped_f32(const xggm_gemm_problem* probs, int n, hipStream_t stream) {
+    return grouped<float>(probs, n, stream);
+}
+extern "C" int xggm_gemm_set_group_tile(int v) {
+    g_group_tile = v;
     return XGGM_OK;
 }

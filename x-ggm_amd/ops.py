@@ -106,6 +106,63 @@ def _ws(nbytes, device):
     return torch.empty((nbytes + 3) // 4, device=device, dtype=F32), nbytes
 
 
+# ---- grouped launches: several independent products in one grid -------------------------------
+import ctypes as _ct
+
+
+class GemmProblem(_ct.Structure):
+    """mirror of ``xggm_gemm_problem`` (include/xggm.h)"""
+    _fields_ = [("A", _ct.c_void_p), ("B", _ct.c_void_p), ("C", _ct.c_void_p),
+                ("M", _ct.c_int), ("N", _ct.c_int), ("K", _ct.c_int),
+                ("a_rs", _ct.c_int64), ("a_ks", _ct.c_int64), ("b_ns", _ct.c_int64), ("b_ks", _ct.c_int64),
+                ("ldc", _ct.c_int64), ("batch", _ct.c_int),
+                ("a_bs", _ct.c_int64), ("b_bs", _ct.c_int64), ("c_bs", _ct.c_int64),
+                ("bias", _ct.c_void_p), ("residual", _ct.c_void_p), ("preact", _ct.c_void_p), ("aux", _ct.c_void_p),
+                ("act", _ct.c_int), ("c_f32", _ct.c_int), ("accumulate", _ct.c_int), ("alpha", _ct.c_float)]
+
+
+def _problem(A, B, C, M, N, K, a_rs, a_ks, b_ns, b_ks, ldc, bias=None, residual=None, preact=None, aux=None,
+             act=ACT_NONE, c_f32=False, accumulate=False):
+    return GemmProblem(ptr(A), ptr(B), ptr(C), M, N, K, a_rs, a_ks, b_ns, b_ks, ldc, 1, 0, 0, 0, ptr(bias),
+                       ptr(residual), ptr(preact), ptr(aux), act, int(c_f32), int(accumulate), 1.0)
+
+
+def p_fwd(x, w, bias=None, act=ACT_NONE, want_preact=False, out_f32=False):
+    """problem for y = act(x @ w^T + bias); returns (problem, y, preact)."""
+    M, K, a_rs = _rows(_chk(x))
+    N = w.shape[0]
+    assert w.shape[1] == K and w.dtype == x.dtype and w.is_contiguous()
+    y = torch.empty((M, N), device=x.device, dtype=F32 if out_f32 else x.dtype)
+    pre = torch.empty((M, N), device=x.device, dtype=x.dtype) if want_preact else None
+    return _problem(x, w, y, M, N, K, a_rs, 1, K, 1, N, bias=bias, preact=pre, act=act, c_f32=out_f32), y, pre
+
+
+def p_dgrad(dy, w, residual=None, gelu_aux=None):
+    """problem for dx = dy @ w (+ residual) (* gelu'(aux)); returns (problem, dx)."""
+    M, N, a_rs = _rows(_chk(dy))
+    K = w.shape[1]
+    assert w.shape[0] == N and w.dtype == dy.dtype and w.is_contiguous()
+    dx = torch.empty((M, K), device=dy.device, dtype=dy.dtype)
+    return _problem(dy, w, dx, M, K, N, a_rs, 1, 1, K, K, residual=residual, aux=gelu_aux,
+                    act=ACT_GELU_GRAD if gelu_aux is not None else ACT_NONE), dx
+
+
+def p_wgrad(dy, x, gw, accumulate):
+    """problem for gw (+)= dy^T @ x (fp32)."""
+    M, N, dy_rs = _rows(_chk(dy))
+    M2, K, x_rs = _rows(_chk(x))
+    assert M2 == M and x.dtype == dy.dtype and tuple(gw.shape) == (N, K) and gw.dtype == F32 and gw.is_contiguous()
+    return _problem(dy, x, gw, N, K, M, 1, dy_rs, 1, x_rs, K, c_f32=True, accumulate=accumulate)
+
+
+def gemm_group(dt, problems):
+    """launch up to 4 independent products in one grid (more: consecutive groups of 4)."""
+    for i in range(0, len(problems), 4):
+        chunk = problems[i:i + 4]
+        arr = (GemmProblem * len(chunk))(*chunk)
+        call("xggm_gemm_grouped_" + sfx(dt), _ct.cast(arr, _ct.c_void_p), len(chunk), stream())
+
+
 def colsum(x, out):
     """out[n] += sum_m x[m, n]  (fp32 accumulator)."""
     M, N, ld = _rows(_chk(x))
