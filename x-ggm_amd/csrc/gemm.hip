@@ -224,28 +224,28 @@ template <int R, bool KMAJ> struct OpLds {
 };
 
 // Branch-free tile load: addresses are clamped into the operand (rows beyond the edge re-read
-// the last valid row: they only feed output rows/columns the epilogue never stores) and
-// chunks beyond K are zeroed by a select.  No control flow around the loads, so the compiler
-// can keep them in flight behind counted s_waitcnt vmcnt(N) instead of vmcnt(0).
+// the last valid row: they only feed output rows/columns the epilogue never stores) and chunks
+// beyond K are redirected to a 16-byte page of zeros -- the select acts on the ADDRESS, never on
+// the loaded data, so nothing depends on a load until its registers are copied to LDS D tiles
+// later and the compiler keeps the loads in flight behind counted s_waitcnt vmcnt(N).
+__device__ __attribute__((aligned(16))) unsigned short g_zero_chunk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
 template <int R, bool KMAJ>
 __device__ __forceinline__ void fast_load(short8_t (&reg)[R / 32], const bf16* __restrict__ base, int64_t rs, int64_t ks,
                                           int r0, int k0, int Rtot, int K, int tid) {
+    const bf16* zero = reinterpret_cast<const bf16*>(g_zero_chunk);
 #pragma unroll
     for (int i = 0; i < R / 32; ++i) {
         const int c = tid + NT * i;
-        short8_t v;
-        bool kvalid;
+        const bf16* p;
         if (KMAJ) {
             const int row = min(r0 + (c >> 3), Rtot - 1), kc = k0 + (c & 7) * 8;
-            kvalid = kc < K;
-            v = *reinterpret_cast<const short8_t*>(base + (int64_t)row * rs + (kvalid ? kc : 0));
+            p = kc < K ? base + (int64_t)row * rs + kc : zero;
         } else {
             const int kl = k0 + c / (R / 8), rc = min(r0 + (c % (R / 8)) * 8, Rtot - 8);
-            kvalid = kl < K;
-            v = *reinterpret_cast<const short8_t*>(base + (int64_t)(kvalid ? kl : 0) * ks + rc);
+            p = kl < K ? base + (int64_t)kl * ks + rc : zero;
         }
-        const short8_t zero = {};
-        reg[i] = kvalid ? v : zero;
+        reg[i] = *reinterpret_cast<const short8_t*>(p);
     }
 }
 
@@ -286,6 +286,128 @@ __device__ __forceinline__ bf16x8_t fast_frag(const bf16* lds, int row0, int ks,
         v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
         v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
         return __builtin_bit_cast(bf16x8_t, v);
+    }
+}
+
+// ---- epilogue of the tuned kernels -------------------------------------------------------------
+// The accumulators of a half tile (BM/2 rows) are parked in LDS as fp32, then every thread walks
+// 8-element row chunks: bias, activation, residual, pre-activation save and the store are done on
+// 16/32-byte vectors along the row (full lines instead of 64 scattered 2-byte stores per lane), in a
+// rolled loop -- a fully unrolled per-element epilogue with its activation switch made the code
+// object ~100 KB and the instruction fetch of that was most of the kernel's fixed cost.
+template <int BM, int BN, int TM, int TN>
+__device__ __forceinline__ void epilogue_staged(const GemmArgs& g, const float4_t (&acc)[TM][TN], int m0, int n0, int bz,
+                                             float* stage, int wm, int wn) {
+    constexpr int LDS_LD = BN + 4;
+    constexpr int CPR = BN / 8;           // 8-element chunks per row
+    constexpr int HALF = BM / 2;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int64_t coff = (int64_t)bz * g.c_bs;
+    const bool vec_ok = (g.ldc % 8 == 0) && (g.N % 8 == 0) && (reinterpret_cast<uintptr_t>(g.C) % 16 == 0) &&
+                        (!g.residual || reinterpret_cast<uintptr_t>(g.residual) % 16 == 0) &&
+                        (!g.preact || reinterpret_cast<uintptr_t>(g.preact) % 16 == 0) &&
+                        (!g.aux || reinterpret_cast<uintptr_t>(g.aux) % 16 == 0) && (coff % 8 == 0);
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        if ((wid >> 1) == h) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        stage[(i * 16 + fq * 4 + r) * LDS_LD + wn + j * 16 + fr] = acc[i][j][r];
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int c = tid; c < HALF * CPR; c += NT) {
+            const int lr = c / CPR, lc = (c % CPR) * 8;
+            const int row = m0 + h * HALF + lr, col = n0 + lc;
+            if (row >= g.M || col >= g.N) continue;
+            float v[8];
+            {
+                const float4 a = *reinterpret_cast<const float4*>(stage + lr * LDS_LD + lc);
+                const float4 b = *reinterpret_cast<const float4*>(stage + lr * LDS_LD + lc + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            }
+            const int nval = min(8, g.N - col);
+            const int64_t idx = coff + (int64_t)row * g.ldc + col;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = g.alpha * v[e] + ((g.bias && e < nval) ? g.bias[col + e] : 0.f);
+            bf16* pre = reinterpret_cast<bf16*>(g.preact);
+            const bf16* aux = reinterpret_cast<const bf16*>(g.aux);
+            const bf16* res = reinterpret_cast<const bf16*>(g.residual);
+            if (vec_ok) {
+                if (pre) {
+                    short8_t pv;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const bf16 t = __float2bfloat16(v[e]);
+                        pv[e] = __builtin_bit_cast(short, t);
+                        v[e] = __bfloat162float(t);  // the activation sees the value as stored
+                    }
+                    *reinterpret_cast<short8_t*>(pre + idx) = pv;
+                }
+                if (g.act != XGGM_ACT_NONE) {
+                    float ax[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (g.act == XGGM_ACT_GELU_GRAD) {
+                        const short8_t av = *reinterpret_cast<const short8_t*>(aux + idx);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ax[e] = __bfloat162float(__builtin_bit_cast(bf16, (short)av[e]));
+                    }
+#pragma unroll 1
+                    for (int e = 0; e < 8; ++e) v[e] = act_apply<bf16>(g.act, v[e], ax[e]);
+                }
+                if (res) {
+                    const short8_t rv = *reinterpret_cast<const short8_t*>(res + idx);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += __bfloat162float(__builtin_bit_cast(bf16, (short)rv[e]));
+                }
+                if (g.c_f32) {
+                    float* c = reinterpret_cast<float*>(g.C) + idx;
+                    float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
+                    if (g.accumulate) {
+                        const float4 p0 = *reinterpret_cast<const float4*>(c), p1 = *reinterpret_cast<const float4*>(c + 4);
+                        o0.x += p0.x; o0.y += p0.y; o0.z += p0.z; o0.w += p0.w;
+                        o1.x += p1.x; o1.y += p1.y; o1.z += p1.z; o1.w += p1.w;
+                    }
+                    *reinterpret_cast<float4*>(c) = o0;
+                    *reinterpret_cast<float4*>(c + 4) = o1;
+                } else {
+                    bf16* c = reinterpret_cast<bf16*>(g.C) + idx;
+                    if (g.accumulate) {
+                        const short8_t pv = *reinterpret_cast<const short8_t*>(c);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += __bfloat162float(__builtin_bit_cast(bf16, (short)pv[e]));
+                    }
+                    short8_t ov;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ov[e] = __builtin_bit_cast(short, __float2bfloat16(v[e]));
+                    *reinterpret_cast<short8_t*>(c) = ov;
+                }
+            } else {
+#pragma unroll 1
+                for (int e = 0; e < nval; ++e) {
+                    float x = v[e];
+                    if (pre) {
+                        pre[idx + e] = __float2bfloat16(x);
+                        x = round_to<bf16>(x);
+                    }
+                    if (g.act != XGGM_ACT_NONE)
+                        x = act_apply<bf16>(g.act, x, g.act == XGGM_ACT_GELU_GRAD ? __bfloat162float(aux[idx + e]) : 0.f);
+                    if (res) x += __bfloat162float(res[idx + e]);
+                    if (g.c_f32) {
+                        float* c = reinterpret_cast<float*>(g.C) + idx + e;
+                        *c = g.accumulate ? (*c + x) : x;
+                    } else {
+                        bf16* c = reinterpret_cast<bf16*>(g.C) + idx + e;
+                        *c = __float2bfloat16(g.accumulate ? (__bfloat162float(*c) + x) : x);
+                    }
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -359,12 +481,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile_m, int til
             lds_barrier();
         }
     }
-    const int fr = lane & 15, fq = lane >> 4;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-            epilogue_tile<bf16>(g, acc[i][j], m0 + wm + i * 16 + fq * 4, n0 + wn + j * 16 + fr, bz);
+    // the k-loop ended with a barrier: LDS is free for the staged epilogue
+    epilogue_staged<BM, BN, TM, TN>(g, acc, m0, n0, bz, reinterpret_cast<float*>(fsm), wm, wn);
 }
 
 
@@ -401,21 +519,23 @@ struct GroupArgs {
 
 template <int BM, int BN> __global__ __launch_bounds__(NT) void gemm_grouped_kernel(GroupArgs ga) {
     extern __shared__ __attribute__((aligned(16))) bf16 fsm[];
-    int b = blockIdx.x;
-    if (ga.p[0].xcd_swizzle) b = xcd_remap(b, gridDim.x);
+    // natural block order: an XCD-contiguous remap would hand whole problems (with different
+    // k-loop lengths) to different XCDs and unbalance them
+    const int b = blockIdx.x;
     int i = 0;
 #pragma unroll
     for (int k = 1; k < MAX_GROUP; ++k)
         if (k < ga.nprob && b >= ga.tile_start[k]) i = k;
-    const GemmArgs& g = ga.p[i];
+    const GemmArgs g = ga.p[i];
     const int local = b - ga.tile_start[i];
     const int gx = (g.N + BN - 1) / BN, gy = (g.M + BM - 1) / BM;
     const int tile_n = local % gx, tile_m = (local / gx) % gy, bz = local / (gx * gy);
+    constexpr int DK = (BM * BN <= 64 * 64) ? 4 : 2;  // prefetch depth when an operand is k-major
     if (g.a_mode == 1) {
-        if (g.b_mode == 1) gemm_tile<BM, BN, true, true, 3>(g, tile_m, tile_n, bz, fsm);
-        else gemm_tile<BM, BN, true, false, 3>(g, tile_m, tile_n, bz, fsm);
+        if (g.b_mode == 1) gemm_tile<BM, BN, true, true, DK>(g, tile_m, tile_n, bz, fsm);
+        else gemm_tile<BM, BN, true, false, DK>(g, tile_m, tile_n, bz, fsm);
     } else {
-        if (g.b_mode == 1) gemm_tile<BM, BN, false, true, 3>(g, tile_m, tile_n, bz, fsm);
+        if (g.b_mode == 1) gemm_tile<BM, BN, false, true, DK>(g, tile_m, tile_n, bz, fsm);
         else gemm_tile<BM, BN, false, false, 2>(g, tile_m, tile_n, bz, fsm);
     }
 }
@@ -474,8 +594,9 @@ inline int launch_fast(const GemmArgs& g, int batch, hipStream_t stream) {
         v = (g.a_mode == 2 && g.b_mode == 2) ? 1 : 2;
     }
     switch (v) {
-        case 6: return launch_fast_tile<32, 64, 4>(g, batch, stream);
-        case 7: return launch_fast_tile<32, 32, 4>(g, batch, stream);
+        case 6: return launch_fast_tile<64, 64, 1>(g, batch, stream);
+        case 7: return launch_fast_tile<128, 64, 1>(g, batch, stream);
+        case 8: return launch_fast_tile<128, 128, 1>(g, batch, stream);
         case 1: return launch_fast_tile<64, 64, 2>(g, batch, stream);
         case 2: return launch_fast_tile<64, 64, 4>(g, batch, stream);
         case 3: return launch_fast_tile<128, 64, 2>(g, batch, stream);
@@ -568,6 +689,9 @@ template <typename T> int grouped(const xggm_gemm_problem* probs, int n, hipStre
         if (g.a_mode == 0 || g.b_mode == 0) fast = false;
         ga.p[i] = g;
     }
+    // longest k-loops first: their tiles start early and the short ones fill the tail
+    for (int i = 1; i < n && fast; ++i)
+        for (int j = i; j > 0 && ga.p[j].K > ga.p[j - 1].K; --j) std::swap(ga.p[j], ga.p[j - 1]);
     if (!fast || n == 1) {  // odd shapes, fp32 mode or a single problem: one launch each
         for (int i = 0; i < n; ++i)
             if (int e = launch<T>(from_problem(probs[i]), probs[i].batch, stream)) return e;
