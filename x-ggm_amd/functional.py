@@ -108,108 +108,233 @@ class VisnEmbedFn(Function):
 
 
 # --------------------------------------------------------------------------------- transformer blocks
-class AttnBlockFn(Function):
-    """BertSelfattLayer / BertCrossattLayer (src/lxrt/modeling.py:391-414):
+# Every block is written as a GENERATOR that yields lists of GEMM problems (ops.GemmProblem) at the
+# points where it needs dense products done, and runs its other kernels (attention core, row
+# kernels) inline.  ``drive`` advances one or several generators in lockstep and launches what
+# they yielded in the same round as ONE grouped GEMM: dgrad + wgrad of a layer, or the same layer
+# of the language and the vision stream, share a grid -- these products are too skinny
+# (M = 640 / 1152 rows) to fill 256 CUs alone.
+def drive(dt, gens):
+    """advance the generators in lockstep; returns their return values."""
+    n = len(gens)
+    out = [None] * n
+    alive = list(range(n))
+    while alive:
+        probs, nxt = [], []
+        for i in alive:
+            try:
+                p = next(gens[i])
+                if p:
+                    probs.extend(p)
+                nxt.append(i)
+            except StopIteration as e:
+                out[i] = e.value
+        if probs:
+            ops.gemm_group(dt, probs)
+        alive = nxt
+    return out
+
+
+def _p_wgrad(rt, dy, x, ps):
+    gw, acc = rt.arena.target(ps)
+    return ops.p_wgrad(dy, x, gw, acc)
+
+
+def g_attn_fwd(rt, att, outm, xq, xkv, mask, B, Sq, Sk, salt):
+    """BertSelfattLayer / BertCrossattLayer forward (src/lxrt/modeling.py:391-414):
     y = LN(dropout(W_o attn(W_q x_q, W_k x_kv, W_v x_kv) + b_o) + x_q).
-    ``xkv is None`` = self-attention: one fused [3H,H] projection.  ``salt`` separates the
-    dropout streams of the two calls of the shared ``visual_attention`` block."""
+    ``xkv is None`` = self-attention: one fused [3H,H] projection."""
+    a = rt.arena
+    H = xq.shape[1]
+    heads = att.num_attention_heads
+    wq, wk, wv = att.query.weight, att.key.weight, att.value.weight
+    bq, bk, bv = att.query.bias, att.key.bias, att.value.bias
+    self_att = xkv is None
+    if self_att:
+        p1, qkv, _ = ops.p_fwd(xq, a.fused([wq, wk, wv]), a.fused([bq, bk, bv]))
+        kv = None
+        yield [p1]
+        q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+    else:
+        p1, qkv, _ = ops.p_fwd(xq, a.w(wq), bq.data)
+        p2, kv, _ = ops.p_fwd(xkv, a.fused([wk, wv]), a.fused([bk, bv]))
+        yield [p1, p2]
+        q, k, v = qkv, kv[:, :H], kv[:, H:]
+    p_att, p_hid = rt.p(rt.p_attn), rt.p(rt.p_hidden)
+    c = ops.attn_fwd(q, k, v, mask, B, heads, Sq, Sk, p_att, rt.rng, att._sid + salt)
+    p3, h, _ = ops.p_fwd(c, a.w(outm.dense.weight), None)
+    yield [p3]
+    y, z, stats = ops.ln_fwd(h, outm.dense.bias.data, xq, outm.LayerNorm.weight.data, outm.LayerNorm.bias.data,
+                             1e-12, p_pre=p_hid, rng=rt.rng, sid_pre=outm._sid + salt)
+    return y, (att, outm, (B, Sq, Sk, heads, H, p_att, p_hid, self_att, salt), (xq, xkv, mask, qkv, kv, c, z, stats))
+
+
+def g_attn_bwd(rt, saved, dy, defer_wgrad=False):
+    """backward of g_attn_fwd -> (dxq, dxkv).  ``defer_wgrad``: issue the weight-gradient products
+    one round later (second use of SHARED weights in a lockstep pair: its read-modify-write of the
+    gradient must not share a launch with the first use's write)."""
+    att, outm, dims, tens = saved
+    B, Sq, Sk, heads, H, p_att, p_hid, self_att, salt = dims
+    xq, xkv, mask, qkv, kv, c, z, stats = tens
+    a = rt.arena
+    wq, wk, wv = att.query.weight, att.key.weight, att.value.weight
+    bq, bk, bv = att.query.bias, att.key.bias, att.value.bias
+    d_h, d_res = ops.ln_bwd(dy.contiguous(), z, stats, outm.LayerNorm.weight.data,
+                            a.atomic_target(outm.LayerNorm.weight), a.atomic_target(outm.LayerNorm.bias),
+                            a.atomic_target(outm.dense.bias), want_dres=True, p_pre=p_hid, rng=rt.rng,
+                            sid_pre=outm._sid + salt)
+    pd, d_c = ops.p_dgrad(d_h, a.w(outm.dense.weight))
+    if defer_wgrad:
+        yield [pd]
+        late = [_p_wgrad(rt, d_h, c, outm.dense.weight)]
+    else:
+        yield [_p_wgrad(rt, d_h, c, outm.dense.weight), pd]
+        late = []
+    if self_att:
+        dqkv = torch.empty_like(qkv)
+        ops.attn_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], mask, d_c, dqkv[:, :H], dqkv[:, H:2 * H],
+                     dqkv[:, 2 * H:], B, heads, Sq, Sk, p_att, rt.rng, att._sid + salt)
+        _colsum(rt, dqkv, [bq, bk, bv])
+        pdx, dxq = ops.p_dgrad(dqkv, a.fused([wq, wk, wv]), residual=d_res)
+        dxkv = None
+        if defer_wgrad:
+            yield late + [pdx]
+            yield [_p_wgrad(rt, dqkv, xq, [wq, wk, wv])]
+        else:
+            yield [_p_wgrad(rt, dqkv, xq, [wq, wk, wv]), pdx]
+    else:
+        dq = torch.empty_like(qkv)
+        dkv = torch.empty_like(kv)
+        ops.attn_bwd(qkv, kv[:, :H], kv[:, H:], mask, d_c, dq, dkv[:, :H], dkv[:, H:], B, heads, Sq, Sk, p_att, rt.rng,
+                     att._sid + salt)
+        _colsum(rt, dq, bq)
+        _colsum(rt, dkv, [bk, bv])
+        pdq, dxq = ops.p_dgrad(dq, a.w(wq), residual=d_res)
+        pdk, dxkv = ops.p_dgrad(dkv, a.fused([wk, wv]))
+        if defer_wgrad:
+            yield late + [pdq, pdk]
+            yield [_p_wgrad(rt, dq, xq, wq), _p_wgrad(rt, dkv, xkv, [wk, wv])]
+        else:
+            yield [_p_wgrad(rt, dq, xq, wq), _p_wgrad(rt, dkv, xkv, [wk, wv]), pdq, pdk]
+    return dxq, dxkv
+
+
+def g_ffn_fwd(rt, inter, outm, x):
+    """BertIntermediate + BertOutput (src/lxrt/modeling.py:428-445):
+    y = LN(dropout(W_2 gelu(W_1 x + b_1) + b_2) + x)."""
+    a = rt.arena
+    p1, act, u = ops.p_fwd(x, a.w(inter.dense.weight), inter.dense.bias.data, act=ops.ACT_GELU, want_preact=True)
+    yield [p1]
+    p2, h, _ = ops.p_fwd(act, a.w(outm.dense.weight), None)
+    yield [p2]
+    p_hid = rt.p(rt.p_hidden)
+    y, z, stats = ops.ln_fwd(h, outm.dense.bias.data, x, outm.LayerNorm.weight.data, outm.LayerNorm.bias.data, 1e-12,
+                             p_pre=p_hid, rng=rt.rng, sid_pre=outm._sid)
+    return y, (inter, outm, p_hid, (x, u, act, z, stats))
+
+
+def g_ffn_bwd(rt, saved, dy):
+    inter, outm, p_hid, (x, u, act, z, stats) = saved
+    a = rt.arena
+    d_h, d_res = ops.ln_bwd(dy.contiguous(), z, stats, outm.LayerNorm.weight.data,
+                            a.atomic_target(outm.LayerNorm.weight), a.atomic_target(outm.LayerNorm.bias),
+                            a.atomic_target(outm.dense.bias), want_dres=True, p_pre=p_hid, rng=rt.rng,
+                            sid_pre=outm._sid)
+    pd, d_u = ops.p_dgrad(d_h, a.w(outm.dense.weight), gelu_aux=u)
+    yield [_p_wgrad(rt, d_h, act, outm.dense.weight), pd]
+    _colsum(rt, d_u, inter.dense.bias)
+    pdx, dx = ops.p_dgrad(d_u, a.w(inter.dense.weight), residual=d_res)
+    yield [_p_wgrad(rt, d_u, x, inter.dense.weight), pdx]
+    return dx
+
+
+class AttnBlockFn(Function):
+    """one attention block (self or cross); see g_attn_fwd."""
 
     @staticmethod
     def forward(ctx, rt, att, outm, xq, xkv, mask, B, Sq, Sk, salt, *params):
         ctx.np = len(params)
-        a = rt.arena
-        H = xq.shape[1]
-        heads = att.num_attention_heads
-        wq, wk, wv = att.query.weight, att.key.weight, att.value.weight
-        bq, bk, bv = att.query.bias, att.key.bias, att.value.bias
-        self_att = xkv is None
-        if self_att:
-            qkv, _ = ops.linear_fwd(xq, a.fused([wq, wk, wv]), a.fused([bq, bk, bv]))
-            q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
-            kv = None
-        else:
-            qkv, _ = ops.linear_fwd(xq, a.w(wq), bq.data)
-            kv, _ = ops.linear_fwd(xkv, a.fused([wk, wv]), a.fused([bk, bv]))
-            q, k, v = qkv, kv[:, :H], kv[:, H:]
-        p_att, p_hid = rt.p(rt.p_attn), rt.p(rt.p_hidden)
-        c = ops.attn_fwd(q, k, v, mask, B, heads, Sq, Sk, p_att, rt.rng, att._sid + salt)
-        h, _ = ops.linear_fwd(c, a.w(outm.dense.weight), None)
-        y, z, stats = ops.ln_fwd(h, outm.dense.bias.data, xq, outm.LayerNorm.weight.data, outm.LayerNorm.bias.data,
-                                 1e-12, p_pre=p_hid, rng=rt.rng, sid_pre=outm._sid + salt)
-        ctx.rt, ctx.att, ctx.outm = rt, att, outm
-        ctx.dims = (B, Sq, Sk, heads, H, p_att, p_hid, self_att, salt)
-        ctx.saved = (xq, xkv, mask, qkv, kv, c, z, stats)
+        (res,) = drive(xq.dtype, [g_attn_fwd(rt, att, outm, xq, xkv, mask, B, Sq, Sk, salt)])
+        y, ctx.saved = res
+        ctx.rt = rt
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        rt, att, outm = ctx.rt, ctx.att, ctx.outm
-        B, Sq, Sk, heads, H, p_att, p_hid, self_att, salt = ctx.dims
-        xq, xkv, mask, qkv, kv, c, z, stats = ctx.saved
-        a = rt.arena
-        wq, wk, wv = att.query.weight, att.key.weight, att.value.weight
-        bq, bk, bv = att.query.bias, att.key.bias, att.value.bias
-        d_h, d_res = ops.ln_bwd(dy.contiguous(), z, stats, outm.LayerNorm.weight.data,
-                                a.atomic_target(outm.LayerNorm.weight), a.atomic_target(outm.LayerNorm.bias),
-                                a.atomic_target(outm.dense.bias), want_dres=True, p_pre=p_hid, rng=rt.rng,
-                                sid_pre=outm._sid + salt)
-        _wgrad(rt, d_h, c, outm.dense.weight)
-        d_c = ops.linear_dgrad(d_h, a.w(outm.dense.weight))
-        if self_att:
-            dqkv = torch.empty_like(qkv)
-            ops.attn_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], mask, d_c, dqkv[:, :H], dqkv[:, H:2 * H],
-                         dqkv[:, 2 * H:], B, heads, Sq, Sk, p_att, rt.rng, att._sid + salt)
-            _wgrad(rt, dqkv, xq, [wq, wk, wv])
-            _colsum(rt, dqkv, [bq, bk, bv])
-            dxq = ops.linear_dgrad(dqkv, a.fused([wq, wk, wv]), residual=d_res)
-            dxkv = None
-        else:
-            dq = torch.empty_like(qkv)
-            dkv = torch.empty_like(kv)
-            ops.attn_bwd(qkv, kv[:, :H], kv[:, H:], mask, d_c, dq, dkv[:, :H], dkv[:, H:], B, heads, Sq, Sk, p_att,
-                         rt.rng, att._sid + salt)
-            _wgrad(rt, dq, xq, wq)
-            _colsum(rt, dq, bq)
-            _wgrad(rt, dkv, xkv, [wk, wv])
-            _colsum(rt, dkv, [bk, bv])
-            dxq = ops.linear_dgrad(dq, a.w(wq), residual=d_res)
-            dxkv = ops.linear_dgrad(dkv, a.fused([wk, wv]))
+        ((dxq, dxkv),) = drive(dy.dtype, [g_attn_bwd(ctx.rt, ctx.saved, dy)])
         return (None, None, None, dxq, dxkv, None, None, None, None, None) + (None,) * ctx.np
 
 
 class FFNFn(Function):
-    """BertIntermediate + BertOutput (src/lxrt/modeling.py:428-445):
-    y = LN(dropout(W_2 gelu(W_1 x + b_1) + b_2) + x)."""
+    """one feed-forward block; see g_ffn_fwd."""
 
     @staticmethod
     def forward(ctx, rt, inter, outm, x, *params):
         ctx.np = len(params)
-        a = rt.arena
-        act, u = ops.linear_fwd(x, a.w(inter.dense.weight), inter.dense.bias.data, act=ops.ACT_GELU,
-                                want_preact=True)
-        h, _ = ops.linear_fwd(act, a.w(outm.dense.weight), None)
-        p_hid = rt.p(rt.p_hidden)
-        y, z, stats = ops.ln_fwd(h, outm.dense.bias.data, x, outm.LayerNorm.weight.data, outm.LayerNorm.bias.data,
-                                 1e-12, p_pre=p_hid, rng=rt.rng, sid_pre=outm._sid)
-        ctx.rt, ctx.inter, ctx.outm, ctx.p = rt, inter, outm, p_hid
-        ctx.saved = (x, u, act, z, stats)
+        (res,) = drive(x.dtype, [g_ffn_fwd(rt, inter, outm, x)])
+        y, ctx.saved = res
+        ctx.rt = rt
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        rt, inter, outm = ctx.rt, ctx.inter, ctx.outm
-        x, u, act, z, stats = ctx.saved
-        a = rt.arena
-        d_h, d_res = ops.ln_bwd(dy.contiguous(), z, stats, outm.LayerNorm.weight.data,
-                                a.atomic_target(outm.LayerNorm.weight), a.atomic_target(outm.LayerNorm.bias),
-                                a.atomic_target(outm.dense.bias), want_dres=True, p_pre=ctx.p, rng=rt.rng,
-                                sid_pre=outm._sid)
-        _wgrad(rt, d_h, act, outm.dense.weight)
-        d_u = ops.linear_dgrad(d_h, a.w(outm.dense.weight), gelu_aux=u)
-        _wgrad(rt, d_u, x, inter.dense.weight)
-        _colsum(rt, d_u, inter.dense.bias)
-        dx = ops.linear_dgrad(d_u, a.w(inter.dense.weight), residual=d_res)
+        (dx,) = drive(dy.dtype, [g_ffn_bwd(ctx.rt, ctx.saved, dy)])
         return (None, None, None, dx) + (None,) * ctx.np
+
+
+class PairFn(Function):
+    """two independent blocks (the same layer of the language and of the vision stream, or the two
+    directions of a cross-attention layer) advanced in lockstep so that their GEMMs share launches.
+    ``kind``: 'self' (two self-attention blocks), 'cross' (ONE shared attention module applied
+    lang<-visn and visn<-lang, src/lxrt/modeling.py:485-492) or 'ffn'."""
+
+    @staticmethod
+    def forward(ctx, rt, kind, mods, x_l, x_v, mask_l, B, T, N, *params):
+        ctx.np = len(params)
+        if kind == "self":
+            (att_l, out_l), (att_v, out_v) = mods
+            gens = [g_attn_fwd(rt, att_l, out_l, x_l, None, mask_l, B, T, T, 0),
+                    g_attn_fwd(rt, att_v, out_v, x_v, None, None, B, N, N, 0)]
+        elif kind == "cross":
+            att, outm = mods
+            gens = [g_attn_fwd(rt, att, outm, x_l, x_v, None, B, T, N, 1),
+                    g_attn_fwd(rt, att, outm, x_v, x_l, mask_l, B, N, T, 2)]
+        else:
+            (in_l, out_l), (in_v, out_v) = mods
+            gens = [g_ffn_fwd(rt, in_l, out_l, x_l), g_ffn_fwd(rt, in_v, out_v, x_v)]
+        (y_l, s_l), (y_v, s_v) = drive(x_l.dtype, gens)
+        ctx.rt, ctx.kind, ctx.saved = rt, kind, (s_l, s_v)
+        return y_l, y_v
+
+    @staticmethod
+    def backward(ctx, dy_l, dy_v):
+        rt, kind = ctx.rt, ctx.kind
+        s_l, s_v = ctx.saved
+        # a stream whose output is not used downstream (the vision side of the last cross layer
+        # in the plain-VQA pass) receives no gradient: autograd hands a None / never calls us
+        gens, who = [], []
+        if dy_l is not None:
+            gens.append(g_ffn_bwd(rt, s_l, dy_l) if kind == "ffn" else g_attn_bwd(rt, s_l, dy_l))
+            who.append("l")
+        if dy_v is not None:
+            gens.append(g_ffn_bwd(rt, s_v, dy_v) if kind == "ffn"
+                        else g_attn_bwd(rt, s_v, dy_v, defer_wgrad=(kind == "cross" and dy_l is not None)))
+            who.append("v")
+        res = dict(zip(who, drive((dy_l if dy_l is not None else dy_v).dtype, gens)))
+        dx_l = dx_v = None
+        if kind == "ffn":
+            dx_l, dx_v = res.get("l"), res.get("v")
+        elif kind == "self":
+            dx_l = res["l"][0] if "l" in res else None
+            dx_v = res["v"][0] if "v" in res else None
+        else:  # cross: lang block's dxkv is a gradient of x_v and vice versa
+            if "l" in res:
+                dx_l, dx_v = res["l"]
+            if "v" in res:
+                dv_q, dv_kv = res["v"]
+                dx_v = dv_q if dx_v is None else dx_v.add_(dv_q)
+                dx_l = dv_kv if dx_l is None else dx_l.add_(dv_kv)
+        return (None, None, None, dx_l, dx_v, None, None, None, None) + (None,) * ctx.np
 
 
 # --------------------------------------------------------------------------------- heads
@@ -242,10 +367,13 @@ class LinearActFn(Function):
             g = ops.tanh_bwd(dy, y)
         else:
             g = ops.cast_from_f32(dy, dt) if dy.dtype == F32 and dt != F32 else dy
-        _wgrad(rt, g, x2, lin.weight)
         if lin.bias is not None:
             _colsum(rt, g, lin.bias)
-        dx = ops.linear_dgrad(g, a.w(lin.weight)) if ctx.needs_input_grad[2] else None
+        probs, dx = [_p_wgrad(rt, g, x2, lin.weight)], None
+        if ctx.needs_input_grad[2]:
+            pd, dx = ops.p_dgrad(g, a.w(lin.weight))
+            probs.append(pd)
+        ops.gemm_group(dt, probs)
         if dx is not None:
             dx = dx.view(ctx.xshape)
         return (None, None, dx, None, None) + (None,) * ctx.np
@@ -274,8 +402,13 @@ class MLPFn(Function):
         a = rt.arena
         d_u, _ = ops.ln_bwd(dy.reshape(z.shape).contiguous(), z, stats, ln.weight.data, a.atomic_target(ln.weight),
                             a.atomic_target(ln.bias), a.atomic_target(lin.bias), gelu_aux=u)
-        _wgrad(rt, d_u, x2, lin.weight)
-        dx = ops.linear_dgrad(d_u, a.w(lin.weight)).view(ctx.xshape) if ctx.needs_input_grad[4] else None
+        probs, dx = [_p_wgrad(rt, d_u, x2, lin.weight)], None
+        if ctx.needs_input_grad[4]:
+            pd, dx = ops.p_dgrad(d_u, a.w(lin.weight))
+            probs.append(pd)
+        ops.gemm_group(d_u.dtype, probs)
+        if dx is not None:
+            dx = dx.view(ctx.xshape)
         return (None, None, None, None, dx) + (None,) * ctx.np
 
 
@@ -301,9 +434,11 @@ class GCNFn(Function):
         p_ro = rt.p(gcn.dropout_p)
         ret = torch.empty((B * N, H), device=x.device, dtype=x.dtype)
         reads = []
-        for k, (mlp, h) in enumerate(zip(gcn.linear_prediction, hs)):
-            act, u = ops.linear_fwd(h.view(B * N, H), a.w(mlp[0].weight), mlp[0].bias.data, act=ops.ACT_GELU,
-                                    want_preact=True)
+        pf = [ops.p_fwd(h.view(B * N, H), a.w(mlp[0].weight), mlp[0].bias.data, act=ops.ACT_GELU, want_preact=True)
+              for mlp, h in zip(gcn.linear_prediction, hs)]
+        ops.gemm_group(x.dtype, [t[0] for t in pf])  # the three read-out projections in one launch
+        for k, mlp in enumerate(gcn.linear_prediction):
+            _, act, u = pf[k]
             _, z, stats = ops.ln_fwd(act, None, None, mlp[2].weight.data, mlp[2].bias.data, 1e-5, p_post=p_ro,
                                      rng=rt.rng, sid_post=gcn._sid + k, out=ret, accumulate=k > 0)
             reads.append((u, z, stats))
@@ -318,14 +453,16 @@ class GCNFn(Function):
         a = rt.arena
         B, N, H = hs[0].shape
         d_ret = d_ret.contiguous().view(B * N, H)
-        dh = []
+        dh, probs = [], []
         for k, (mlp, h) in enumerate(zip(gcn.linear_prediction, hs)):
             u, z, stats = reads[k]
             d_u, _ = ops.ln_bwd(d_ret, z, stats, mlp[2].weight.data, a.atomic_target(mlp[2].weight),
                                 a.atomic_target(mlp[2].bias), a.atomic_target(mlp[0].bias), p_post=ctx.p, rng=rt.rng,
                                 sid_post=gcn._sid + k, gelu_aux=u)
-            _wgrad(rt, d_u, h.view(B * N, H), mlp[0].weight)
-            dh.append(ops.linear_dgrad(d_u, a.w(mlp[0].weight)))
+            pd, dhk = ops.p_dgrad(d_u, a.w(mlp[0].weight))
+            probs += [_p_wgrad(rt, d_u, h.view(B * N, H), mlp[0].weight), pd]
+            dh.append(dhk)
+        ops.gemm_group(d_ret.dtype, probs)  # wgrad + dgrad of the three read-outs: two launches
         d_adj = None
         for k in reversed(range(len(gcn.gnn_layers))):
             conv = gcn.gnn_layers[k]
@@ -334,8 +471,9 @@ class GCNFn(Function):
             d_t, _ = ops.ln_bwd(dh[k + 1], z, stats, conv.layer_norm.weight.data,
                                 a.atomic_target(conv.layer_norm.weight), a.atomic_target(conv.layer_norm.bias), None,
                                 d_res=dh[k])
-            _wgrad(rt, d_t, agg.view(B * N, H), conv.ctx_layer.weight)
-            d_agg = ops.linear_dgrad(d_t, a.w(conv.ctx_layer.weight)).view(B, N, H)
+            pd, d_agg = ops.p_dgrad(d_t, a.w(conv.ctx_layer.weight))
+            ops.gemm_group(d_t.dtype, [_p_wgrad(rt, d_t, agg.view(B * N, H), conv.ctx_layer.weight), pd])
+            d_agg = d_agg.view(B, N, H)
             ops.aggregate(adj, d_agg, mode=ops.AGG_TRANSPOSE, out=dh[k].view(B, N, H))
             if ctx.needs_input_grad[3]:
                 g = ops.bmm_nt(d_agg, hs[k])

@@ -221,6 +221,28 @@ def _ffn_block(inter, outm, x):
     return y.view(shape)
 
 
+def _pair(kind, mods, lang, visn, lang_mask, params):
+    """run the language and the vision side of one layer in lockstep (functional.PairFn)."""
+    rt = runtime_of(mods[0] if kind == "cross" else mods[0][0])
+    B, T, H = lang.shape
+    N = visn.shape[1]
+    y_l, y_v = XF.PairFn.apply(rt, kind, mods, _2d(lang), _2d(visn), _mask2d(lang_mask, B, T), B, T, N, *params)
+    return y_l.view(B, T, H), y_v.view(B, N, H)
+
+
+def bert_layer_pair(layer_l, layer_v, lang, lang_mask, visn, visn_mask):
+    """BertLayer on the language stream and BertLayer on the vision stream, independent of each
+    other (src/lxrt/modeling.py:593-598), executed together so their GEMMs share launches."""
+    if visn_mask is not None:  # not used by any trainer; keep the plain path for it
+        return layer_l(lang, lang_mask), layer_v(visn, visn_mask)
+    al, av = layer_l.attention, layer_v.attention
+    lang, visn = _pair("self", ((al.self, al.output), (av.self, av.output)), lang, visn, lang_mask,
+                       [*al.parameters(), *av.parameters()])
+    return _pair("ffn", ((layer_l.intermediate, layer_l.output), (layer_v.intermediate, layer_v.output)), lang, visn,
+                 None, [*layer_l.intermediate.parameters(), *layer_l.output.parameters(),
+                        *layer_v.intermediate.parameters(), *layer_v.output.parameters()])
+
+
 class BertLayer(nn.Module):
     """ref: src/lxrt/modeling.py:448-459"""
 
@@ -262,11 +284,21 @@ class LXRTXLayer(nn.Module):
                 _ffn_block(self.visn_inter, self.visn_output, visn_input))
 
     def forward(self, lang_feats, lang_attention_mask, visn_feats, visn_attention_mask):
-        lang_att_output, visn_att_output = self.cross_att(lang_feats, lang_attention_mask, visn_feats,
-                                                          visn_attention_mask)
-        lang_att_output, visn_att_output = self.self_att(lang_att_output, lang_attention_mask, visn_att_output,
-                                                         visn_attention_mask)
-        return self.output_fc(lang_att_output, visn_att_output)
+        if visn_attention_mask is not None:  # unused by the trainers: unpaired path
+            lang_att_output, visn_att_output = self.cross_att(lang_feats, lang_attention_mask, visn_feats,
+                                                              visn_attention_mask)
+            lang_att_output, visn_att_output = self.self_att(lang_att_output, lang_attention_mask, visn_att_output,
+                                                             visn_attention_mask)
+            return self.output_fc(lang_att_output, visn_att_output)
+        va = self.visual_attention
+        lang, visn = _pair("cross", (va.att, va.output), lang_feats, visn_feats, lang_attention_mask,
+                           list(va.parameters()))
+        ls, vs = self.lang_self_att, self.visn_self_att
+        lang, visn = _pair("self", ((ls.self, ls.output), (vs.self, vs.output)), lang, visn, lang_attention_mask,
+                           [*ls.parameters(), *vs.parameters()])
+        return _pair("ffn", ((self.lang_inter, self.lang_output), (self.visn_inter, self.visn_output)), lang, visn,
+                     None, [*self.lang_inter.parameters(), *self.lang_output.parameters(),
+                            *self.visn_inter.parameters(), *self.visn_output.parameters()])
 
 
 class VisualFeatEncoder(nn.Module):
@@ -314,9 +346,15 @@ class LXRTEncoder(nn.Module):
 
     def forward(self, lang_feats, lang_attention_mask, visn_feats, visn_attention_mask=None):
         visn_feats = self.visn_fc(visn_feats)
-        for layer_module in self.layer:
+        # language layers and relational (vision) layers are independent chains: the first
+        # min(l, r) layers of both run pairwise in lockstep, the rest alone
+        n_pair = min(self.num_l_layers, self.num_r_layers)
+        for i in range(n_pair):
+            lang_feats, visn_feats = bert_layer_pair(self.layer[i], self.r_layers[i], lang_feats,
+                                                     lang_attention_mask, visn_feats, visn_attention_mask)
+        for layer_module in self.layer[n_pair:]:
             lang_feats = layer_module(lang_feats, lang_attention_mask)
-        for layer_module in self.r_layers:
+        for layer_module in self.r_layers[n_pair:]:
             visn_feats = layer_module(visn_feats, visn_attention_mask)
         for layer_module in self.x_layers:
             lang_feats, visn_feats = layer_module(lang_feats, lang_attention_mask, visn_feats, visn_attention_mask)
