@@ -291,6 +291,7 @@ class PairFn(Function):
     @staticmethod
     def forward(ctx, rt, kind, mods, x_l, x_v, mask_l, B, T, N, *params):
         ctx.np = len(params)
+        ctx.set_materialize_grads(False)  # an unused output must arrive as None, not as zeros
         if kind == "self":
             (att_l, out_l), (att_v, out_v) = mods
             gens = [g_attn_fwd(rt, att_l, out_l, x_l, None, mask_l, B, T, T, 0),
