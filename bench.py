@@ -75,18 +75,25 @@ def kernel_timing(trainer, branches):
     on the launch stream; a long sleep kernel is queued first so the host runs ahead and the
     events bracket back-to-back GPU execution, not Python latency."""
     from xggm_amd import _lib
+    import xggm_amd.ops as ops_mod
     rec = []
     orig = _lib.call
 
     def timed(name, *a):
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
+        work = 0.0
+        if name.startswith("xggm_gemm_grouped_"):
+            probs = (ops_mod.GemmProblem * a[1]).from_address(a[0].value)
+            work = sum(2.0 * p.M * p.N * p.K * p.batch for p in probs)
+            name = "xggm_gemm_" + name.rsplit("_", 1)[1]  # same kernel family as the single launches
+        elif name.startswith("xggm_gemm_"):
+            work = 2.0 * a[3] * a[4] * a[5] * a[11]
         e0.record()
-        orig(name, *a)
+        orig(name if not name.startswith("xggm_gemm_") or len(a) > 3 else "xggm_gemm_grouped_" + name.rsplit("_", 1)[1], *a)
         e1.record()
-        rec.append((name, a, e0, e1))
+        rec.append((name, a, e0, e1, work))
 
-    import xggm_amd.ops as ops_mod
     for kind in ["plain"] + list(branches):
         torch.cuda.synchronize()
         torch.cuda._sleep(int(5e7))  # head start for the host: launches queue up behind it
@@ -97,14 +104,13 @@ def kernel_timing(trainer, branches):
             ops_mod.call = orig
         torch.cuda.synchronize()
     fam = {}
-    for name, a, e0, e1 in rec:
+    for name, a, e0, e1, work in rec:
         ms = e0.elapsed_time(e1)
         f = fam.setdefault(name, dict(ms=0.0, n=0, flops=0.0, bytes=0.0))
         f["ms"] += ms
         f["n"] += 1
         if name.startswith("xggm_gemm_"):
-            M, N, K, batch = a[3], a[4], a[5], a[11]
-            f["flops"] += 2.0 * M * N * K * batch
+            f["flops"] += work
         elif name == "xggm_bertadam_f32":
             f["bytes"] += a[5] * (16 + 12 + (2 if a[4] else 0))
         elif name == "xggm_sqnorm_f32":
