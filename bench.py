@@ -92,7 +92,13 @@ def kernel_timing(trainer, branches):
         e0.record()
         orig(name if not name.startswith("xggm_gemm_") or len(a) > 3 else "xggm_gemm_grouped_" + name.rsplit("_", 1)[1], *a)
         e1.record()
-        rec.append((name, a, e0, e1, work))
+        desc = ""
+        if os.environ.get("XGGM_DUMP_GEMMS") and name.startswith("xggm_gemm_"):
+            if len(a) == 3:
+                desc = " + ".join("%dx%dx%d%s" % (p.M, p.N, p.K, "f" if p.c_f32 else "") for p in probs)
+            else:
+                desc = "%dx%dx%d" % (a[3], a[4], a[5])
+        rec.append((name, a, e0, e1, work, desc))
 
     for kind in ["plain"] + list(branches):
         torch.cuda.synchronize()
@@ -104,7 +110,15 @@ def kernel_timing(trainer, branches):
             ops_mod.call = orig
         torch.cuda.synchronize()
     fam = {}
-    for name, a, e0, e1, work in rec:
+    if os.environ.get("XGGM_DUMP_GEMMS"):
+        agg = {}
+        for name, a, e0, e1, work, desc in rec:
+            if desc:
+                t = agg.setdefault(desc, [0.0, 0, 0.0])
+                t[0] += e0.elapsed_time(e1); t[1] += 1; t[2] += work
+        for desc, (ms, n, w) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:40]:
+            log("gemm %-60s n=%3d total %.3f ms avg %.1f us %.0f TF" % (desc, n, ms, 1000 * ms / n, w / ms / 1e9))
+    for name, a, e0, e1, work, desc in rec:
         ms = e0.elapsed_time(e1)
         f = fam.setdefault(name, dict(ms=0.0, n=0, flops=0.0, bytes=0.0))
         f["ms"] += ms

@@ -56,18 +56,19 @@ const char* xggm_last_error(void);
  *   A(z,m,k) = A[z*a_bs + m*a_rs + k*a_ks],  B(z,k,n) = B[z*b_bs + n*b_ns + k*b_ks],
  *   C at C[z*c_bs + m*ldc + n].
  * epilogue: v = alpha*acc + bias[n]; preact (if given) <- v; v = act(v) (GELU_GRAD: v *
- * gelu'(aux)); v += residual; C = accumulate ? C + v : v; C is T, or float when c_f32.
+ * gelu'(aux)); v += residual; colsum[n] += sum_m v (if given: bias gradients, fp32 atomics);
+ * C = accumulate ? C + v : v; C is T, or float when c_f32.
  * Replaces nn.Linear forward/backward (src/lxrt/modeling.py:345-347, 385, 429, 442, 617;
  * src/module/gcn.py:28; src/vqa/vqacpv2_model.py:63-105) and torch.bmm(x, x^T)
  * (src/module/graph_generative_modeling.py:225). */
 int xggm_gemm_f32(const void* A, const void* B, void* C, int M, int N, int K, int64_t a_rs, int64_t a_ks, int64_t b_ns,
                   int64_t b_ks, int64_t ldc, int batch, int64_t a_bs, int64_t b_bs, int64_t c_bs, const float* bias,
-                  const void* residual, void* preact, const void* aux, int act, int c_f32, int accumulate, float alpha,
-                  xggm_stream_t stream);
+                  const void* residual, void* preact, const void* aux, float* colsum, int act, int c_f32, int accumulate,
+                  float alpha, xggm_stream_t stream);
 int xggm_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, int64_t a_rs, int64_t a_ks, int64_t b_ns,
                    int64_t b_ks, int64_t ldc, int batch, int64_t a_bs, int64_t b_bs, int64_t c_bs, const float* bias,
-                   const void* residual, void* preact, const void* aux, int act, int c_f32, int accumulate, float alpha,
-                   xggm_stream_t stream);
+                   const void* residual, void* preact, const void* aux, float* colsum, int act, int c_f32, int accumulate,
+                   float alpha, xggm_stream_t stream);
 /* Up to 4 independent products in ONE launch (forward of both modalities, dgrad + wgrad of a layer):
  * skinny problems that cannot fill 256 CUs alone share a grid.  `probs` is a HOST array; fields as
  * the arguments of xggm_gemm_*.  Falls back to one launch per problem for shapes the tuned kernel
@@ -84,6 +85,7 @@ typedef struct xggm_gemm_problem {
     const void* residual;
     void* preact;
     const void* aux;
+    float* colsum;
     int act, c_f32, accumulate;
     float alpha;
 } xggm_gemm_problem;
@@ -107,7 +109,9 @@ size_t xggm_colsum_workspace_bytes(int M, int N);
 /* ---- attention core: src/lxrt/modeling.py:355-373 (BertAttention.forward after the
  * projections).  q/k/v/out rows of sample b start at row b*S of a matrix with the given row
  * stride (so fused-QKV buffers are addressed in place); head h occupies columns
- * [64h, 64h+64).  mask: additive [B,Sk] fp32 or NULL.  Sq, Sk <= 64, head_dim == 64. */
+ * [64h, 64h+64).  mask: additive [B,Sk] fp32 or NULL.  Sq, Sk <= 64, head_dim == 64.
+ * backward: dbq/dbk/dbv (fp32 [heads*64], NULL ok) += column sums of dq/dk/dv = the gradients
+ * of the query/key/value biases (fp32 atomics, one per column per workgroup). */
 int xggm_attn_fwd_f32(const void* q, const void* k, const void* v, const float* mask, void* out, int B, int heads, int Sq,
                       int Sk, int head_dim, int64_t q_rs, int64_t k_rs, int64_t v_rs, int64_t o_rs, float scale, float p,
                       const uint64_t* rng, uint32_t sid, xggm_stream_t stream);
@@ -117,11 +121,11 @@ int xggm_attn_fwd_bf16(const void* q, const void* k, const void* v, const float*
 int xggm_attn_bwd_f32(const void* q, const void* k, const void* v, const float* mask, const void* d_out, void* dq, void* dk,
                       void* dv, int B, int heads, int Sq, int Sk, int head_dim, int64_t q_rs, int64_t k_rs, int64_t v_rs,
                       int64_t o_rs, int64_t dq_rs, int64_t dk_rs, int64_t dv_rs, float scale, float p, const uint64_t* rng,
-                      uint32_t sid, xggm_stream_t stream);
+                      uint32_t sid, float* dbq, float* dbk, float* dbv, xggm_stream_t stream);
 int xggm_attn_bwd_bf16(const void* q, const void* k, const void* v, const float* mask, const void* d_out, void* dq,
                        void* dk, void* dv, int B, int heads, int Sq, int Sk, int head_dim, int64_t q_rs, int64_t k_rs,
                        int64_t v_rs, int64_t o_rs, int64_t dq_rs, int64_t dk_rs, int64_t dv_rs, float scale, float p,
-                       const uint64_t* rng, uint32_t sid, xggm_stream_t stream);
+                       const uint64_t* rng, uint32_t sid, float* dbq, float* dbk, float* dbv, xggm_stream_t stream);
 
 /* ---- row kernels -----------------------------------------------------------------------
  * out = [out +] out_scale * drop_post( LN( drop_pre(in + bias) + residual ; gamma, beta, eps) )

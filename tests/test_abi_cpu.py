@@ -36,7 +36,8 @@ def test_argument_validation_fails_before_launch():
     from xggm_amd import _lib
     L = _lib.lib
     # empty GEMM, null pointers: rejected on the host, nothing is enqueued
-    rc = L.xggm_gemm_f32(None, None, None, 0, 4, 4, 4, 1, 4, 1, 4, 1, 0, 0, 0, None, None, None, None, 0, 0, 0, 1.0, None)
+    rc = L.xggm_gemm_f32(None, None, None, 0, 4, 4, 4, 1, 4, 1, 4, 1, 0, 0, 0, None, None, None, None, None, 0, 0, 0, 1.0,
+                         None)
     assert rc != 0 and b"xggm_gemm" in L.xggm_last_error()
     assert L.xggm_ln_bwd_workspace_bytes(1152, 768) == 4 * 128 * 3 * 768
     rc = L.xggm_ln_fwd_bf16(None, None, None, None, None, None, None, None, 4, 6, 1e-5, 0.0, 0.0, None, 0, 0, 0, 1.0, None)

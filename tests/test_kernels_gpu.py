@@ -65,6 +65,12 @@ def test_linear_fwd_dgrad_wgrad(ops, dt, M, N, K):
     cdf = 0.5 * (1 + torch.erf(ur / math.sqrt(2)))
     pdf = torch.exp(-0.5 * ur * ur) / math.sqrt(2 * math.pi)
     assert rel_err(dxg, (dyr @ wr) * (cdf + ur * pdf)) < tol(dt)
+    # ... and with the column sums (bias gradient) taken in the same epilogue
+    cs = torch.full((K,), 2.0, device=DEV)
+    pcs, dxc = ops.p_dgrad(dy, w, gelu_aux=u, colsum=cs)
+    ops.gemm_group(dt, [pcs])
+    assert rel_err(dxc, (dyr @ wr) * (cdf + ur * pdf)) < tol(dt)
+    assert rel_err(cs, 2.0 + ((dyr @ wr) * (cdf + ur * pdf)).sum(0)) < tol(dt, 1e-4, 2e-3)
     # wgrad (fp32 out), overwrite then accumulate
     gw = torch.full((N, K), 7.0, device=DEV)
     ops.linear_wgrad(dy, x, gw, accumulate=False)
@@ -166,7 +172,13 @@ def test_attention(ops, dt, Sq, Sk, masked):
     (ref(qa, ka, va) * dor).sum().backward()
     dq = torch.empty((B * Sq, H), device=DEV, dtype=dt)
     dkv = torch.empty((B * Sk, 2 * H), device=DEV, dtype=dt)
-    ops.attn_bwd(q, k, v, mask, do, dq, dkv[:, :H], dkv[:, H:], B, heads, Sq, Sk, 0.0, None, 0)
+    gb = torch.zeros(3 * H, device=DEV)
+    ops.attn_bwd(q, k, v, mask, do, dq, dkv[:, :H], dkv[:, H:], B, heads, Sq, Sk, 0.0, None, 0, gb[:H], gb[H:2 * H],
+                 gb[2 * H:])
+    assert rel_err(gb[:H], qa.grad.sum(0)) < tol(dt, 1e-4, 2e-3)   # fused bias gradients
+    # the key bias cannot change a softmax: its gradient is zero up to rounding
+    assert float((gb[H:2 * H].double().cpu() - ka.grad.sum(0)).abs().max()) < 1e-3 * float(qa.grad.abs().max()) * Sq
+    assert rel_err(gb[2 * H:], va.grad.sum(0)) < tol(dt, 1e-4, 2e-3)
     assert rel_err(dq, qa.grad) < tol(dt, 5e-5)
     assert rel_err(dkv[:, :H], ka.grad) < tol(dt, 5e-5)
     assert rel_err(dkv[:, H:], va.grad) < tol(dt, 5e-5)

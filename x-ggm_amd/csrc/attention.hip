@@ -117,7 +117,9 @@ template <typename T> __global__ __launch_bounds__(NT) void attn_fwd_kernel(Attn
 
 template <typename T>
 __global__ __launch_bounds__(NT) void attn_bwd_kernel(AttnArgs a, const T* d_out, T* dq, T* dk, T* dv, int64_t dq_rs,
-                                                      int64_t dk_rs, int64_t dv_rs) {
+                                                      int64_t dk_rs, int64_t dv_rs, float* dbq, float* dbk, float* dbv) {
+    __shared__ float csum[3][D];  // column sums of dQ / dK / dV over this sample's rows (bias gradients)
+    if (threadIdx.x < 3 * D) (&csum[0][0])[threadIdx.x] = 0.f;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
@@ -167,6 +169,10 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(AttnArgs a, const T* d_out
             o[3] += s * kk.w;
         }
         store4(dq + ((int64_t)b * Sq + i) * dq_rs + h * D + c, o);
+        if (dbq) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(&csum[0][c + e], o[e]);
+        }
     }
     // dK[j][c] = sum_i dS[i][j] Q[i][c];  dV[j][c] = sum_i P[i][j] D[i][j] dO[i][c]
     for (int w = tid; w < Sk * 16; w += NT) {
@@ -189,6 +195,21 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(AttnArgs a, const T* d_out
         }
         store4(dk + ((int64_t)b * Sk + j) * dk_rs + h * D + c, ok);
         store4(dv + ((int64_t)b * Sk + j) * dv_rs + h * D + c, ov);
+        if (dbk) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                atomicAdd(&csum[1][c + e], ok[e]);
+                atomicAdd(&csum[2][c + e], ov[e]);
+            }
+        }
+    }
+    if (dbq || dbk) {
+        // one fp32 atomic per column per (sample, head) workgroup: <= B adders per address
+        __syncthreads();
+        const int t = threadIdx.x;
+        if (t < D && dbq) atomicAdd(dbq + h * D + t, csum[0][t]);
+        else if (t >= D && t < 2 * D && dbk) atomicAdd(dbk + h * D + (t - D), csum[1][t - D]);
+        else if (t >= 2 * D && t < 3 * D && dbv) atomicAdd(dbv + h * D + (t - 2 * D), csum[2][t - 2 * D]);
     }
 }
 
@@ -220,14 +241,15 @@ template <typename T>
 int attn_bwd(const void* q, const void* k, const void* v, const float* mask, const void* d_out, void* dq, void* dk, void* dv,
              int B, int heads, int Sq, int Sk, int head_dim, int64_t q_rs, int64_t k_rs, int64_t v_rs, int64_t o_rs,
              int64_t dq_rs, int64_t dk_rs, int64_t dv_rs, float scale, float p, const uint64_t* rng, uint32_t sid,
-             hipStream_t st) {
+             float* dbq, float* dbk, float* dbv, hipStream_t st) {
     AttnArgs a{q, k, v, mask, q_rs, k_rs, v_rs, o_rs, B, heads, Sq, Sk, scale, p, rng, sid};
     if (int e = check("xggm_attn_bwd", a, head_dim)) return e;
     XGGM_REQUIRE(d_out && dq && dk && dv, "xggm_attn_bwd: null pointer");
     XGGM_REQUIRE(dq_rs % 4 == 0 && dk_rs % 4 == 0 && dv_rs % 4 == 0, "xggm_attn_bwd: row strides must be multiples of 4");
+    XGGM_REQUIRE((dbk == nullptr) == (dbv == nullptr), "xggm_attn_bwd: dbk and dbv go together");
     const size_t lds = sizeof(float) * ((size_t)(2 * Sq + 2 * Sk) * LD + 3 * (size_t)Sq * (Sk + 1));
     hipLaunchKernelGGL((attn_bwd_kernel<T>), dim3(B * heads), dim3(NT), lds, st, a, (const T*)d_out, (T*)dq, (T*)dk, (T*)dv,
-                       dq_rs, dk_rs, dv_rs);
+                       dq_rs, dk_rs, dv_rs, dbq, dbk, dbv);
     return xggm_check_launch("xggm_attn_bwd");
 }
 
@@ -244,9 +266,9 @@ int attn_bwd(const void* q, const void* k, const void* v, const float* mask, con
                                        void* dq, void* dk, void* dv, int B, int heads, int Sq, int Sk, int head_dim,      \
                                        int64_t q_rs, int64_t k_rs, int64_t v_rs, int64_t o_rs, int64_t dq_rs,             \
                                        int64_t dk_rs, int64_t dv_rs, float scale, float p, const uint64_t* rng,           \
-                                       uint32_t sid, hipStream_t st) {                                                    \
+                                       uint32_t sid, float* dbq, float* dbk, float* dbv, hipStream_t st) {                \
         return attn_bwd<T>(q, k, v, mask, d_out, dq, dk, dv, B, heads, Sq, Sk, head_dim, q_rs, k_rs, v_rs, o_rs, dq_rs,    \
-                           dk_rs, dv_rs, scale, p, rng, sid, st);                                                          \
+                           dk_rs, dv_rs, scale, p, rng, sid, dbq, dbk, dbv, st);                                           \
     }
 
 ATTN_API(f32, float)

@@ -72,12 +72,25 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---------------------------------------------------------------- math
+// erf by Abramowitz & Stegun 7.1.26 (|abs error| <= 1.5e-7), branch-free: one rcp, one exp and a
+// degree-5 Horner chain instead of libm's range-split erff.  Inside GELU the error is 7.5e-8*|x|,
+// far below both the fp32 parity tolerance and bf16 rounding.
+__device__ __forceinline__ float erf_fast(float x) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float r = 1.0f - p * t * __expf(-ax * ax);
+    return copysignf(r, x);
+}
 __device__ __forceinline__ float gelu_f(float x) {
-    return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    return x * 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f));
 }
 __device__ __forceinline__ float gelu_grad_f(float x) {
     // d/dx [x Phi(x)] = Phi(x) + x phi(x)
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f));
     const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
     return cdf + x * pdf;
 }

@@ -32,6 +32,7 @@ struct GemmArgs {
     const void* residual;  // T, layout of C (same ldc / batch stride), or null
     void* preact;          // T, layout of C, or null: alpha*acc + bias before the activation
     const void* aux;       // T, layout of C: pre-activation u for act == GELU_GRAD
+    float* colsum;         // [N] or null: += column sums of the stored result (bias gradients)
     int act;
     int c_f32;         // store C as float regardless of T
     int accumulate;    // C += result
@@ -115,6 +116,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& g, const float4_t&
     if (col >= g.N) return;
     const int64_t coff = (int64_t)bz * g.c_bs;
     const float bias = g.bias ? g.bias[col] : 0.0f;
+    float csum = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = row0 + r;
@@ -137,7 +139,9 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& g, const float4_t&
             T* c = reinterpret_cast<T*>(g.C) + idx;
             *c = from_f32<T>(g.accumulate ? (to_f32(*c) + v) : v);
         }
+        csum += v;
     }
+    if (g.colsum) atomicAdd(g.colsum + col, csum);
 }
 
 template <typename T> __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
@@ -356,13 +360,25 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, const float4_
 #pragma unroll
                         for (int e = 0; e < 8; ++e) ax[e] = __bfloat162float(__builtin_bit_cast(bf16, (short)av[e]));
                     }
+                    if (g.act == XGGM_ACT_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+                    } else if (g.act == XGGM_ACT_GELU_GRAD) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(ax[e]);
+                    } else {
 #pragma unroll 1
-                    for (int e = 0; e < 8; ++e) v[e] = act_apply<bf16>(g.act, v[e], ax[e]);
+                        for (int e = 0; e < 8; ++e) v[e] = act_apply<bf16>(g.act, v[e], ax[e]);
+                    }
                 }
                 if (res) {
                     const short8_t rv = *reinterpret_cast<const short8_t*>(res + idx);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += __bfloat162float(__builtin_bit_cast(bf16, (short)rv[e]));
+                }
+                if (g.colsum) {  // park the final values for the column pass below
+                    *reinterpret_cast<float4*>(stage + lr * LDS_LD + lc) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(stage + lr * LDS_LD + lc + 4) = make_float4(v[4], v[5], v[6], v[7]);
                 }
                 if (g.c_f32) {
                     float* c = reinterpret_cast<float*>(g.C) + idx;
@@ -397,6 +413,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, const float4_
                     if (g.act != XGGM_ACT_NONE)
                         x = act_apply<bf16>(g.act, x, g.act == XGGM_ACT_GELU_GRAD ? __bfloat162float(aux[idx + e]) : 0.f);
                     if (res) x += __bfloat162float(res[idx + e]);
+                    if (g.colsum) stage[lr * LDS_LD + lc + e] = x;
                     if (g.c_f32) {
                         float* c = reinterpret_cast<float*>(g.C) + idx + e;
                         *c = g.accumulate ? (*c + x) : x;
@@ -408,6 +425,16 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, const float4_
             }
         }
         __syncthreads();
+        if (g.colsum) {
+            // bias gradient: column sums of this half tile's stored values, one atomic per column
+            const int rows = min(HALF, g.M - (m0 + h * HALF));
+            if (tid < BN && n0 + tid < g.N && rows > 0) {
+                float sacc = 0.f;
+                for (int r = 0; r < rows; ++r) sacc += stage[r * LDS_LD + tid];
+                atomicAdd(g.colsum + n0 + tid, sacc);
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -636,13 +663,13 @@ template <typename T> int launch(GemmArgs g, int batch, hipStream_t stream) {
 #define XGGM_GEMM_IMPL(NAME, T)                                                                                        \
     extern "C" int NAME(const void* A, const void* B, void* C, int M, int N, int K, int64_t a_rs, int64_t a_ks,       \
                         int64_t b_ns, int64_t b_ks, int64_t ldc, int batch, int64_t a_bs, int64_t b_bs, int64_t c_bs, \
-                        const float* bias, const void* residual, void* preact, const void* aux, int act, int c_f32,   \
-                        int accumulate, float alpha, hipStream_t stream) {                                            \
+                        const float* bias, const void* residual, void* preact, const void* aux, float* colsum,       \
+                        int act, int c_f32, int accumulate, float alpha, hipStream_t stream) {                        \
         GemmArgs g;                                                                                                    \
         g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K;                                                          \
         g.a_rs = a_rs; g.a_ks = a_ks; g.b_ns = b_ns; g.b_ks = b_ks; g.ldc = ldc;                                       \
         g.a_bs = a_bs; g.b_bs = b_bs; g.c_bs = c_bs;                                                                   \
-        g.bias = bias; g.residual = residual; g.preact = preact; g.aux = aux;                                         \
+        g.bias = bias; g.residual = residual; g.preact = preact; g.aux = aux; g.colsum = colsum;                      \
         g.act = act; g.c_f32 = c_f32; g.accumulate = accumulate; g.alpha = alpha;                                     \
         g.a_mode = g.b_mode = 0; g.xcd_swizzle = g_xcd_swizzle; g.batch = batch;                                       \
         return launch<T>(g, batch, stream);                                                                            \
@@ -670,7 +697,7 @@ GemmArgs from_problem(const xggm_gemm_problem& p) {
     g.A = p.A; g.B = p.B; g.C = p.C; g.M = p.M; g.N = p.N; g.K = p.K;
     g.a_rs = p.a_rs; g.a_ks = p.a_ks; g.b_ns = p.b_ns; g.b_ks = p.b_ks; g.ldc = p.ldc;
     g.a_bs = p.a_bs; g.b_bs = p.b_bs; g.c_bs = p.c_bs;
-    g.bias = p.bias; g.residual = p.residual; g.preact = p.preact; g.aux = p.aux;
+    g.bias = p.bias; g.residual = p.residual; g.preact = p.preact; g.aux = p.aux; g.colsum = p.colsum;
     g.act = p.act; g.c_f32 = p.c_f32; g.accumulate = p.accumulate; g.alpha = p.alpha;
     g.a_mode = g.b_mode = 0; g.xcd_swizzle = g_xcd_swizzle; g.batch = p.batch;
     return g;

@@ -192,9 +192,9 @@ def g_attn_bwd(rt, saved, dy, defer_wgrad=False):
         late = []
     if self_att:
         dqkv = torch.empty_like(qkv)
+        gb = a.atomic_target([bq, bk, bv])  # q/k/v bias gradients come out of the attention backward
         ops.attn_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], mask, d_c, dqkv[:, :H], dqkv[:, H:2 * H],
-                     dqkv[:, 2 * H:], B, heads, Sq, Sk, p_att, rt.rng, att._sid + salt)
-        _colsum(rt, dqkv, [bq, bk, bv])
+                     dqkv[:, 2 * H:], B, heads, Sq, Sk, p_att, rt.rng, att._sid + salt, gb[:H], gb[H:2 * H], gb[2 * H:])
         pdx, dxq = ops.p_dgrad(dqkv, a.fused([wq, wk, wv]), residual=d_res)
         dxkv = None
         if defer_wgrad:
@@ -205,10 +205,9 @@ def g_attn_bwd(rt, saved, dy, defer_wgrad=False):
     else:
         dq = torch.empty_like(qkv)
         dkv = torch.empty_like(kv)
+        gbq, gbkv = a.atomic_target(bq), a.atomic_target([bk, bv])
         ops.attn_bwd(qkv, kv[:, :H], kv[:, H:], mask, d_c, dq, dkv[:, :H], dkv[:, H:], B, heads, Sq, Sk, p_att, rt.rng,
-                     att._sid + salt)
-        _colsum(rt, dq, bq)
-        _colsum(rt, dkv, [bk, bv])
+                     att._sid + salt, gbq, gbkv[:H], gbkv[H:])
         pdq, dxq = ops.p_dgrad(dq, a.w(wq), residual=d_res)
         pdk, dxkv = ops.p_dgrad(dkv, a.fused([wk, wv]))
         if defer_wgrad:
@@ -240,9 +239,9 @@ def g_ffn_bwd(rt, saved, dy):
                             a.atomic_target(outm.LayerNorm.weight), a.atomic_target(outm.LayerNorm.bias),
                             a.atomic_target(outm.dense.bias), want_dres=True, p_pre=p_hid, rng=rt.rng,
                             sid_pre=outm._sid)
-    pd, d_u = ops.p_dgrad(d_h, a.w(outm.dense.weight), gelu_aux=u)
+    # d_u = (d_h W_2) * gelu'(u); its column sums (= grad of b_1) are taken in the same epilogue
+    pd, d_u = ops.p_dgrad(d_h, a.w(outm.dense.weight), gelu_aux=u, colsum=a.atomic_target(inter.dense.bias))
     yield [_p_wgrad(rt, d_h, act, outm.dense.weight), pd]
-    _colsum(rt, d_u, inter.dense.bias)
     pdx, dx = ops.p_dgrad(d_u, a.w(inter.dense.weight), residual=d_res)
     yield [_p_wgrad(rt, d_u, x, inter.dense.weight), pdx]
     return dx

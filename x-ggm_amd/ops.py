@@ -40,9 +40,9 @@ def _c(t, dt=None, name="tensor"):
 # ----------------------------------------------------------------------------- GEMM
 def gemm_raw(dt, A, B, C, M, N, K, a_rs, a_ks, b_ns, b_ks, ldc, batch=1, a_bs=0, b_bs=0, c_bs=0,
              bias=None, residual=None, preact=None, aux=None, act=ACT_NONE, c_f32=False,
-             accumulate=False, alpha=1.0):
+             accumulate=False, alpha=1.0, colsum=None):
     call("xggm_gemm_" + sfx(dt), ptr(A), ptr(B), ptr(C), M, N, K, a_rs, a_ks, b_ns, b_ks, ldc, batch,
-         a_bs, b_bs, c_bs, ptr(bias), ptr(residual), ptr(preact), ptr(aux), act, int(c_f32),
+         a_bs, b_bs, c_bs, ptr(bias), ptr(residual), ptr(preact), ptr(aux), ptr(colsum), act, int(c_f32),
          int(accumulate), float(alpha), stream())
 
 
@@ -118,13 +118,13 @@ class GemmProblem(_ct.Structure):
                 ("ldc", _ct.c_int64), ("batch", _ct.c_int),
                 ("a_bs", _ct.c_int64), ("b_bs", _ct.c_int64), ("c_bs", _ct.c_int64),
                 ("bias", _ct.c_void_p), ("residual", _ct.c_void_p), ("preact", _ct.c_void_p), ("aux", _ct.c_void_p),
-                ("act", _ct.c_int), ("c_f32", _ct.c_int), ("accumulate", _ct.c_int), ("alpha", _ct.c_float)]
+                ("colsum", _ct.c_void_p), ("act", _ct.c_int), ("c_f32", _ct.c_int), ("accumulate", _ct.c_int), ("alpha", _ct.c_float)]
 
 
 def _problem(A, B, C, M, N, K, a_rs, a_ks, b_ns, b_ks, ldc, bias=None, residual=None, preact=None, aux=None,
-             act=ACT_NONE, c_f32=False, accumulate=False):
+             act=ACT_NONE, c_f32=False, accumulate=False, colsum=None):
     return GemmProblem(ptr(A), ptr(B), ptr(C), M, N, K, a_rs, a_ks, b_ns, b_ks, ldc, 1, 0, 0, 0, ptr(bias),
-                       ptr(residual), ptr(preact), ptr(aux), act, int(c_f32), int(accumulate), 1.0)
+                       ptr(residual), ptr(preact), ptr(aux), ptr(colsum), act, int(c_f32), int(accumulate), 1.0)
 
 
 def p_fwd(x, w, bias=None, act=ACT_NONE, want_preact=False, out_f32=False):
@@ -137,14 +137,18 @@ def p_fwd(x, w, bias=None, act=ACT_NONE, want_preact=False, out_f32=False):
     return _problem(x, w, y, M, N, K, a_rs, 1, K, 1, N, bias=bias, preact=pre, act=act, c_f32=out_f32), y, pre
 
 
-def p_dgrad(dy, w, residual=None, gelu_aux=None):
-    """problem for dx = dy @ w (+ residual) (* gelu'(aux)); returns (problem, dx)."""
+def p_dgrad(dy, w, residual=None, gelu_aux=None, colsum=None):
+    """problem for dx = dy @ w (+ residual) (* gelu'(aux)); ``colsum`` (fp32 [K]) += column sums of dx
+    (the bias gradient of the Linear that produced the activation); returns (problem, dx)."""
     M, N, a_rs = _rows(_chk(dy))
     K = w.shape[1]
     assert w.shape[0] == N and w.dtype == dy.dtype and w.is_contiguous()
     dx = torch.empty((M, K), device=dy.device, dtype=dy.dtype)
+    if colsum is not None:
+        _c(colsum, F32, "colsum")
+        assert colsum.numel() == K
     return _problem(dy, w, dx, M, K, N, a_rs, 1, 1, K, K, residual=residual, aux=gelu_aux,
-                    act=ACT_GELU_GRAD if gelu_aux is not None else ACT_NONE), dx
+                    act=ACT_GELU_GRAD if gelu_aux is not None else ACT_NONE, colsum=colsum), dx
 
 
 def p_wgrad(dy, x, gw, accumulate):
@@ -203,7 +207,8 @@ def attn_fwd(q, k, v, mask, B, heads, Sq, Sk, p, rng, sid):
     return out
 
 
-def attn_bwd(q, k, v, mask, d_out, dq, dk, dv, B, heads, Sq, Sk, p, rng, sid):
+def attn_bwd(q, k, v, mask, d_out, dq, dk, dv, B, heads, Sq, Sk, p, rng, sid, dbq=None, dbk=None, dbv=None):
+    """dbq/dbk/dbv: fp32 [heads*64] accumulators of the query/key/value bias gradients"""
     d = 64
     H = heads * d
     _c(d_out)
@@ -213,7 +218,7 @@ def attn_bwd(q, k, v, mask, d_out, dq, dk, dv, B, heads, Sq, Sk, p, rng, sid):
             raise RuntimeError("attn_bwd: bad gradient buffer %s" % (tuple(t.shape),))
     call("xggm_attn_bwd_" + sfx(q.dtype), ptr(q), ptr(k), ptr(v), ptr(mask), ptr(d_out), ptr(dq), ptr(dk),
          ptr(dv), B, heads, Sq, Sk, d, q.stride(0), k.stride(0), v.stride(0), H, dq.stride(0),
-         dk.stride(0), dv.stride(0), 0.125, float(p), ptr(rng), sid, stream())
+         dk.stride(0), dv.stride(0), 0.125, float(p), ptr(rng), sid, ptr(dbq), ptr(dbk), ptr(dbv), stream())
 
 
 # ----------------------------------------------------------------------------- row kernels
