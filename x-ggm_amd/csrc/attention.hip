@@ -157,10 +157,12 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(AttnArgs a, const T* d_out
     }
     __syncthreads();
     // dQ[i][c] = sum_j dS[i][j] K[j][c]
-    for (int w = tid; w < Sq * 16; w += NT) {
-        const int i = w >> 4, c = (w & 15) * 4;
+    // whole waves iterate (the shuffles below need every lane); lanes past the end are predicated
+    for (int w = tid; w < ((Sq * 16 + 63) & ~63); w += NT) {
+        const bool valid = w < Sq * 16;
+        const int i = valid ? (w >> 4) : 0, c = (w & 15) * 4;
         float o[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int j = 0; j < Sk; ++j) {
+        for (int j = 0; j < (valid ? Sk : 0); ++j) {
             const float s = dS[i * ldp + j];
             const float4 kk = *reinterpret_cast<const float4*>(Ks + j * LD + c);
             o[0] += s * kk.x;
@@ -168,17 +170,25 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(AttnArgs a, const T* d_out
             o[2] += s * kk.z;
             o[3] += s * kk.w;
         }
-        store4(dq + ((int64_t)b * Sq + i) * dq_rs + h * D + c, o);
+        if (valid) store4(dq + ((int64_t)b * Sq + i) * dq_rs + h * D + c, o);
         if (dbq) {
+            // lanes l, l+16, l+32, l+48 hold the same 4 columns of 4 consecutive rows: fold them
+            // with two shuffles, then one LDS atomic per column from the low 16 lanes
 #pragma unroll
-            for (int e = 0; e < 4; ++e) atomicAdd(&csum[0][c + e], o[e]);
+            for (int e = 0; e < 4; ++e) {
+                float t = o[e];
+                t += __shfl_xor(t, 16, 64);
+                t += __shfl_xor(t, 32, 64);
+                if ((tid & 63) < 16) atomicAdd(&csum[0][c + e], t);
+            }
         }
     }
     // dK[j][c] = sum_i dS[i][j] Q[i][c];  dV[j][c] = sum_i P[i][j] D[i][j] dO[i][c]
-    for (int w = tid; w < Sk * 16; w += NT) {
-        const int j = w >> 4, c = (w & 15) * 4;
+    for (int w = tid; w < ((Sk * 16 + 63) & ~63); w += NT) {
+        const bool valid = w < Sk * 16;
+        const int j = valid ? (w >> 4) : 0, c = (w & 15) * 4;
         float ok[4] = {0.f, 0.f, 0.f, 0.f}, ov[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int i = 0; i < Sq; ++i) {
+        for (int i = 0; i < (valid ? Sq : 0); ++i) {
             const float s = dS[i * ldp + j];
             float pj = P[i * ldp + j];
             if (a.p > 0.f) pj *= Dm[i * ldp + j];
@@ -193,13 +203,22 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(AttnArgs a, const T* d_out
             ov[2] += pj * gg.z;
             ov[3] += pj * gg.w;
         }
-        store4(dk + ((int64_t)b * Sk + j) * dk_rs + h * D + c, ok);
-        store4(dv + ((int64_t)b * Sk + j) * dv_rs + h * D + c, ov);
+        if (valid) {
+            store4(dk + ((int64_t)b * Sk + j) * dk_rs + h * D + c, ok);
+            store4(dv + ((int64_t)b * Sk + j) * dv_rs + h * D + c, ov);
+        }
         if (dbk) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                atomicAdd(&csum[1][c + e], ok[e]);
-                atomicAdd(&csum[2][c + e], ov[e]);
+                float t1 = ok[e], t2 = ov[e];
+                t1 += __shfl_xor(t1, 16, 64);
+                t2 += __shfl_xor(t2, 16, 64);
+                t1 += __shfl_xor(t1, 32, 64);
+                t2 += __shfl_xor(t2, 32, 64);
+                if ((tid & 63) < 16) {
+                    atomicAdd(&csum[1][c + e], t1);
+                    atomicAdd(&csum[2][c + e], t2);
+                }
             }
         }
     }

@@ -620,7 +620,7 @@ int ln_fwd(const void* in, const float* bias, const void* residual, const float*
     return xggm_check_launch("xggm_ln_fwd");
 }
 
-inline size_t bwd_ws_bytes(int M, int H, int K) { return sizeof(float) * (size_t)rows_grid(M, 128) * K * H; }
+inline size_t bwd_ws_bytes(int M, int H, int K) { return sizeof(float) * (size_t)rows_grid(M, 512) * K * H; }
 
 inline void launch_reduce(const float* ws, int nblk, int K, int H, const ReduceTargets& tg, hipStream_t st) {
     hipLaunchKernelGGL(partial_reduce_kernel, dim3(ceil_div(K * H, 64)), dim3(NT), 0, st, ws, nblk, K, H, tg);
@@ -637,7 +637,7 @@ int ln_bwd(const void* dy, const void* z, const float* stats, const float* gamma
     XGGM_REQUIRE(ws && ws_bytes >= bwd_ws_bytes(M, H, 3), "xggm_ln_bwd: workspace of %zu bytes needed, got %zu",
                  bwd_ws_bytes(M, H, 3), ws_bytes);
     DropArgs d{p_pre, p_post, rng, s_pre, s_post};
-    const int grid = rows_grid(M, 128);
+    const int grid = rows_grid(M, 512);
     DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), dim3(grid), dim3(NT), sizeof(float) * WPB * H, st,
                                        (const T*)dy, (const T*)z, stats, gamma, (T*)d_in, (T*)d_res, ws, M, H, d,
                                        out_scale, accumulate_dres, (const T*)gelu_aux));
@@ -707,7 +707,7 @@ int visn_bwd(const void* dy, const void* z1, const void* z2, const float* stats,
                  bwd_ws_bytes(M, H, 10), ws_bytes);
     DropArgs d{0.f, p, rng, 0, sid};
     const int nv_ = ceil_div(H, 256);
-    const int grid = rows_grid(M, 128);
+    const int grid = rows_grid(M, 512);
     const size_t lds = sizeof(float) * WPB * H;
     if (nv_ <= 1) {
         hipLaunchKernelGGL((visn_embed_bwd_kernel<T, 1>), dim3(grid), dim3(NT), lds, st, (const T*)dy, (const T*)z1,
