@@ -127,6 +127,9 @@ int xggm_attn_bwd_bf16(const void* q, const void* k, const void* v, const float*
                        int64_t v_rs, int64_t o_rs, int64_t dq_rs, int64_t dk_rs, int64_t dv_rs, float scale, float p,
                        const uint64_t* rng, uint32_t sid, float* dbq, float* dbk, float* dbv, xggm_stream_t stream);
 
+/* HOST: 1 = run bf16 attention on the scalar kernels (A/B tests), 0 = matrix-core kernels */
+int xggm_attn_set_scalar(int on);
+
 /* ---- row kernels -----------------------------------------------------------------------
  * out = [out +] out_scale * drop_post( LN( drop_pre(in + bias) + residual ; gamma, beta, eps) )
  * in/residual/out/z_out: T [M,H]; z_out (may alias `in`) receives the LN input, stats [M,2]

@@ -5,16 +5,33 @@
 // lives in the LDS of one 256-thread workgroup: HBM traffic is exactly one read of
 // Q/K/V(/dO) and one write of O (dQ/dK/dV).  Nothing but the inputs is saved for backward:
 // P and the Philox dropout mask are recomputed.  Per-row softmax uses wave64 shuffle
-// reductions; fp32 math throughout (the products are ~1% of the step's FLOPs, MFMA would
-// buy nothing here while the tiles are latency- not throughput-bound).
+// reductions; fp32 math throughout.  These scalar kernels serve fp32 storage (exact parity
+// mode); bf16 storage runs the matrix-core versions of attention_mfma.hip.
 #include "common.h"
 #include "xggm.h"
+
+// bf16 matrix-core versions (attention_mfma.hip)
+int xggm_attn_fwd_mfma(const void* q, const void* k, const void* v, const float* mask, void* out, int B, int heads, int Sq,
+                       int Sk, int64_t q_rs, int64_t k_rs, int64_t v_rs, int64_t o_rs, float scale, float p,
+                       const uint64_t* rng, uint32_t sid, hipStream_t st);
+int xggm_attn_bwd_mfma(const void* q, const void* k, const void* v, const float* mask, const void* d_out, void* dq, void* dk,
+                       void* dv, int B, int heads, int Sq, int Sk, int64_t q_rs, int64_t k_rs, int64_t v_rs, int64_t o_rs,
+                       int64_t dq_rs, int64_t dk_rs, int64_t dv_rs, float scale, float p, const uint64_t* rng, uint32_t sid,
+                       float* dbq, float* dbk, float* dbv, hipStream_t st);
 
 namespace {
 
 constexpr int NT = 256;
 constexpr int D = 64;
 constexpr int LD = D + 4;  // float4-aligned rows, conflict-free 16-byte reads
+bool g_attn_scalar = false;  // test hook (xggm_attn_set_scalar): bf16 on the scalar kernels
+
+inline bool mfma_ok(const void* a, const void* b, const void* c, const void* d, int64_t s0, int64_t s1, int64_t s2, int64_t s3) {
+    return !g_attn_scalar &&
+           ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
+             reinterpret_cast<uintptr_t>(d)) % 16 == 0) &&
+           s0 % 8 == 0 && s1 % 8 == 0 && s2 % 8 == 0 && s3 % 8 == 0;
+}
 
 struct AttnArgs {
     const void *q, *k, *v;
@@ -251,6 +268,10 @@ int attn_fwd(const void* q, const void* k, const void* v, const float* mask, voi
     AttnArgs a{q, k, v, mask, q_rs, k_rs, v_rs, o_rs, B, heads, Sq, Sk, scale, p, rng, sid};
     if (int e = check("xggm_attn_fwd", a, head_dim)) return e;
     XGGM_REQUIRE(out, "xggm_attn_fwd: null output");
+    if constexpr (sizeof(T) == 2) {
+        if (mfma_ok(q, k, v, nullptr, q_rs, k_rs, v_rs, 8))
+            return xggm_attn_fwd_mfma(q, k, v, mask, out, B, heads, Sq, Sk, q_rs, k_rs, v_rs, o_rs, scale, p, rng, sid, st);
+    }
     const size_t lds = sizeof(float) * ((size_t)(Sq + 2 * Sk) * LD + 2 * (size_t)Sq * (Sk + 1));
     hipLaunchKernelGGL((attn_fwd_kernel<T>), dim3(B * heads), dim3(NT), lds, st, a, (T*)out);
     return xggm_check_launch("xggm_attn_fwd");
@@ -266,6 +287,11 @@ int attn_bwd(const void* q, const void* k, const void* v, const float* mask, con
     XGGM_REQUIRE(d_out && dq && dk && dv, "xggm_attn_bwd: null pointer");
     XGGM_REQUIRE(dq_rs % 4 == 0 && dk_rs % 4 == 0 && dv_rs % 4 == 0, "xggm_attn_bwd: row strides must be multiples of 4");
     XGGM_REQUIRE((dbk == nullptr) == (dbv == nullptr), "xggm_attn_bwd: dbk and dbv go together");
+    if constexpr (sizeof(T) == 2) {
+        if (mfma_ok(q, k, v, d_out, q_rs, k_rs, v_rs, o_rs))
+            return xggm_attn_bwd_mfma(q, k, v, mask, d_out, dq, dk, dv, B, heads, Sq, Sk, q_rs, k_rs, v_rs, o_rs, dq_rs,
+                                      dk_rs, dv_rs, scale, p, rng, sid, dbq, dbk, dbv, st);
+    }
     const size_t lds = sizeof(float) * ((size_t)(2 * Sq + 2 * Sk) * LD + 3 * (size_t)Sq * (Sk + 1));
     hipLaunchKernelGGL((attn_bwd_kernel<T>), dim3(B * heads), dim3(NT), lds, st, a, (const T*)d_out, (T*)dq, (T*)dk, (T*)dv,
                        dq_rs, dk_rs, dv_rs, dbq, dbk, dbv);
@@ -292,3 +318,9 @@ int attn_bwd(const void* q, const void* k, const void* v, const float* mask, con
 
 ATTN_API(f32, float)
 ATTN_API(bf16, bf16)
+
+// test / A-B hook: 1 = bf16 attention on the scalar fp32-math kernels, 0 = matrix-core kernels
+extern "C" int xggm_attn_set_scalar(int on) {
+    g_attn_scalar = on != 0;
+    return XGGM_OK;
+}

@@ -1,0 +1,302 @@
+// bf16 attention core on the matrix cores (the fp32 path keeps the scalar kernels of attention.hip).
+//
+// One 256-thread workgroup per (sample, head).  Q, K, V (and dO) tiles are staged in LDS as bf16 with
+// an 80-element row stride, a layout that serves BOTH operand shapes of the 16x16x32 MFMA: rows read
+// with ds_read_b128 when the reduction index is the tile's column (S = Q K^T, dP = dO V^T) and
+// columns read with the transposing ds_read_b64_tr_b16 when the reduction index is the tile's row
+// (O = P V, dQ = dS K, dK = dS^T Q, dV = P^T dO).  Scores / probabilities pass through LDS once as
+// fp32 for the wave-per-row softmax (shuffle reductions) and return as bf16 operands.  All five
+// products of the backward are 108 MFMAs per (b, h) at S = 36 instead of ~420 K scalar FMAs.
+// Sequences are padded to the MFMA granularity with zero rows, which contribute nothing.
+#include "common.h"
+#include "xggm.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int D = 64;
+constexpr int LDT = D + 16;  // tile row stride in elements (160 B): tr-reads conflict-free, b128 rows 16-B aligned
+
+typedef __attribute__((ext_vector_type(8))) short short8_t;
+typedef __attribute__((ext_vector_type(4))) short short4_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float float4_t;
+
+struct MArgs {
+    const bf16 *q, *k, *v;
+    const float* mask;
+    int64_t q_rs, k_rs, v_rs, o_rs;
+    int B, heads, Sq, Sk;
+    float scale, p;
+    const uint64_t* rng;
+    uint32_t sid;
+};
+
+__device__ __forceinline__ int rup(int x, int m) { return (x + m - 1) / m * m; }
+
+// rows x 64 bf16 tile -> LDS (row stride LDT); rows [valid, rows) are zero
+__device__ __forceinline__ void load_tile(bf16* lds, const bf16* base, int64_t rs, int valid, int rows, int tid) {
+    for (int c = tid; c < rows * 8; c += NT) {
+        const int r = c >> 3, cc = (c & 7) * 8;
+        short8_t v = {};
+        if (r < valid) v = *reinterpret_cast<const short8_t*>(base + (int64_t)r * rs + cc);
+        *reinterpret_cast<short8_t*>(lds + r * LDT + cc) = v;
+    }
+}
+
+// operand whose reduction index k is contiguous: lane (fr, fq) gets row row0+fr, k = k0+8fq .. +7
+__device__ __forceinline__ bf16x8_t frag_rows(const bf16* lds, int ld, int row0, int k0, int lane) {
+    const int fr = lane & 15, fq = lane >> 4;
+    return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(lds + (row0 + fr) * ld + k0 + fq * 8));
+}
+// operand stored [k][n] (n contiguous): lane gets n = n0+fr, k = k0+8fq .. +7 through two transposing reads
+__device__ __forceinline__ bf16x8_t frag_tr(const bf16* lds, int ld, int k0, int n0, int lane) {
+    const int fr = lane & 15, fq = lane >> 4, q = fr >> 2, p = fr & 3;
+    const bf16* a0 = lds + (k0 + 8 * fq + q) * ld + n0 + 4 * p;
+    const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(a0));
+    const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(a0 + 4 * ld));
+    short8_t v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+
+// S = scale * Q K^T + mask  ->  Sf (fp32, row stride lds_s), tiles shared round-robin by the waves
+__device__ __forceinline__ void scores(const MArgs& a, const bf16* Qs, const bf16* Ks, float* Sf, int lds_s, int b, int tid) {
+    const int lane = tid & 63, wid = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    const int tq = rup(a.Sq, 16) / 16, tk = rup(a.Sk, 16) / 16;
+    for (int t = wid; t < tq * tk; t += NT / 64) {
+        const int ti = t / tk, tj = t % tk;
+        float4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < D; ks += 32)
+            acc = MFMA(frag_rows(Qs, LDT, ti * 16, ks, lane), frag_rows(Ks, LDT, tj * 16, ks, lane), acc);
+        const int j = tj * 16 + fr;
+        const float mk = (a.mask && j < a.Sk) ? a.mask[(int64_t)b * a.Sk + j] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = ti * 16 + fq * 4 + r;
+            if (i < a.Sq && j < a.Sk) Sf[i * lds_s + j] = acc[r] * a.scale + mk;
+        }
+    }
+}
+
+// row softmax of Sf in place (fp32), dropout scale into Dm when p > 0.  wave w owns rows w, w+4, ...
+__device__ __forceinline__ void softmax_rows(const MArgs& a, float* Sf, float* Dm, int lds_s, int b, int h, int tid) {
+    const int lane = tid & 63, wid = tid >> 6;
+    uint64_t seed = 0, off = 0;
+    if (a.p > 0.f) {
+        seed = a.rng[0];
+        off = a.rng[1];
+    }
+    const float ik = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
+    for (int i = wid; i < a.Sq; i += NT / 64) {
+        const float v = lane < a.Sk ? Sf[i * lds_s + lane] : -INFINITY;
+        const float m = wave_max(v);
+        const float e = lane < a.Sk ? __expf(v - m) : 0.f;
+        const float sum = wave_sum(e);
+        if (lane < a.Sk) {
+            Sf[i * lds_s + lane] = e / sum;
+            if (a.p > 0.f)
+                Dm[i * lds_s + lane] =
+                    dropout_scale(a.p, ik, seed, off, a.sid, (((uint64_t)b * a.heads + h) * a.Sq + i) * a.Sk + lane);
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT) void attn_fwd_mfma_kernel(MArgs a, bf16* out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+    const int Sq = a.Sq, Sk = a.Sk;
+    const int RQ = rup(Sq, 16), RK = rup(Sk, 32);  // Q rows (M of every product), K/V rows (k of P V)
+    const int LDP = RK + 16, lds_s = rup(Sk, 16) + 1;
+    bf16* Qs = reinterpret_cast<bf16*>(smem_raw);
+    bf16* Ks = Qs + RQ * LDT;
+    bf16* Vs = Ks + RK * LDT;
+    bf16* Pb = Vs + RK * LDT;                                    // [RQ][LDP] bf16 probabilities (dropout folded in)
+    float* Sf = reinterpret_cast<float*>(Pb + RQ * LDP);         // [RQ][lds_s]
+    float* Dm = Sf + RQ * lds_s;
+    load_tile(Qs, a.q + (int64_t)b * Sq * a.q_rs + h * D, a.q_rs, Sq, RQ, tid);
+    load_tile(Ks, a.k + (int64_t)b * Sk * a.k_rs + h * D, a.k_rs, Sk, RK, tid);
+    load_tile(Vs, a.v + (int64_t)b * Sk * a.v_rs + h * D, a.v_rs, Sk, RK, tid);
+    __syncthreads();
+    scores(a, Qs, Ks, Sf, lds_s, b, tid);
+    __syncthreads();
+    softmax_rows(a, Sf, Dm, lds_s, b, h, tid);
+    __syncthreads();
+    for (int e = tid; e < RQ * RK; e += NT) {  // bf16 operand copy, zero outside [Sq) x [Sk)
+        const int i = e / RK, j = e % RK;
+        float v = 0.f;
+        if (i < Sq && j < Sk) {
+            v = Sf[i * lds_s + j];
+            if (a.p > 0.f) v *= Dm[i * lds_s + j];
+        }
+        Pb[i * LDP + j] = __float2bfloat16(v);
+    }
+    __syncthreads();
+    // O = P V : tiles (ti, tc), k = j over RK
+    const int tq = RQ / 16;
+    for (int t = wid; t < tq * 4; t += NT / 64) {
+        const int ti = t >> 2, tc = t & 3;
+        float4_t acc = {0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < RK; ks += 32)
+            acc = MFMA(frag_rows(Pb, LDP, ti * 16, ks, lane), frag_tr(Vs, LDT, ks, tc * 16, lane), acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = ti * 16 + fq * 4 + r;
+            if (i < Sq) out[((int64_t)b * Sq + i) * a.o_rs + h * D + tc * 16 + fr] = __float2bfloat16(acc[r]);
+        }
+    }
+}
+
+// store a 16x16 gradient tile (rows row0.., 16 columns at col0) and fold its column sums into csum
+__device__ __forceinline__ void store_grad_tile(const float4_t& acc, bf16* dst, int64_t rs, int row_base, int rows_valid,
+                                                int row0, int col0, float* csum, int lane) {
+    const int fr = lane & 15, fq = lane >> 4;
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = row0 + fq * 4 + r;
+        if (i < rows_valid) {
+            dst[(int64_t)(row_base + i) * rs + col0 + fr] = __float2bfloat16(acc[r]);
+            s += acc[r];
+        }
+    }
+    if (csum) {
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (lane < 16) atomicAdd(csum + col0 + fr, s);
+    }
+}
+
+__global__ __launch_bounds__(NT) void attn_bwd_mfma_kernel(MArgs a, const bf16* d_out, bf16* dq, bf16* dk, bf16* dv,
+                                                           int64_t dq_rs, int64_t dk_rs, int64_t dv_rs, float* dbq,
+                                                           float* dbk, float* dbv) {
+    __shared__ float csum[3][D];
+    if (threadIdx.x < 3 * D) (&csum[0][0])[threadIdx.x] = 0.f;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+    const int Sq = a.Sq, Sk = a.Sk;
+    const int RQ = rup(Sq, 32), RK = rup(Sk, 32);  // both row counts also serve as reduction lengths here
+    const int LDP = RK + 16, lds_s = rup(Sk, 16) + 1;
+    bf16* Qs = reinterpret_cast<bf16*>(smem_raw);
+    bf16* Ks = Qs + RQ * LDT;
+    bf16* Vs = Ks + RK * LDT;
+    bf16* dOs = Vs + RK * LDT;
+    bf16* dSb = dOs + RQ * LDT;   // [RQ][LDP] bf16: dS (scaled)
+    bf16* Pdb = dSb + RQ * LDP;   // [RQ][LDP] bf16: P with dropout folded in
+    float* Sf = reinterpret_cast<float*>(Pdb + RQ * LDP);  // [RQ][lds_s]: S then P
+    float* Dm = Sf + RQ * lds_s;
+    float* dPf = Dm + RQ * lds_s;
+    load_tile(Qs, a.q + (int64_t)b * Sq * a.q_rs + h * D, a.q_rs, Sq, RQ, tid);
+    load_tile(Ks, a.k + (int64_t)b * Sk * a.k_rs + h * D, a.k_rs, Sk, RK, tid);
+    load_tile(Vs, a.v + (int64_t)b * Sk * a.v_rs + h * D, a.v_rs, Sk, RK, tid);
+    load_tile(dOs, d_out + (int64_t)b * Sq * a.o_rs + h * D, a.o_rs, Sq, RQ, tid);
+    __syncthreads();
+    scores(a, Qs, Ks, Sf, lds_s, b, tid);
+    // dP = dO V^T (both operands read by rows: the reduction index is the feature)
+    {
+        const int tq = rup(Sq, 16) / 16, tk = rup(Sk, 16) / 16;
+        for (int t = wid; t < tq * tk; t += NT / 64) {
+            const int ti = t / tk, tj = t % tk;
+            float4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < D; ks += 32)
+                acc = MFMA(frag_rows(dOs, LDT, ti * 16, ks, lane), frag_rows(Vs, LDT, tj * 16, ks, lane), acc);
+            const int j = tj * 16 + fr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = ti * 16 + fq * 4 + r;
+                if (i < Sq && j < Sk) dPf[i * lds_s + j] = acc[r];
+            }
+        }
+    }
+    __syncthreads();
+    softmax_rows(a, Sf, Dm, lds_s, b, h, tid);
+    __syncthreads();
+    // dS = P (dP D - rowsum(dP D P)) scale;  Pd = P D.  Rows/columns outside the problem are zero.
+    for (int i = wid; i < RQ; i += NT / 64) {
+        const bool in = i < Sq && lane < Sk;
+        const float pv = in ? Sf[i * lds_s + lane] : 0.f;
+        const float dm = (in && a.p > 0.f) ? Dm[i * lds_s + lane] : 1.f;
+        const float dp = in ? dPf[i * lds_s + lane] * dm : 0.f;
+        const float rs = wave_sum(pv * dp);
+        if (lane < RK) {
+            dSb[i * LDP + lane] = __float2bfloat16(in ? pv * (dp - rs) * a.scale : 0.f);
+            Pdb[i * LDP + lane] = __float2bfloat16(in ? pv * dm : 0.f);
+        }
+    }
+    __syncthreads();
+    const int tq = rup(Sq, 16) / 16, tk = rup(Sk, 16) / 16;
+    // 4 column tiles each for dQ (tq row tiles), dK and dV (tk row tiles): one list shared by the waves
+    const int n_dq = tq * 4, n_dk = tk * 4;
+    for (int t = wid; t < n_dq + 2 * n_dk; t += NT / 64) {
+        float4_t acc = {0.f, 0.f, 0.f, 0.f};
+        if (t < n_dq) {
+            const int ti = t >> 2, tc = t & 3;  // dQ = dS K: k = j
+            for (int ks = 0; ks < RK; ks += 32)
+                acc = MFMA(frag_rows(dSb, LDP, ti * 16, ks, lane), frag_tr(Ks, LDT, ks, tc * 16, lane), acc);
+            store_grad_tile(acc, dq + h * D, dq_rs, b * Sq, Sq, ti * 16, tc * 16, dbq ? csum[0] : nullptr, lane);
+        } else if (t < n_dq + n_dk) {
+            const int u = t - n_dq, tj = u >> 2, tc = u & 3;  // dK = dS^T Q: k = i
+            for (int ks = 0; ks < RQ; ks += 32)
+                acc = MFMA(frag_tr(dSb, LDP, ks, tj * 16, lane), frag_tr(Qs, LDT, ks, tc * 16, lane), acc);
+            store_grad_tile(acc, dk + h * D, dk_rs, b * Sk, Sk, tj * 16, tc * 16, dbk ? csum[1] : nullptr, lane);
+        } else {
+            const int u = t - n_dq - n_dk, tj = u >> 2, tc = u & 3;  // dV = (P D)^T dO: k = i
+            for (int ks = 0; ks < RQ; ks += 32)
+                acc = MFMA(frag_tr(Pdb, LDP, ks, tj * 16, lane), frag_tr(dOs, LDT, ks, tc * 16, lane), acc);
+            store_grad_tile(acc, dv + h * D, dv_rs, b * Sk, Sk, tj * 16, tc * 16, dbv ? csum[2] : nullptr, lane);
+        }
+    }
+    if (dbq || dbk) {
+        __syncthreads();
+        const int t = threadIdx.x;
+        if (t < D && dbq) atomicAdd(dbq + h * D + t, csum[0][t]);
+        else if (t >= D && t < 2 * D && dbk) atomicAdd(dbk + h * D + (t - D), csum[1][t - D]);
+        else if (t >= 2 * D && t < 3 * D && dbv) atomicAdd(dbv + h * D + (t - 2 * D), csum[2][t - 2 * D]);
+    }
+}
+
+template <typename K> void allow_big_lds(K kernel, size_t lds) {
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+}  // namespace
+
+// called by attention.hip for bf16 storage (arguments already validated there)
+int xggm_attn_fwd_mfma(const void* q, const void* k, const void* v, const float* mask, void* out, int B, int heads, int Sq,
+                       int Sk, int64_t q_rs, int64_t k_rs, int64_t v_rs, int64_t o_rs, float scale, float p,
+                       const uint64_t* rng, uint32_t sid, hipStream_t st) {
+    XGGM_REQUIRE(q_rs % 8 == 0 && k_rs % 8 == 0 && v_rs % 8 == 0, "xggm_attn_fwd: bf16 row strides must be multiples of 8");
+    XGGM_REQUIRE((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) % 16 == 0,
+                 "xggm_attn_fwd: bf16 operands must be 16-byte aligned");
+    MArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, mask, q_rs, k_rs, v_rs, o_rs, B, heads, Sq, Sk, scale, p, rng, sid};
+    const int RQ = (Sq + 15) / 16 * 16, RK = (Sk + 31) / 32 * 32, lds_s = (Sk + 15) / 16 * 16 + 1;
+    const size_t lds = sizeof(bf16) * ((size_t)(RQ + 2 * RK) * LDT + (size_t)RQ * (RK + 16)) + sizeof(float) * 2 * RQ * lds_s;
+    allow_big_lds(attn_fwd_mfma_kernel, lds);
+    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(B * heads), dim3(NT), lds, st, a, (bf16*)out);
+    return xggm_check_launch("xggm_attn_fwd(mfma)");
+}
+
+int xggm_attn_bwd_mfma(const void* q, const void* k, const void* v, const float* mask, const void* d_out, void* dq, void* dk,
+                       void* dv, int B, int heads, int Sq, int Sk, int64_t q_rs, int64_t k_rs, int64_t v_rs, int64_t o_rs,
+                       int64_t dq_rs, int64_t dk_rs, int64_t dv_rs, float scale, float p, const uint64_t* rng, uint32_t sid,
+                       float* dbq, float* dbk, float* dbv, hipStream_t st) {
+    XGGM_REQUIRE(q_rs % 8 == 0 && k_rs % 8 == 0 && v_rs % 8 == 0 && o_rs % 8 == 0,
+                 "xggm_attn_bwd: bf16 row strides must be multiples of 8");
+    XGGM_REQUIRE((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) |
+                  reinterpret_cast<uintptr_t>(d_out)) % 16 == 0,
+                 "xggm_attn_bwd: bf16 operands must be 16-byte aligned");
+    MArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, mask, q_rs, k_rs, v_rs, o_rs, B, heads, Sq, Sk, scale, p, rng, sid};
+    const int RQ = (Sq + 31) / 32 * 32, RK = (Sk + 31) / 32 * 32, lds_s = (Sk + 15) / 16 * 16 + 1;
+    const size_t lds = sizeof(bf16) * ((size_t)(2 * RQ + 2 * RK) * LDT + 2 * (size_t)RQ * (RK + 16)) + sizeof(float) * 3 * RQ * lds_s;
+    allow_big_lds(attn_bwd_mfma_kernel, lds);
+    hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(B * heads), dim3(NT), lds, st, a, (const bf16*)d_out, (bf16*)dq, (bf16*)dk,
+                       (bf16*)dv, dq_rs, dk_rs, dv_rs, dbq, dbk, dbv);
+    return xggm_check_launch("xggm_attn_bwd(mfma)");
+}
