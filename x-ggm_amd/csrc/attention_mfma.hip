@@ -34,13 +34,25 @@ struct MArgs {
 
 __device__ __forceinline__ int rup(int x, int m) { return (x + m - 1) / m * m; }
 
-// rows x 64 bf16 tile -> LDS (row stride LDT); rows [valid, rows) are zero
-__device__ __forceinline__ void load_tile(bf16* lds, const bf16* base, int64_t rs, int valid, int rows, int tid) {
-    for (int c = tid; c < rows * 8; c += NT) {
-        const int r = c >> 3, cc = (c & 7) * 8;
-        short8_t v = {};
-        if (r < valid) v = *reinterpret_cast<const short8_t*>(base + (int64_t)r * rs + cc);
-        *reinterpret_cast<short8_t*>(lds + r * LDT + cc) = v;
+// rows (<= 64) x 64 bf16 tile: two 16-byte chunks per thread.  tile_fetch only ISSUES the loads
+// (addresses clamped into the tile, no branches) so the loads of all tiles of a workgroup are in
+// flight together; tile_commit zeroes the padding rows and writes LDS (row stride LDT).
+struct TileRegs { short8_t v[2]; };
+__device__ __forceinline__ TileRegs tile_fetch(const bf16* base, int64_t rs, int valid, int tid) {
+    TileRegs t;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int c = tid + it * NT, r = min(c >> 3, valid - 1), cc = (c & 7) * 8;
+        t.v[it] = *reinterpret_cast<const short8_t*>(base + (int64_t)r * rs + cc);
+    }
+    return t;
+}
+__device__ __forceinline__ void tile_commit(bf16* lds, const TileRegs& t, int valid, int rows, int tid) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int c = tid + it * NT, r = c >> 3, cc = (c & 7) * 8;
+        const short8_t zero = {};
+        if (r < rows) *reinterpret_cast<short8_t*>(lds + r * LDT + cc) = r < valid ? t.v[it] : zero;
     }
 }
 
@@ -83,26 +95,33 @@ __device__ __forceinline__ void scores(const MArgs& a, const bf16* Qs, const bf1
     }
 }
 
-// row softmax of Sf in place (fp32), dropout scale into Dm when p > 0.  wave w owns rows w, w+4, ...
-__device__ __forceinline__ void softmax_rows(const MArgs& a, float* Sf, float* Dm, int lds_s, int b, int h, int tid) {
-    const int lane = tid & 63, wid = tid >> 6;
-    uint64_t seed = 0, off = 0;
-    if (a.p > 0.f) {
-        seed = a.rng[0];
-        off = a.rng[1];
+// dropout keep-scale of probability (i, j) of this (sample, head): a pure function of the Philox
+// state, recomputed wherever it is needed instead of being parked in LDS
+struct Drop {
+    float p, ik;
+    uint64_t seed, off, base;
+    uint32_t sid;
+    __device__ __forceinline__ Drop(const MArgs& a, int b, int h) : p(a.p), ik(a.p > 0.f ? 1.f / (1.f - a.p) : 1.f), seed(0), off(0),
+                                                                  base(((uint64_t)b * a.heads + h) * a.Sq * a.Sk), sid(a.sid) {
+        if (a.p > 0.f) {
+            seed = a.rng[0];
+            off = a.rng[1];
+        }
     }
-    const float ik = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
+    __device__ __forceinline__ float scale(int i, int j, int Sk) const {
+        return p > 0.f ? dropout_scale(p, ik, seed, off, sid, base + (uint64_t)i * Sk + j) : 1.f;
+    }
+};
+
+// row softmax of Sf in place (fp32).  wave w owns rows w, w+4, ...
+__device__ __forceinline__ void softmax_rows(const MArgs& a, float* Sf, int lds_s, int tid) {
+    const int lane = tid & 63, wid = tid >> 6;
     for (int i = wid; i < a.Sq; i += NT / 64) {
         const float v = lane < a.Sk ? Sf[i * lds_s + lane] : -INFINITY;
         const float m = wave_max(v);
         const float e = lane < a.Sk ? __expf(v - m) : 0.f;
         const float sum = wave_sum(e);
-        if (lane < a.Sk) {
-            Sf[i * lds_s + lane] = e / sum;
-            if (a.p > 0.f)
-                Dm[i * lds_s + lane] =
-                    dropout_scale(a.p, ik, seed, off, a.sid, (((uint64_t)b * a.heads + h) * a.Sq + i) * a.Sk + lane);
-        }
+        if (lane < a.Sk) Sf[i * lds_s + lane] = e / sum;
     }
 }
 
@@ -112,29 +131,33 @@ __global__ __launch_bounds__(NT) void attn_fwd_mfma_kernel(MArgs a, bf16* out) {
     const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
     const int Sq = a.Sq, Sk = a.Sk;
     const int RQ = rup(Sq, 16), RK = rup(Sk, 32);  // Q rows (M of every product), K/V rows (k of P V)
-    const int LDP = RK + 16, lds_s = rup(Sk, 16) + 1;
+    const int LDP = RK + 8, lds_s = rup(Sk, 16) + 1;
     bf16* Qs = reinterpret_cast<bf16*>(smem_raw);
     bf16* Ks = Qs + RQ * LDT;
     bf16* Vs = Ks + RK * LDT;
     bf16* Pb = Vs + RK * LDT;                                    // [RQ][LDP] bf16 probabilities (dropout folded in)
     float* Sf = reinterpret_cast<float*>(Pb + RQ * LDP);         // [RQ][lds_s]
-    float* Dm = Sf + RQ * lds_s;
-    load_tile(Qs, a.q + (int64_t)b * Sq * a.q_rs + h * D, a.q_rs, Sq, RQ, tid);
-    load_tile(Ks, a.k + (int64_t)b * Sk * a.k_rs + h * D, a.k_rs, Sk, RK, tid);
-    load_tile(Vs, a.v + (int64_t)b * Sk * a.v_rs + h * D, a.v_rs, Sk, RK, tid);
+    {
+        const TileRegs tq_ = tile_fetch(a.q + (int64_t)b * Sq * a.q_rs + h * D, a.q_rs, Sq, tid);
+        const TileRegs tk_ = tile_fetch(a.k + (int64_t)b * Sk * a.k_rs + h * D, a.k_rs, Sk, tid);
+        const TileRegs tv_ = tile_fetch(a.v + (int64_t)b * Sk * a.v_rs + h * D, a.v_rs, Sk, tid);
+        tile_commit(Qs, tq_, Sq, RQ, tid);
+        tile_commit(Ks, tk_, Sk, RK, tid);
+        tile_commit(Vs, tv_, Sk, RK, tid);
+    }
     __syncthreads();
     scores(a, Qs, Ks, Sf, lds_s, b, tid);
     __syncthreads();
-    softmax_rows(a, Sf, Dm, lds_s, b, h, tid);
+    softmax_rows(a, Sf, lds_s, tid);
     __syncthreads();
-    for (int e = tid; e < RQ * RK; e += NT) {  // bf16 operand copy, zero outside [Sq) x [Sk)
-        const int i = e / RK, j = e % RK;
-        float v = 0.f;
-        if (i < Sq && j < Sk) {
-            v = Sf[i * lds_s + j];
-            if (a.p > 0.f) v *= Dm[i * lds_s + j];
+    {
+        const Drop dr(a, b, h);
+        for (int e = tid; e < RQ * RK; e += NT) {  // bf16 operand copy, zero outside [Sq) x [Sk)
+            const int i = e / RK, j = e % RK;
+            float v = 0.f;
+            if (i < Sq && j < Sk) v = Sf[i * lds_s + j] * dr.scale(i, j, Sk);
+            Pb[i * LDP + j] = __float2bfloat16(v);
         }
-        Pb[i * LDP + j] = __float2bfloat16(v);
     }
     __syncthreads();
     // O = P V : tiles (ti, tc), k = j over RK
@@ -182,20 +205,25 @@ __global__ __launch_bounds__(NT) void attn_bwd_mfma_kernel(MArgs a, const bf16* 
     const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
     const int Sq = a.Sq, Sk = a.Sk;
     const int RQ = rup(Sq, 32), RK = rup(Sk, 32);  // both row counts also serve as reduction lengths here
-    const int LDP = RK + 16, lds_s = rup(Sk, 16) + 1;
+    const int LDP = RK + 8, R16 = rup(Sq, 16), lds_s = rup(Sk, 16) + 1;
     bf16* Qs = reinterpret_cast<bf16*>(smem_raw);
     bf16* Ks = Qs + RQ * LDT;
     bf16* Vs = Ks + RK * LDT;
     bf16* dOs = Vs + RK * LDT;
     bf16* dSb = dOs + RQ * LDT;   // [RQ][LDP] bf16: dS (scaled)
     bf16* Pdb = dSb + RQ * LDP;   // [RQ][LDP] bf16: P with dropout folded in
-    float* Sf = reinterpret_cast<float*>(Pdb + RQ * LDP);  // [RQ][lds_s]: S then P
-    float* Dm = Sf + RQ * lds_s;
-    float* dPf = Dm + RQ * lds_s;
-    load_tile(Qs, a.q + (int64_t)b * Sq * a.q_rs + h * D, a.q_rs, Sq, RQ, tid);
-    load_tile(Ks, a.k + (int64_t)b * Sk * a.k_rs + h * D, a.k_rs, Sk, RK, tid);
-    load_tile(Vs, a.v + (int64_t)b * Sk * a.v_rs + h * D, a.v_rs, Sk, RK, tid);
-    load_tile(dOs, d_out + (int64_t)b * Sq * a.o_rs + h * D, a.o_rs, Sq, RQ, tid);
+    float* Sf = reinterpret_cast<float*>(Pdb + RQ * LDP);  // [R16][lds_s]: S then P
+    float* dPf = Sf + R16 * lds_s;
+    {
+        const TileRegs tq_ = tile_fetch(a.q + (int64_t)b * Sq * a.q_rs + h * D, a.q_rs, Sq, tid);
+        const TileRegs tk_ = tile_fetch(a.k + (int64_t)b * Sk * a.k_rs + h * D, a.k_rs, Sk, tid);
+        const TileRegs tv_ = tile_fetch(a.v + (int64_t)b * Sk * a.v_rs + h * D, a.v_rs, Sk, tid);
+        const TileRegs to_ = tile_fetch(d_out + (int64_t)b * Sq * a.o_rs + h * D, a.o_rs, Sq, tid);
+        tile_commit(Qs, tq_, Sq, RQ, tid);
+        tile_commit(Ks, tk_, Sk, RK, tid);
+        tile_commit(Vs, tv_, Sk, RK, tid);
+        tile_commit(dOs, to_, Sq, RQ, tid);
+    }
     __syncthreads();
     scores(a, Qs, Ks, Sf, lds_s, b, tid);
     // dP = dO V^T (both operands read by rows: the reduction index is the feature)
@@ -216,13 +244,14 @@ __global__ __launch_bounds__(NT) void attn_bwd_mfma_kernel(MArgs a, const bf16* 
         }
     }
     __syncthreads();
-    softmax_rows(a, Sf, Dm, lds_s, b, h, tid);
+    softmax_rows(a, Sf, lds_s, tid);
     __syncthreads();
     // dS = P (dP D - rowsum(dP D P)) scale;  Pd = P D.  Rows/columns outside the problem are zero.
+    const Drop dr(a, b, h);
     for (int i = wid; i < RQ; i += NT / 64) {
         const bool in = i < Sq && lane < Sk;
         const float pv = in ? Sf[i * lds_s + lane] : 0.f;
-        const float dm = (in && a.p > 0.f) ? Dm[i * lds_s + lane] : 1.f;
+        const float dm = in ? dr.scale(i, lane, Sk) : 1.f;
         const float dp = in ? dPf[i * lds_s + lane] * dm : 0.f;
         const float rs = wave_sum(pv * dp);
         if (lane < RK) {
@@ -277,7 +306,7 @@ int xggm_attn_fwd_mfma(const void* q, const void* k, const void* v, const float*
                  "xggm_attn_fwd: bf16 operands must be 16-byte aligned");
     MArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, mask, q_rs, k_rs, v_rs, o_rs, B, heads, Sq, Sk, scale, p, rng, sid};
     const int RQ = (Sq + 15) / 16 * 16, RK = (Sk + 31) / 32 * 32, lds_s = (Sk + 15) / 16 * 16 + 1;
-    const size_t lds = sizeof(bf16) * ((size_t)(RQ + 2 * RK) * LDT + (size_t)RQ * (RK + 16)) + sizeof(float) * 2 * RQ * lds_s;
+    const size_t lds = sizeof(bf16) * ((size_t)(RQ + 2 * RK) * LDT + (size_t)RQ * (RK + 8)) + sizeof(float) * RQ * lds_s;
     allow_big_lds(attn_fwd_mfma_kernel, lds);
     hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(B * heads), dim3(NT), lds, st, a, (bf16*)out);
     return xggm_check_launch("xggm_attn_fwd(mfma)");
@@ -294,7 +323,8 @@ int xggm_attn_bwd_mfma(const void* q, const void* k, const void* v, const float*
                  "xggm_attn_bwd: bf16 operands must be 16-byte aligned");
     MArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, mask, q_rs, k_rs, v_rs, o_rs, B, heads, Sq, Sk, scale, p, rng, sid};
     const int RQ = (Sq + 31) / 32 * 32, RK = (Sk + 31) / 32 * 32, lds_s = (Sk + 15) / 16 * 16 + 1;
-    const size_t lds = sizeof(bf16) * ((size_t)(2 * RQ + 2 * RK) * LDT + 2 * (size_t)RQ * (RK + 16)) + sizeof(float) * 3 * RQ * lds_s;
+    const int R16 = (Sq + 15) / 16 * 16;
+    const size_t lds = sizeof(bf16) * ((size_t)(2 * RQ + 2 * RK) * LDT + 2 * (size_t)RQ * (RK + 8)) + sizeof(float) * 2 * R16 * lds_s;
     allow_big_lds(attn_bwd_mfma_kernel, lds);
     hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(B * heads), dim3(NT), lds, st, a, (const bf16*)d_out, (bf16*)dq, (bf16*)dk,
                        (bf16*)dv, dq_rs, dk_rs, dv_rs, dbq, dbk, dbv);
