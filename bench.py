@@ -176,6 +176,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if os.environ.get("XGGM_SHARE_GPU"):  # several ranks on one GPU (logic rehearsal only)
+        local = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -183,7 +185,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("XGGM_DIST_BACKEND", "nccl")  # "gloo": logic check of the N>1 path on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     from xggm_amd.engine import CapturedTrainer
     from xggm_amd.runtime import runtime_of
 
@@ -273,9 +279,10 @@ def main():
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "1xMI355X bf16: VQA-CP-v2-shaped synthetic batch=%d/GPU, 36 objects x 2048, "
+            "config": {"workload": "%dxMI355X %s: VQA-CP-v2-shaped synthetic batch=%d/GPU, 36 objects x 2048, "
                                    "20 tokens, A=%d, LXMERT 9/5/5 + GCNx2, full fwd+bwd+clip+BertAdam x2 passes, "
-                                   "dropout on, delta=%d branch mix" % (args.batch, args.answers, args.delta),
+                                   "dropout on, delta=%d branch mix" % (world, args.dtype, args.batch, args.answers,
+                                                                        args.delta),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "hip_graph": not args.no_graph, "grad_wire": args.wire if world > 1 else None},
             "ms_per_step_by_branch": per_branch,
