@@ -160,6 +160,16 @@ int xggm_ln_bwd_bf16(const void* dy, const void* z, const float* stats, const fl
  * reduced vector, summed by a second kernel instead of contended atomics */
 size_t xggm_ln_bwd_workspace_bytes(int M, int H);
 size_t xggm_visn_embed_bwd_workspace_bytes(int M, int H);
+/* Deferred second stage.  xggm_ln_bwd called with dgamma = dbeta = dbias = NULL only fills its
+ * workspace ws[nblk][3][H] (nblk = workspace_bytes / (12 H)); the sums of many such workspaces
+ * are then added to their gradients by ONE launch at the end of the backward pass instead of one
+ * tiny launch per LayerNorm (58 per pass in LXMERT 9/5/5).  target[k] += sum_b ws[b][k][:]. */
+typedef struct xggm_reduce_job {
+    const float* ws;
+    int nblk, K, H; /* K <= 3 partial vectors of H floats per workgroup */
+    float* target[3]; /* NULL = vector not wanted */
+} xggm_reduce_job;
+int xggm_partial_reduce_batch(const xggm_reduce_job* jobs, int n, xggm_stream_t stream);
 /* BertEmbeddings: src/lxrt/modeling.py:298-313.  ids/seg: int64 [M] (M = B*Tlen), tables T.
  * backward scatter-adds into the fp32 table gradients; row 0 (padding_idx) gets none. */
 int xggm_embed_fwd_f32(const int64_t* ids, const int64_t* seg, const void* word, const void* pos, const void* type,

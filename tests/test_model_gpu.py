@@ -271,6 +271,9 @@ def test_dropout_training_mode_runs_and_is_reproducible():
             traj += [float(o["loss_plain"]), float(o["loss_ggm"])]
         assert all(np.isfinite(traj))
         runs.append(traj)
-    # same seed -> same masks; fp32 atomics make the last bits run-dependent, nothing more
-    assert np.allclose(runs[0], runs[1], rtol=1e-4)
-    assert not np.allclose(runs[0], runs[2], rtol=1e-3)
+    # same seed -> same masks: the first iteration's losses agree to fp32 rounding; fp32 atomics (bias
+    # gradients) make the last bits of the updates run-dependent, which the hard thresholds of the
+    # adjacency regeneration amplify to a few 1e-4 in later GGM losses.  Another seed moves every loss ~1 %.
+    assert np.allclose(runs[0][:2], runs[1][:2], rtol=1e-6)
+    assert np.allclose(runs[0], runs[1], rtol=2e-3)
+    assert not np.allclose(runs[0], runs[2], rtol=3e-3)

@@ -70,6 +70,21 @@ def main():
         return x, w, dy, gw
 
 
+    # the problems hold raw pointers: the outputs p_fwd / p_dgrad allocate must outlive the launches
+    KEEP = []
+    _fwd, _dgrad = ops.p_fwd, ops.p_dgrad
+
+    def keep_fwd(*a, **k):
+        r = _fwd(*a, **k)
+        KEEP.append(r[1:])
+        return r
+
+    def keep_dgrad(*a, **k):
+        r = _dgrad(*a, **k)
+        KEEP.append(r[1:])
+        return r
+
+    ops.p_fwd, ops.p_dgrad = keep_fwd, keep_dgrad
     groups = {
         "FFN2 bwd visn: wgrad+dgrad (768x3072)": lambda t: [ops.p_wgrad(t[0][2], t[0][0], t[0][3], False), ops.p_dgrad(t[0][2], t[0][1])[0]],
         "FFN1 bwd visn: wgrad+dgrad (3072x768)": lambda t: [ops.p_wgrad(t[1][2], t[1][0], t[1][3], False), ops.p_dgrad(t[1][2], t[1][1])[0]],

@@ -10,7 +10,7 @@ import re
 import torch  # noqa: F401  (loads PyTorch's HIP runtime first so both share it)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libxggm_hip.so")
+LIB_PATH = os.environ.get("XGGM_LIB") or os.path.join(_HERE, "csrc", "libxggm_hip.so")  # XGGM_LIB: instrumented builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "xggm.h")
 
 _CT = {

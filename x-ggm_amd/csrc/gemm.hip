@@ -40,7 +40,41 @@ struct GemmArgs {
     int a_mode, b_mode;  // 0 scalar, 1 vector along k, 2 vector along rows
     int xcd_swizzle;
     int batch;
+#ifdef XGGM_STAMP
+    long long* stamp;  // instrumented build (make stamp): 8 cycle-counter slots per workgroup
+    int ablate;        // instrumented build: 1 skips the chunk loop of the epilogue, 2 the whole epilogue
+#endif
 };
+
+#ifdef XGGM_STAMP
+long long* g_stamp = nullptr;
+int g_ablate = 0;
+#define ABLATE(g, bit) ((g).ablate & (bit))
+#define STAMP(g, slot)                                                                                \
+    do {                                                                                              \
+        if ((g).stamp && threadIdx.x == 0)                                                            \
+            (g).stamp[(int64_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + (slot)] = \
+                __builtin_readcyclecounter();                                                         \
+    } while (0)
+#define SET_STAMP(g) ((g).stamp = g_stamp, (g).ablate = g_ablate)
+// slots 5, 6: HW_ID (cu / sh / se fields) and XCC_ID of the workgroup's first wave
+#define STAMP_HW(g)                                                                                   \
+    do {                                                                                              \
+        if ((g).stamp && threadIdx.x == 0) {                                                          \
+            unsigned hw, xcc;                                                                         \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                          \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                        \
+            long long* q = (g).stamp + (int64_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8; \
+            q[5] = hw;                                                                                \
+            q[6] = xcc;                                                                               \
+        }                                                                                             \
+    } while (0)
+#else
+#define STAMP_HW(g)
+#define ABLATE(g, bit) false
+#define STAMP(g, slot)
+#define SET_STAMP(g)
+#endif
 
 template <typename T> struct Tile;
 template <> struct Tile<bf16> {
@@ -227,29 +261,47 @@ template <int R, bool KMAJ> struct OpLds {
     static constexpr int NCH = R / 32;  // 16-byte chunks per thread per k-tile
 };
 
-// Branch-free tile load: addresses are clamped into the operand (rows beyond the edge re-read
-// the last valid row: they only feed output rows/columns the epilogue never stores) and chunks
-// beyond K are redirected to a 16-byte page of zeros -- the select acts on the ADDRESS, never on
-// the loaded data, so nothing depends on a load until its registers are copied to LDS D tiles
-// later and the compiler keeps the loads in flight behind counted s_waitcnt vmcnt(N).
-__device__ __attribute__((aligned(16))) unsigned short g_zero_chunk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+// Branch-free tile load through a buffer descriptor: the hardware range check returns zeros for
+// the chunks beyond K (their offset is pushed past num_records), rows beyond the edge are clamped
+// to the last valid row (they only feed output rows/columns the epilogue never stores).  No select
+// on a pointer and no predicated load: hipcc rewrites both into branches with s_waitcnt vmcnt(0)
+// behind them, which serialises the k-loop on memory latency.  Nothing depends on a load until its
+// registers are copied to LDS D tiles later, so the loads stay in flight behind counted vmcnt(N).
+typedef __attribute__((ext_vector_type(4))) unsigned int uint4_t;
+constexpr int OOB_OFFSET = 0x7ffffff0;
+
+struct OpSrc {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int rs, ks;  // element strides of the row / reduction index
+};
+
+// `base`, `bytes` must be wave-uniform; readfirstlane makes that provable (a descriptor the
+// compiler believes divergent is loaded through a waterfall loop per memory op)
+__device__ __forceinline__ OpSrc make_src(const bf16* base, int64_t bytes, int64_t rs, int64_t ks) {
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    const int nb = __builtin_amdgcn_readfirstlane((int)bytes);
+    OpSrc s;
+    s.rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>((uint64_t)lo | ((uint64_t)hi << 32)), 0, nb, 0x00020000);
+    s.rs = __builtin_amdgcn_readfirstlane((int)rs);
+    s.ks = __builtin_amdgcn_readfirstlane((int)ks);
+    return s;
+}
 
 template <int R, bool KMAJ>
-__device__ __forceinline__ void fast_load(short8_t (&reg)[R / 32], const bf16* __restrict__ base, int64_t rs, int64_t ks,
-                                          int r0, int k0, int Rtot, int K, int tid) {
-    const bf16* zero = reinterpret_cast<const bf16*>(g_zero_chunk);
+__device__ __forceinline__ void fast_load(short8_t (&reg)[R / 32], const OpSrc& src, int r0, int k0, int Rtot, int K, int tid) {
 #pragma unroll
     for (int i = 0; i < R / 32; ++i) {
         const int c = tid + NT * i;
-        const bf16* p;
+        int off;
         if (KMAJ) {
             const int row = min(r0 + (c >> 3), Rtot - 1), kc = k0 + (c & 7) * 8;
-            p = kc < K ? base + (int64_t)row * rs + kc : zero;
+            off = kc < K ? (row * src.rs + kc) * 2 : OOB_OFFSET;
         } else {
             const int kl = k0 + c / (R / 8), rc = min(r0 + (c % (R / 8)) * 8, Rtot - 8);
-            p = kl < K ? base + (int64_t)kl * ks + rc : zero;
+            off = kl < K ? (kl * src.ks + rc) * 2 : OOB_OFFSET;
         }
-        reg[i] = *reinterpret_cast<const short8_t*>(p);
+        reg[i] = __builtin_bit_cast(short8_t, __builtin_amdgcn_raw_buffer_load_b128(src.rsrc, off, 0, 0));
     }
 }
 
@@ -293,6 +345,14 @@ __device__ __forceinline__ bf16x8_t fast_frag(const bf16* lds, int row0, int ks,
     }
 }
 
+// workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also waits
+// vmcnt(0), i.e. for the global prefetches that are supposed to stay in flight across it.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // ---- epilogue of the tuned kernels -------------------------------------------------------------
 // The accumulators of a half tile (BM/2 rows) are parked in LDS as fp32, then every thread walks
 // 8-element row chunks: bias, activation, residual, pre-activation save and the store are done on
@@ -305,6 +365,10 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, const float4_
     constexpr int LDS_LD = BN + 4;
     constexpr int CPR = BN / 8;           // 8-element chunks per row
     constexpr int HALF = BM / 2;
+    constexpr int ITER = HALF * CPR / NT;  // chunks per thread per half tile
+    constexpr int RPI = NT / CPR;          // rows between a thread's consecutive chunks
+    constexpr int BATCH = ITER < 2 ? ITER : 2;  // chunks whose global loads are issued together
+    static_assert(HALF * CPR % NT == 0 && NT % CPR == 0 && ITER % BATCH == 0, "epilogue tiling");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int64_t coff = (int64_t)bz * g.c_bs;
@@ -312,6 +376,15 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, const float4_
                         (!g.residual || reinterpret_cast<uintptr_t>(g.residual) % 16 == 0) &&
                         (!g.preact || reinterpret_cast<uintptr_t>(g.preact) % 16 == 0) &&
                         (!g.aux || reinterpret_cast<uintptr_t>(g.aux) % 16 == 0) && (coff % 8 == 0);
+    bf16* pre = reinterpret_cast<bf16*>(g.preact);
+    const bf16* aux = reinterpret_cast<const bf16*>(g.aux);
+    const bf16* res = reinterpret_cast<const bf16*>(g.residual);
+    // a thread's chunks all sit in one column group (NT is a multiple of CPR): its bias is loaded once
+    const int lc = (tid % CPR) * 8, col = n0 + lc, lr0 = tid / CPR;
+    const bool col_ok = col < g.N;
+    float bias[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias[e] = (g.bias && col + e < g.N) ? g.bias[col + e] : 0.f;
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {
         if ((wid >> 1) == h) {
@@ -319,93 +392,112 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, const float4_
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        stage[(i * 16 + fq * 4 + r) * LDS_LD + wn + j * 16 + fr] = acc[i][j][r];
+                    *reinterpret_cast<float4_t*>(stage + (i * 16 + fr) * LDS_LD + wn + j * 16 + fq * 4) = acc[i][j];
         }
-        __syncthreads();
+        lds_barrier();  // LDS only: global stores of the previous half stay in flight
+        if (h == 0) STAMP(g, 7);
+        if (ABLATE(g, 1)) {
+            if (g.M < 0) reinterpret_cast<float*>(g.C)[tid] = stage[tid];  // never true: keeps the staging alive
+        } else if (vec_ok) {
 #pragma unroll 1
-        for (int c = tid; c < HALF * CPR; c += NT) {
-            const int lr = c / CPR, lc = (c % CPR) * 8;
-            const int row = m0 + h * HALF + lr, col = n0 + lc;
-            if (row >= g.M || col >= g.N) continue;
-            float v[8];
-            {
-                const float4 a = *reinterpret_cast<const float4*>(stage + lr * LDS_LD + lc);
-                const float4 b = *reinterpret_cast<const float4*>(stage + lr * LDS_LD + lc + 4);
-                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-            }
-            const int nval = min(8, g.N - col);
-            const int64_t idx = coff + (int64_t)row * g.ldc + col;
+            for (int it0 = 0; it0 < ITER; it0 += BATCH) {
+                // issue every global load of the batch, then consume: one memory round trip per batch
+                short8_t rres[BATCH], raux[BATCH], rprev[BATCH];
+                float4 p0[BATCH], p1[BATCH];
+                int64_t idx[BATCH];
+                bool ok[BATCH];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = g.alpha * v[e] + ((g.bias && e < nval) ? g.bias[col + e] : 0.f);
-            bf16* pre = reinterpret_cast<bf16*>(g.preact);
-            const bf16* aux = reinterpret_cast<const bf16*>(g.aux);
-            const bf16* res = reinterpret_cast<const bf16*>(g.residual);
-            if (vec_ok) {
-                if (pre) {
-                    short8_t pv;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const bf16 t = __float2bfloat16(v[e]);
-                        pv[e] = __builtin_bit_cast(short, t);
-                        v[e] = __bfloat162float(t);  // the activation sees the value as stored
+                for (int b = 0; b < BATCH; ++b) {
+                    const int row = m0 + h * HALF + lr0 + (it0 + b) * RPI;
+                    ok[b] = col_ok && row < g.M;
+                    idx[b] = coff + (int64_t)row * g.ldc + col;
+                    if (ok[b]) {
+                        if (res) rres[b] = *reinterpret_cast<const short8_t*>(res + idx[b]);
+                        if (g.act == XGGM_ACT_GELU_GRAD) raux[b] = *reinterpret_cast<const short8_t*>(aux + idx[b]);
+                        if (g.accumulate) {
+                            if (g.c_f32) {
+                                const float* c = reinterpret_cast<const float*>(g.C) + idx[b];
+                                p0[b] = *reinterpret_cast<const float4*>(c);
+                                p1[b] = *reinterpret_cast<const float4*>(c + 4);
+                            } else {
+                                rprev[b] = *reinterpret_cast<const short8_t*>(reinterpret_cast<const bf16*>(g.C) + idx[b]);
+                            }
+                        }
                     }
-                    *reinterpret_cast<short8_t*>(pre + idx) = pv;
                 }
-                if (g.act != XGGM_ACT_NONE) {
-                    float ax[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                    if (g.act == XGGM_ACT_GELU_GRAD) {
-                        const short8_t av = *reinterpret_cast<const short8_t*>(aux + idx);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) ax[e] = __bfloat162float(__builtin_bit_cast(bf16, (short)av[e]));
+                for (int b = 0; b < BATCH; ++b) {
+                    if (!ok[b]) continue;
+                    float* sp = stage + (lr0 + (it0 + b) * RPI) * LDS_LD + lc;
+                    float v[8];
+                    {
+                        const float4 a = *reinterpret_cast<const float4*>(sp);
+                        const float4 c4 = *reinterpret_cast<const float4*>(sp + 4);
+                        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c4.x; v[5] = c4.y; v[6] = c4.z; v[7] = c4.w;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = g.alpha * v[e] + bias[e];
+                    if (pre) {
+                        short8_t pv;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const bf16 t = __float2bfloat16(v[e]);
+                            pv[e] = __builtin_bit_cast(short, t);
+                            v[e] = __bfloat162float(t);  // the activation sees the value as stored
+                        }
+                        *reinterpret_cast<short8_t*>(pre + idx[b]) = pv;
                     }
                     if (g.act == XGGM_ACT_GELU) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
                     } else if (g.act == XGGM_ACT_GELU_GRAD) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(ax[e]);
-                    } else {
+                        for (int e = 0; e < 8; ++e)
+                            v[e] *= gelu_grad_f(__bfloat162float(__builtin_bit_cast(bf16, (short)raux[b][e])));
+                    } else if (g.act != XGGM_ACT_NONE) {
 #pragma unroll 1
-                        for (int e = 0; e < 8; ++e) v[e] = act_apply<bf16>(g.act, v[e], ax[e]);
+                        for (int e = 0; e < 8; ++e) v[e] = act_apply<bf16>(g.act, v[e], 0.f);
+                    }
+                    if (res) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += __bfloat162float(__builtin_bit_cast(bf16, (short)rres[b][e]));
+                    }
+                    if (g.colsum) {  // park the final values for the column pass below
+                        *reinterpret_cast<float4*>(sp) = make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4*>(sp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    }
+                    if (g.c_f32) {
+                        float* c = reinterpret_cast<float*>(g.C) + idx[b];
+                        float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
+                        if (g.accumulate) {
+                            o0.x += p0[b].x; o0.y += p0[b].y; o0.z += p0[b].z; o0.w += p0[b].w;
+                            o1.x += p1[b].x; o1.y += p1[b].y; o1.z += p1[b].z; o1.w += p1[b].w;
+                        }
+                        *reinterpret_cast<float4*>(c) = o0;
+                        *reinterpret_cast<float4*>(c + 4) = o1;
+                    } else {
+                        if (g.accumulate) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += __bfloat162float(__builtin_bit_cast(bf16, (short)rprev[b][e]));
+                        }
+                        short8_t ov;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ov[e] = __builtin_bit_cast(short, __float2bfloat16(v[e]));
+                        *reinterpret_cast<short8_t*>(reinterpret_cast<bf16*>(g.C) + idx[b]) = ov;
                     }
                 }
-                if (res) {
-                    const short8_t rv = *reinterpret_cast<const short8_t*>(res + idx);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += __bfloat162float(__builtin_bit_cast(bf16, (short)rv[e]));
-                }
-                if (g.colsum) {  // park the final values for the column pass below
-                    *reinterpret_cast<float4*>(stage + lr * LDS_LD + lc) = make_float4(v[0], v[1], v[2], v[3]);
-                    *reinterpret_cast<float4*>(stage + lr * LDS_LD + lc + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                }
-                if (g.c_f32) {
-                    float* c = reinterpret_cast<float*>(g.C) + idx;
-                    float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
-                    if (g.accumulate) {
-                        const float4 p0 = *reinterpret_cast<const float4*>(c), p1 = *reinterpret_cast<const float4*>(c + 4);
-                        o0.x += p0.x; o0.y += p0.y; o0.z += p0.z; o0.w += p0.w;
-                        o1.x += p1.x; o1.y += p1.y; o1.z += p1.z; o1.w += p1.w;
-                    }
-                    *reinterpret_cast<float4*>(c) = o0;
-                    *reinterpret_cast<float4*>(c + 4) = o1;
-                } else {
-                    bf16* c = reinterpret_cast<bf16*>(g.C) + idx;
-                    if (g.accumulate) {
-                        const short8_t pv = *reinterpret_cast<const short8_t*>(c);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += __bfloat162float(__builtin_bit_cast(bf16, (short)pv[e]));
-                    }
-                    short8_t ov;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) ov[e] = __builtin_bit_cast(short, __float2bfloat16(v[e]));
-                    *reinterpret_cast<short8_t*>(c) = ov;
-                }
-            } else {
+            }
+        } else {
+            // unaligned output (odd N / ldc): element-wise
+#pragma unroll 1
+            for (int it = 0; it < ITER; ++it) {
+                const int lr = lr0 + it * RPI, row = m0 + h * HALF + lr;
+                if (row >= g.M || !col_ok) continue;
+                const int nval = min(8, g.N - col);
+                const int64_t idx = coff + (int64_t)row * g.ldc + col;
 #pragma unroll 1
                 for (int e = 0; e < nval; ++e) {
-                    float x = v[e];
+                    float x = g.alpha * stage[lr * LDS_LD + lc + e] + (g.bias ? g.bias[col + e] : 0.f);
                     if (pre) {
                         pre[idx + e] = __float2bfloat16(x);
                         x = round_to<bf16>(x);
@@ -424,7 +516,8 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, const float4_
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();  // every chunk of the staged half has been read (and parked back for colsum)
+        if (h == 0) STAMP(g, 3);
         if (g.colsum) {
             // bias gradient: column sums of this half tile's stored values, one atomic per column
             const int rows = min(HALF, g.M - (m0 + h * HALF));
@@ -433,17 +526,9 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, const float4_
                 for (int r = 0; r < rows; ++r) sacc += stage[r * LDS_LD + tid];
                 atomicAdd(g.colsum + n0 + tid, sacc);
             }
-            __syncthreads();
+            lds_barrier();
         }
     }
-}
-
-// workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also waits
-// vmcnt(0), i.e. for the global prefetches that are supposed to stay in flight across it.
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
 }
 
 template <int BM, int BN, bool AK, bool BKM, int D>
@@ -460,8 +545,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile_m, int til
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = (wid >> 1) * (BM / 2), wn = (wid & 1) * (BN / 2);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    STAMP(g, 0);
+    STAMP_HW(g);
     const bf16* A = reinterpret_cast<const bf16*>(g.A) + (int64_t)bz * g.a_bs;
     const bf16* B = reinterpret_cast<const bf16*>(g.B) + (int64_t)bz * g.b_bs;
+    // bytes from the (batch) base to the end of the operand: last row / k-row start + its valid length
+    const OpSrc sa = make_src(A, AK ? ((int64_t)(g.M - 1) * g.a_rs + g.K) * 2 : ((int64_t)(g.K - 1) * g.a_ks + g.M) * 2, g.a_rs, g.a_ks);
+    const OpSrc sb = make_src(B, BKM ? ((int64_t)(g.N - 1) * g.b_ns + g.K) * 2 : ((int64_t)(g.K - 1) * g.b_ks + g.N) * 2, g.b_ns, g.b_ks);
 
     float4_t acc[TM][TN];
 #pragma unroll
@@ -474,12 +564,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile_m, int til
     const int nk = ((g.K + 63) / 64 + UNR - 1) / UNR * UNR;
 #pragma unroll
     for (int s = 0; s < D; ++s) {
-        fast_load<BM, AK>(ra[s], A, g.a_rs, g.a_ks, m0, s * 64, g.M, g.K, tid);
-        fast_load<BN, BKM>(rb[s], B, g.b_ns, g.b_ks, n0, s * 64, g.N, g.K, tid);
+        fast_load<BM, AK>(ra[s], sa, m0, s * 64, g.M, g.K, tid);
+        fast_load<BN, BKM>(rb[s], sb, n0, s * 64, g.N, g.K, tid);
     }
     fast_store<BM, AK>(fsm, ra[0], tid);
     fast_store<BN, BKM>(fsm + LA::ELEMS, rb[0], tid);
     lds_barrier();
+    STAMP(g, 1);
     for (int t0 = 0; t0 < nk; t0 += UNR) {
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
@@ -488,8 +579,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile_m, int til
             const bf16* Bc = Ac + LA::ELEMS;
             bf16* An = fsm + ((u + 1) & 1) * STAGE;
             // stage (t % D) was copied to LDS one step ago: refill it with tile t + D
-            fast_load<BM, AK>(ra[u % D], A, g.a_rs, g.a_ks, m0, (t + D) * 64, g.M, g.K, tid);
-            fast_load<BN, BKM>(rb[u % D], B, g.b_ns, g.b_ks, n0, (t + D) * 64, g.N, g.K, tid);
+            fast_load<BM, AK>(ra[u % D], sa, m0, (t + D) * 64, g.M, g.K, tid);
+            fast_load<BN, BKM>(rb[u % D], sb, n0, (t + D) * 64, g.N, g.K, tid);
 #pragma unroll
             for (int ks = 0; ks < 64; ks += 32) {
                 bf16x8_t a[TM], b[TN];
@@ -501,7 +592,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile_m, int til
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                        // operands swapped: the 16x16 block comes out transposed, i.e. lane (fr, fq) holds
+                        // row fr, columns 4 fq .. 4 fq + 3 -- four values that are contiguous in C
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
             }
             fast_store<BM, AK>(An, ra[(u + 1) % D], tid);
             fast_store<BN, BKM>(An + LA::ELEMS, rb[(u + 1) % D], tid);
@@ -509,7 +602,18 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile_m, int til
         }
     }
     // the k-loop ended with a barrier: LDS is free for the staged epilogue
+    STAMP(g, 2);
+    if (ABLATE(g, 2)) {
+        float keep = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (keep == 123.456f) reinterpret_cast<float*>(g.C)[tid] = keep;
+        return;
+    }
     epilogue_staged<BM, BN, TM, TN>(g, acc, m0, n0, bz, reinterpret_cast<float*>(fsm), wm, wn);
+    STAMP(g, 4);
 }
 
 
@@ -521,8 +625,12 @@ __device__ __forceinline__ int xcd_remap(int L, int nb) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// waves per SIMD the register allocation must leave room for: a second (third, fourth) resident
+// workgroup runs its k-loop under this one's prologue and epilogue
+template <int BM, int BN> constexpr int min_waves() { return BM * BN >= 128 * 128 ? 2 : 3; }
+
 template <int BM, int BN, bool AK, bool BKM, int D>
-__global__ __launch_bounds__(NT) void gemm_fast_kernel(GemmArgs g) {
+__global__ __launch_bounds__(NT, (min_waves<BM, BN>())) void gemm_fast_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) bf16 fsm[];
     int tile_m = blockIdx.y, tile_n = blockIdx.x;
     if (g.xcd_swizzle) {
@@ -544,7 +652,7 @@ struct GroupArgs {
     int nprob;
 };
 
-template <int BM, int BN> __global__ __launch_bounds__(NT) void gemm_grouped_kernel(GroupArgs ga) {
+template <int BM, int BN> __global__ __launch_bounds__(NT, (min_waves<BM, BN>())) void gemm_grouped_kernel(GroupArgs ga) {
     extern __shared__ __attribute__((aligned(16))) bf16 fsm[];
     // natural block order: an XCD-contiguous remap would hand whole problems (with different
     // k-loop lengths) to different XCDs and unbalance them
@@ -574,11 +682,18 @@ template <int BM, int BN> int launch_grouped_tile(GroupArgs& ga, hipStream_t str
         total += ceil_div(ga.p[i].M, BM) * ceil_div(ga.p[i].N, BN) * ga.p[i].batch;
     }
     ga.tile_start[ga.nprob] = total;
-    constexpr size_t lds = 2 * sizeof(bf16) * (OpLds<BM, false>::ELEMS + OpLds<BN, false>::ELEMS);
+    // LDS of the largest operand images this group actually uses (r-major images carry padding)
+    size_t lds = 0;
+    for (int i = 0; i < ga.nprob; ++i) {
+        const size_t a = ga.p[i].a_mode == 1 ? OpLds<BM, true>::ELEMS : OpLds<BM, false>::ELEMS;
+        const size_t b = ga.p[i].b_mode == 1 ? OpLds<BN, true>::ELEMS : OpLds<BN, false>::ELEMS;
+        lds = std::max(lds, 2 * sizeof(bf16) * (a + b));
+    }
+    constexpr size_t lds_max = 2 * sizeof(bf16) * (OpLds<BM, false>::ELEMS + OpLds<BN, false>::ELEMS);
     static bool attr_set = false;
-    if (lds > 48 * 1024 && !attr_set) {
+    if (lds_max > 48 * 1024 && !attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_grouped_kernel<BM, BN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         attr_set = true;
     }
     hipLaunchKernelGGL((gemm_grouped_kernel<BM, BN>), dim3(total), dim3(NT), lds, stream, ga);
@@ -608,7 +723,7 @@ template <int BM, int BN, int D> int launch_fast_tile(const GemmArgs& g, int bat
 }
 
 // tile / depth choice.  g_tile_override (xggm_gemm_set_tile) pins one variant for A/B tests:
-// 1 = 64x64 D2, 2 = 64x64 D4, 3 = 128x64 D2, 4 = 128x64 D3, 5 = 128x128 D2; 0 = heuristic.
+// 1 = 64x64 D2, 2 = 64x64 D4, 3 = 128x64 D2, 5 = 128x128 D2, 6-8 = depth 1; 0 = heuristic.
 int g_tile_override = 0;
 inline int launch_fast(const GemmArgs& g, int batch, hipStream_t stream) {
     auto tiles = [&](int bm, int bn) { return (int64_t)ceil_div(g.M, bm) * ceil_div(g.N, bn) * batch; };
@@ -627,7 +742,6 @@ inline int launch_fast(const GemmArgs& g, int batch, hipStream_t stream) {
         case 1: return launch_fast_tile<64, 64, 2>(g, batch, stream);
         case 2: return launch_fast_tile<64, 64, 4>(g, batch, stream);
         case 3: return launch_fast_tile<128, 64, 2>(g, batch, stream);
-        case 4: return launch_fast_tile<128, 64, 3>(g, batch, stream);
         default: return launch_fast_tile<128, 128, 2>(g, batch, stream);
     }
 }
@@ -671,7 +785,7 @@ template <typename T> int launch(GemmArgs g, int batch, hipStream_t stream) {
         g.a_bs = a_bs; g.b_bs = b_bs; g.c_bs = c_bs;                                                                   \
         g.bias = bias; g.residual = residual; g.preact = preact; g.aux = aux; g.colsum = colsum;                      \
         g.act = act; g.c_f32 = c_f32; g.accumulate = accumulate; g.alpha = alpha;                                     \
-        g.a_mode = g.b_mode = 0; g.xcd_swizzle = g_xcd_swizzle; g.batch = batch;                                       \
+        g.a_mode = g.b_mode = 0; g.xcd_swizzle = g_xcd_swizzle; g.batch = batch; SET_STAMP(g); \
         return launch<T>(g, batch, stream);                                                                            \
     }
 
@@ -699,7 +813,7 @@ GemmArgs from_problem(const xggm_gemm_problem& p) {
     g.a_bs = p.a_bs; g.b_bs = p.b_bs; g.c_bs = p.c_bs;
     g.bias = p.bias; g.residual = p.residual; g.preact = p.preact; g.aux = p.aux; g.colsum = p.colsum;
     g.act = p.act; g.c_f32 = p.c_f32; g.accumulate = p.accumulate; g.alpha = p.alpha;
-    g.a_mode = g.b_mode = 0; g.xcd_swizzle = g_xcd_swizzle; g.batch = p.batch;
+    g.a_mode = g.b_mode = 0; g.xcd_swizzle = g_xcd_swizzle; g.batch = p.batch; SET_STAMP(g);
     return g;
 }
 
@@ -743,6 +857,33 @@ extern "C" int xggm_gemm_grouped_bf16(const xggm_gemm_problem* probs, int n, hip
 extern "C" int xggm_gemm_grouped_f32(const xggm_gemm_problem* probs, int n, hipStream_t stream) {
     return grouped<float>(probs, n, stream);
 }
+#ifdef XGGM_STAMP
+// what the runtime thinks: resident workgroups per CU of the grouped kernels at a given dynamic LDS size
+extern "C" int xggm_gemm_occupancy(int tile, int lds_bytes, int* out) {
+    int n = -1;
+    hipError_t e;
+    if (tile == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_grouped_kernel<128, 128>, NT, lds_bytes);
+    else if (tile == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_grouped_kernel<128, 64>, NT, lds_bytes);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_grouped_kernel<64, 64>, NT, lds_bytes);
+    hipDeviceProp_t pr;
+    (void)hipGetDeviceProperties(&pr, 0);
+    out[0] = n;
+    out[1] = (int)pr.maxSharedMemoryPerMultiProcessor;
+    out[2] = (int)pr.sharedMemPerBlock;
+    out[3] = pr.regsPerMultiprocessor;
+    out[4] = pr.regsPerBlock;
+    out[5] = (int)e;
+    return XGGM_OK;
+}
+extern "C" int xggm_gemm_set_ablate(int bits) {
+    g_ablate = bits;
+    return XGGM_OK;
+}
+extern "C" int xggm_gemm_set_stamp(long long* buf) {
+    g_stamp = buf;
+    return XGGM_OK;
+}
+#endif
 extern "C" int xggm_gemm_set_group_tile(int v) {
     g_group_tile = v;
     return XGGM_OK;

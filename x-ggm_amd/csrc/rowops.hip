@@ -87,6 +87,46 @@ __global__ __launch_bounds__(NT) void partial_reduce_kernel(const float* __restr
     }
 }
 
+// the same reduction for a batch of workspaces (deferred second stage of many LN backwards)
+constexpr int MAX_JOBS = 40;
+struct BatchJobs {
+    xggm_reduce_job j[MAX_JOBS];
+    int start[MAX_JOBS + 1];  // first workgroup of each job
+    int n;
+};
+
+__global__ __launch_bounds__(NT) void partial_reduce_batch_kernel(BatchJobs bj) {
+    __shared__ float red[4][64];
+    int ji = 0;
+    for (int k = 1; k < bj.n; ++k)
+        if ((int)blockIdx.x >= bj.start[k]) ji = k;
+    const xggm_reduce_job job = bj.j[ji];
+    const int ci = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int idx = (blockIdx.x - bj.start[ji]) * 64 + ci;
+    const int KH = job.K * job.H;
+    float s = 0.f;
+    if (idx < KH) {
+        const float* p = job.ws + idx;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int b = sl;
+        for (; b + 12 < job.nblk; b += 16) {
+            a0 += p[(int64_t)b * KH];
+            a1 += p[(int64_t)(b + 4) * KH];
+            a2 += p[(int64_t)(b + 8) * KH];
+            a3 += p[(int64_t)(b + 12) * KH];
+        }
+        for (; b < job.nblk; b += 4) a0 += p[(int64_t)b * KH];
+        s = (a0 + a1) + (a2 + a3);
+    }
+    red[sl][ci] = s;
+    __syncthreads();
+    if (sl == 0 && idx < KH) {
+        const int k = idx / job.H, c = idx % job.H;
+        float* t = job.target[k];
+        if (t) t[c] += (red[0][ci] + red[1][ci]) + (red[2][ci] + red[3][ci]);
+    }
+}
+
 // ------------------------------------------------------------------------------- LN fwd
 template <typename T, int NV>
 __global__ __launch_bounds__(NT) void ln_fwd_kernel(const T* in, const float* __restrict__ bias,
@@ -800,6 +840,26 @@ size_t ws_colsum(int M, int N) { return sizeof(float) * (size_t)ceil_div(M, CS_R
 
 ROW_API(f32, float)
 ROW_API(bf16, bf16)
+
+extern "C" int xggm_partial_reduce_batch(const xggm_reduce_job* jobs, int n, hipStream_t stream) {
+    XGGM_REQUIRE(jobs && n > 0, "xggm_partial_reduce_batch: no jobs");
+    for (int i0 = 0; i0 < n; i0 += MAX_JOBS) {
+        BatchJobs bj;
+        bj.n = std::min(MAX_JOBS, n - i0);
+        int total = 0;
+        for (int i = 0; i < bj.n; ++i) {
+            const xggm_reduce_job& j = jobs[i0 + i];
+            XGGM_REQUIRE(j.ws && j.nblk > 0 && j.K > 0 && j.K <= 3 && j.H > 0, "xggm_partial_reduce_batch: bad job %d", i0 + i);
+            bj.j[i] = j;
+            bj.start[i] = total;
+            total += ceil_div(j.K * j.H, 64);
+        }
+        bj.start[bj.n] = total;
+        hipLaunchKernelGGL(partial_reduce_batch_kernel, dim3(total), dim3(NT), 0, stream, bj);
+        if (int e = xggm_check_launch("xggm_partial_reduce_batch")) return e;
+    }
+    return XGGM_OK;
+}
 
 // workspace sizes (bytes) of the backward row kernels: K partial rows per workgroup
 extern "C" size_t xggm_ln_bwd_workspace_bytes(int M, int H) { return ws_ln(M, H); }

@@ -26,6 +26,37 @@ class Runtime:
         self.p_hidden = 0.1   # config.hidden_dropout_prob (src/lxrt/modeling.py:196)
         self.p_attn = 0.1     # config.attention_probs_dropout_prob
         self.p_readout = 0.5  # GCN/GIN read-out dropout (src/module/gcn.py:33)
+        self.pending = []     # deferred second stages of the LN backwards of the running backward pass
+        self._task = -1       # autograd graph task the pending jobs belong to
+
+    def defer_list(self):
+        """list the LN backwards of the running autograd backward append their reduce jobs to; the
+        engine calls ``flush`` once when that backward has finished (before anything reads .grad)."""
+        task = torch._C._current_graph_task_id()
+        if task == -1:
+            return None  # not inside a backward pass: the caller reduces immediately
+        if task != self._task:
+            self.pending = []  # jobs of a backward that died before its callback ran are dropped
+            self._task = task
+            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+        return self.pending
+
+    def flush(self):
+        self._task = -1
+        jobs, self.pending = self.pending, []
+        while jobs:
+            # one writer per gradient vector and launch: a second job on the same targets (the shared
+            # cross-attention module is applied twice per layer) waits for the next launch
+            seen, now, later = set(), [], []
+            for j in jobs:
+                key = tuple(t.data_ptr() for t in j[3] if t is not None)
+                if seen.isdisjoint(key):
+                    seen.update(key)
+                    now.append(j)
+                else:
+                    later.append(j)
+            ops.reduce_batch(now)
+            jobs = later
 
     def p(self, p):
         return p if self.training else 0.0
@@ -182,7 +213,7 @@ def g_attn_bwd(rt, saved, dy, defer_wgrad=False):
     d_h, d_res = ops.ln_bwd(dy.contiguous(), z, stats, outm.LayerNorm.weight.data,
                             a.atomic_target(outm.LayerNorm.weight), a.atomic_target(outm.LayerNorm.bias),
                             a.atomic_target(outm.dense.bias), want_dres=True, p_pre=p_hid, rng=rt.rng,
-                            sid_pre=outm._sid + salt)
+                            sid_pre=outm._sid + salt, defer=rt.defer_list())
     pd, d_c = ops.p_dgrad(d_h, a.w(outm.dense.weight))
     if defer_wgrad:
         yield [pd]
@@ -238,7 +269,7 @@ def g_ffn_bwd(rt, saved, dy):
     d_h, d_res = ops.ln_bwd(dy.contiguous(), z, stats, outm.LayerNorm.weight.data,
                             a.atomic_target(outm.LayerNorm.weight), a.atomic_target(outm.LayerNorm.bias),
                             a.atomic_target(outm.dense.bias), want_dres=True, p_pre=p_hid, rng=rt.rng,
-                            sid_pre=outm._sid)
+                            sid_pre=outm._sid, defer=rt.defer_list())
     # d_u = (d_h W_2) * gelu'(u); its column sums (= grad of b_1) are taken in the same epilogue
     pd, d_u = ops.p_dgrad(d_h, a.w(outm.dense.weight), gelu_aux=u, colsum=a.atomic_target(inter.dense.bias))
     yield [_p_wgrad(rt, d_h, act, outm.dense.weight), pd]

@@ -247,11 +247,29 @@ def ln_fwd(x, bias, residual, gamma, beta, eps, p_pre=0.0, p_post=0.0, rng=None,
     return out, z, stats
 
 
+class ReduceJob(_ct.Structure):
+    """mirror of ``xggm_reduce_job`` (include/xggm.h)"""
+    _fields_ = [("ws", _ct.c_void_p), ("nblk", _ct.c_int), ("K", _ct.c_int), ("H", _ct.c_int),
+                ("target", _ct.c_void_p * 3)]
+
+
+def reduce_batch(jobs):
+    """second stage of deferred LN backwards: ``jobs`` = [(ws, nblk, H, (dgamma, dbeta, dbias))]."""
+    arr = (ReduceJob * len(jobs))()
+    for a, (ws, nblk, H, tg) in zip(arr, jobs):
+        a.ws, a.nblk, a.K, a.H = ptr(ws), nblk, 3, H
+        for k in range(3):
+            a.target[k] = ptr(tg[k])
+    call("xggm_partial_reduce_batch", _ct.cast(arr, _ct.c_void_p), len(jobs), stream())
+
+
 def ln_bwd(dy, z, stats, gamma, dgamma, dbeta, dbias, want_din=True, want_dres=False, d_res=None,
-           p_pre=0.0, p_post=0.0, rng=None, sid_pre=0, sid_post=0, out_scale=1.0, gelu_aux=None):
+           p_pre=0.0, p_post=0.0, rng=None, sid_pre=0, sid_post=0, out_scale=1.0, gelu_aux=None, defer=None):
     """Returns (d_in, d_res).  dgamma/dbeta/dbias (fp32, may be None) are accumulated.
     If ``d_res`` is given the residual gradient is ADDED into it.  ``gelu_aux`` = the
-    pre-activation u when the LN input was gelu(u): d_in/dbias become grads of u."""
+    pre-activation u when the LN input was gelu(u): d_in/dbias become grads of u.
+    ``defer``: a list; the parameter-gradient sums are then left in the workspace and a job for
+    ``reduce_batch`` is appended instead of running the second-stage kernel now."""
     _c(dy), _c(z, dy.dtype)
     M, H = dy.shape
     assert z.shape == dy.shape and tuple(stats.shape) == (M, 2)
@@ -266,8 +284,12 @@ def ln_bwd(dy, z, stats, gamma, dgamma, dbeta, dbias, want_din=True, want_dres=F
     if d_res is not None:
         assert d_res.shape == dy.shape and d_res.dtype == dy.dtype and d_res.is_contiguous()
     ws, nb = _ws(_lib.lib.xggm_ln_bwd_workspace_bytes(M, H), dy.device)
+    now = (dgamma, dbeta, dbias)
+    if defer is not None and any(t is not None for t in now):
+        defer.append((ws, nb // (12 * H), H, now))
+        now = (None, None, None)
     call("xggm_ln_bwd_" + sfx(dy.dtype), ptr(dy), ptr(z), ptr(stats), ptr(gamma), ptr(d_in), ptr(d_res),
-         ptr(dgamma), ptr(dbeta), ptr(dbias), M, H, float(p_pre), float(p_post), ptr(rng), sid_pre, sid_post,
+         ptr(now[0]), ptr(now[1]), ptr(now[2]), M, H, float(p_pre), float(p_post), ptr(rng), sid_pre, sid_post,
          float(out_scale), int(acc), ptr(gelu_aux), ptr(ws), nb, stream())
     return d_in, d_res
 
