@@ -838,13 +838,37 @@ template <typename T> int grouped(const xggm_gemm_problem* probs, int n, hipStre
             if (int e = launch<T>(from_problem(probs[i]), probs[i].batch, stream)) return e;
         return XGGM_OK;
     }
-    int64_t t128 = 0, t12864 = 0;
-    for (int i = 0; i < n; ++i) {
-        t128 += (int64_t)ceil_div(ga.p[i].M, 128) * ceil_div(ga.p[i].N, 128) * ga.p[i].batch;
-        t12864 += (int64_t)ceil_div(ga.p[i].M, 128) * ceil_div(ga.p[i].N, 64) * ga.p[i].batch;
-    }
+    // tile choice from a launch-time model fitted to tools/gemm_ktime.py and tools/bench_gemm.py on
+    // MI355X (microseconds): T = max(a + b r + s W, f + k nk_max), with r = tiles per CU,
+    // W = 64-deep k-tiles per CU and the second term the longest single tile (one CU's critical
+    // path: long-K problems need small tiles).  Big tiles run the k-loop ~1.3x more efficiently
+    // per flop, small ones have the shorter critical path and fill the CUs of a small group.
+    struct TileModel { int bm, bn; float a, b, s, f, k; };
+    static const TileModel models[3] = {{64, 64, 3.3f, 1.2f, 0.19f, 5.0f, 0.28f},
+                                        {128, 64, 4.2f, 2.0f, 0.37f, 5.6f, 0.56f},
+                                        {128, 128, 2.3f, 6.1f, 0.71f, 8.4f, 0.75f}};
     int v = g_group_tile;
-    if (v == 0) v = t128 >= 240 ? 3 : (t12864 >= 240 ? 2 : 1);
+    if (v == 0) {
+        float best = 0.f;
+        for (int c = 0; c < 3; ++c) {
+            const TileModel& tm = models[c];
+            double tiles = 0, work = 0;
+            int nkmax = 0;
+            for (int i = 0; i < n; ++i) {
+                const double t = (double)ceil_div(ga.p[i].M, tm.bm) * ceil_div(ga.p[i].N, tm.bn) * ga.p[i].batch;
+                const int nk = ceil_div(ga.p[i].K, 64);
+                tiles += t;
+                work += t * nk;
+                nkmax = std::max(nkmax, nk);
+            }
+            const float r = std::max(1.0, tiles / 256.0);
+            const float est = std::max(tm.a + tm.b * r + tm.s * (float)(work / 256.0), tm.f + tm.k * nkmax);
+            if (v == 0 || est < best) {
+                best = est;
+                v = c + 1;
+            }
+        }
+    }
     if (v == 3) return launch_grouped_tile<128, 128>(ga, stream);
     if (v == 2) return launch_grouped_tile<128, 64>(ga, stream);
     return launch_grouped_tile<64, 64>(ga, stream);
