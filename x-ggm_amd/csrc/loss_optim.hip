@@ -150,9 +150,18 @@ __global__ __launch_bounds__(NT) void bce_bwd_kernel(const float* __restrict__ l
 __global__ __launch_bounds__(NT) void sqnorm_kernel(const float* __restrict__ g, int64_t n, float* out) {
     float acc = 0.f;
     const int64_t n4 = n >> 2;
-    const float4* g4 = reinterpret_cast<const float4*>(g);
-    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT) {
-        const float4 v = g4[i];
+    typedef float __attribute__((ext_vector_type(4))) f4;
+    const f4* g4 = reinterpret_cast<const f4*>(g);
+    const int64_t stride = (int64_t)gridDim.x * NT;
+    int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
+    // four independent 16-byte loads in flight per thread
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const f4 a = g4[i], b = g4[i + stride], c = g4[i + 2 * stride], d = g4[i + 3 * stride];
+        acc += (a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w) + (b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w) +
+               (c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w) + (d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w);
+    }
+    for (; i < n4; i += stride) {
+        const f4 v = g4[i];
         acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
@@ -177,6 +186,10 @@ struct AdamArgs {
     float b1, b2, eps, wd;
 };
 
+// One float4 of each of p, g, m, v per step; UNR independent float4 quadruples per thread and
+// iteration (loads issued before any use).  g is read once and m, v, shadow are not re-read before the
+// next step: non-temporal accesses keep them from displacing the weights' bf16 shadow in L2/MALL.
+template <int UNR, bool NTMP>
 __global__ __launch_bounds__(NT) void bertadam_kernel(AdamArgs a) {
     float coef = 1.f;
     if (a.sqnorm) {
@@ -185,31 +198,53 @@ __global__ __launch_bounds__(NT) void bertadam_kernel(AdamArgs a) {
     }
     const float lr = a.lr * (a.lr_scale ? *a.lr_scale : 1.f);
     const int64_t n4 = a.n >> 2;
-    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT) {
-        float4 p = reinterpret_cast<float4*>(a.p)[i];
-        const float4 g = reinterpret_cast<const float4*>(a.g)[i];
-        float4 m = reinterpret_cast<float4*>(a.m)[i];
-        float4 v = reinterpret_cast<float4*>(a.v)[i];
-        float* pp = &p.x;
-        const float* gg = &g.x;
-        float* mm = &m.x;
-        float* vv = &v.x;
+    typedef float __attribute__((ext_vector_type(4))) f4;
+    typedef short __attribute__((ext_vector_type(4))) s4;
+    const int64_t stride = (int64_t)gridDim.x * NT;
+    for (int64_t i0 = (int64_t)blockIdx.x * NT + threadIdx.x; i0 < n4; i0 += stride * UNR) {
+        f4 p[UNR], g[UNR], m[UNR], v[UNR];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float gk = gg[k] * coef;
-            mm[k] = mm[k] * a.b1 + (1.f - a.b1) * gk;
-            vv[k] = vv[k] * a.b2 + (1.f - a.b2) * gk * gk;
-            const float u = mm[k] / (sqrtf(vv[k]) + a.eps) + a.wd * pp[k];
-            pp[k] -= lr * u;
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i < n4) {
+                p[u] = reinterpret_cast<const f4*>(a.p)[i];
+                if (NTMP) {
+                    g[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(a.g) + i);
+                    m[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(a.m) + i);
+                    v[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(a.v) + i);
+                } else {
+                    g[u] = reinterpret_cast<const f4*>(a.g)[i];
+                    m[u] = reinterpret_cast<const f4*>(a.m)[i];
+                    v[u] = reinterpret_cast<const f4*>(a.v)[i];
+                }
+            }
         }
-        reinterpret_cast<float4*>(a.p)[i] = p;
-        reinterpret_cast<float4*>(a.m)[i] = m;
-        reinterpret_cast<float4*>(a.v)[i] = v;
-        if (a.shadow) {
-            bf16x4 s;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) s.v[k] = __float2bfloat16(pp[k]);
-            reinterpret_cast<bf16x4*>(a.shadow)[i] = s;
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i >= n4) continue;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float gk = g[u][k] * coef;
+                m[u][k] = m[u][k] * a.b1 + (1.f - a.b1) * gk;
+                v[u][k] = v[u][k] * a.b2 + (1.f - a.b2) * gk * gk;
+                const float upd = m[u][k] / (sqrtf(v[u][k]) + a.eps) + a.wd * p[u][k];
+                p[u][k] -= lr * upd;
+            }
+            reinterpret_cast<f4*>(a.p)[i] = p[u];
+            if (NTMP) {
+                __builtin_nontemporal_store(m[u], reinterpret_cast<f4*>(a.m) + i);
+                __builtin_nontemporal_store(v[u], reinterpret_cast<f4*>(a.v) + i);
+            } else {
+                reinterpret_cast<f4*>(a.m)[i] = m[u];
+                reinterpret_cast<f4*>(a.v)[i] = v[u];
+            }
+            if (a.shadow) {
+                s4 sh;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sh[k] = __builtin_bit_cast(short, __float2bfloat16(p[u][k]));
+                reinterpret_cast<s4*>(a.shadow)[i] = sh;
+            }
         }
     }
     if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {
@@ -330,7 +365,9 @@ extern "C" int xggm_bertadam_f32(float* p, const float* g, float* m, float* v, v
                  "xggm_bertadam_f32: pointers must be 16-byte aligned");
     XGGM_REQUIRE(!shadow_bf16 || reinterpret_cast<uintptr_t>(shadow_bf16) % 8 == 0, "xggm_bertadam_f32: shadow misaligned");
     AdamArgs a{p, g, m, v, (bf16*)shadow_bf16, n, sqnorm, max_norm, lr, lr_scale, b1, b2, eps, weight_decay};
-    hipLaunchKernelGGL(bertadam_kernel, dim3(grid1d(n / 4 + 1, 4096)), dim3(NT), 0, st, a);
+    // measured on MI355X (tools/bench_adam.py, 110 M parameters): 4.7 TB/s with plain accesses and a 4096-block
+    // grid-stride loop, 6.3 TB/s with non-temporal g/m/v and one or two float4 quadruples per thread
+    hipLaunchKernelGGL((bertadam_kernel<2, true>), dim3(grid1d(n / 8 + 1, 65536)), dim3(NT), 0, st, a);
     return xggm_check_launch("xggm_bertadam_f32");
 }
 
