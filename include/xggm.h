@@ -156,6 +156,46 @@ int xggm_ln_bwd_bf16(const void* dy, const void* z, const float* stats, const fl
                      float* dgamma, float* dbeta, float* dbias, int M, int H, float p_pre, float p_post,
                      const uint64_t* rng, uint32_t sid_pre, uint32_t sid_post, float out_scale, int accumulate_dres,
                      const void* gelu_aux, float* ws, size_t ws_bytes, xggm_stream_t stream);
+/* Grouped forms: up to 4 independent row sets with the same H, eps, dropout rates and scaling (the
+ * language and the vision stream of one LXMERT layer, src/lxrt/modeling.py:494-516) in ONE launch;
+ * more than 4 problems are launched in consecutive groups.  Fields as the arguments above. */
+typedef struct xggm_ln_fwd_problem {
+    const void* in;
+    const float* bias;
+    const void* residual;
+    const float* gamma;
+    const float* beta;
+    void* out;
+    void* z_out;
+    float* stats;
+    int M;
+    uint32_t sid_pre, sid_post;
+} xggm_ln_fwd_problem;
+typedef struct xggm_ln_bwd_problem {
+    const void* dy;
+    const void* z;
+    const float* stats;
+    const float* gamma;
+    void* d_in;
+    void* d_res;
+    float* dgamma; /* all three NULL: sums stay in ws for xggm_partial_reduce_batch */
+    float* dbeta;
+    float* dbias;
+    const void* gelu_aux;
+    float* ws;
+    size_t ws_bytes;
+    int M;
+    uint32_t sid_pre, sid_post;
+    int accumulate_dres;
+} xggm_ln_bwd_problem;
+int xggm_ln_fwd_grouped_f32(const xggm_ln_fwd_problem* probs, int n, int H, float eps, float p_pre, float p_post,
+                            const uint64_t* rng, int accumulate, float out_scale, xggm_stream_t stream);
+int xggm_ln_fwd_grouped_bf16(const xggm_ln_fwd_problem* probs, int n, int H, float eps, float p_pre, float p_post,
+                             const uint64_t* rng, int accumulate, float out_scale, xggm_stream_t stream);
+int xggm_ln_bwd_grouped_f32(const xggm_ln_bwd_problem* probs, int n, int H, float p_pre, float p_post,
+                            const uint64_t* rng, float out_scale, xggm_stream_t stream);
+int xggm_ln_bwd_grouped_bf16(const xggm_ln_bwd_problem* probs, int n, int H, float p_pre, float p_post,
+                             const uint64_t* rng, float out_scale, xggm_stream_t stream);
 /* workspaces (bytes) of the backward row kernels: they hold one partial row per workgroup and
  * reduced vector, summed by a second kernel instead of contended atomics */
 size_t xggm_ln_bwd_workspace_bytes(int M, int H);

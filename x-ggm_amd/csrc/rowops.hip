@@ -128,17 +128,40 @@ __global__ __launch_bounds__(NT) void partial_reduce_batch_kernel(BatchJobs bj) 
 }
 
 // ------------------------------------------------------------------------------- LN fwd
+// Up to MAX_SEG independent row sets (the language and the vision stream of one layer) share a
+// launch: each is far too small to fill the GPU and the launches are latency-bound.
+constexpr int MAX_SEG = 4;
+struct LnFwdGroup {
+    xggm_ln_fwd_problem s[MAX_SEG];
+    int start[MAX_SEG + 1];  // first workgroup of each segment
+    int n;
+};
+
 template <typename T, int NV>
-__global__ __launch_bounds__(NT) void ln_fwd_kernel(const T* in, const float* __restrict__ bias,
-                                                    const T* __restrict__ residual, const float* __restrict__ gamma,
-                                                    const float* __restrict__ beta, T* out, T* z_out, float* stats, int M,
-                                                    int H, float eps, DropArgs d, int accumulate, float out_scale) {
+__global__ __launch_bounds__(NT) void ln_fwd_kernel(LnFwdGroup G, int H, float eps, float p_pre, float p_post,
+                                                    const uint64_t* rng, int accumulate, float out_scale) {
+    int si = 0;
+#pragma unroll
+    for (int k = 1; k < MAX_SEG; ++k)
+        if (k < G.n && (int)blockIdx.x >= G.start[k]) si = k;
+    const xggm_ln_fwd_problem sg = G.s[si];
+    const T* in = reinterpret_cast<const T*>(sg.in);
+    const float* __restrict__ bias = sg.bias;
+    const T* __restrict__ residual = reinterpret_cast<const T*>(sg.residual);
+    const float* __restrict__ gamma = sg.gamma;
+    const float* __restrict__ beta = sg.beta;
+    T* out = reinterpret_cast<T*>(sg.out);
+    T* z_out = reinterpret_cast<T*>(sg.z_out);
+    float* stats = sg.stats;
+    const int M = sg.M;
+    const DropArgs d{p_pre, p_post, rng, sg.sid_pre, sg.sid_post};
+    const int blk = blockIdx.x - G.start[si], nblk = G.start[si + 1] - G.start[si];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     uint64_t seed, off;
     rng_load(d.rng, seed, off);
     const float ik_pre = d.p_pre > 0.f ? 1.f / (1.f - d.p_pre) : 1.f;
     const float ik_post = d.p_post > 0.f ? 1.f / (1.f - d.p_post) : 1.f;
-    for (int row = blockIdx.x * WPB + wid; row < M; row += gridDim.x * WPB) {
+    for (int row = blk * WPB + wid; row < M; row += nblk * WPB) {
         const int64_t rb = (int64_t)row * H;
         float z[NV][4];
         float sum = 0.f;
@@ -225,12 +248,31 @@ __global__ __launch_bounds__(NT) void ln_fwd_kernel(const T* in, const float* __
 // dy: gradient w.r.t. `out`.  Produces d_in (grad of `in`, i.e. through drop_pre), d_res
 // (grad of `residual`), and accumulates dgamma / dbeta / dbias (bias of `in`) with one fp32
 // atomic per column per wave after an in-register partial sum over the wave's rows.
+struct LnBwdGroup {
+    xggm_ln_bwd_problem s[MAX_SEG];
+    int start[MAX_SEG + 1];
+    int n;
+};
+
 template <typename T, int NV>
-__global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ z,
-                                                    const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                    T* d_in, T* d_res, float* ws, int M, int H, DropArgs d,
-                                                    float out_scale, int accumulate_dres,
-                                                    const T* __restrict__ gelu_aux) {
+__global__ __launch_bounds__(NT) void ln_bwd_kernel(LnBwdGroup G, int H, float p_pre, float p_post, const uint64_t* rng,
+                                                    float out_scale) {
+    int si = 0;
+#pragma unroll
+    for (int k = 1; k < MAX_SEG; ++k)
+        if (k < G.n && (int)blockIdx.x >= G.start[k]) si = k;
+    const xggm_ln_bwd_problem sg = G.s[si];
+    const T* __restrict__ dy = reinterpret_cast<const T*>(sg.dy);
+    const T* __restrict__ z = reinterpret_cast<const T*>(sg.z);
+    const float* __restrict__ stats = sg.stats;
+    const float* __restrict__ gamma = sg.gamma;
+    T* d_in = reinterpret_cast<T*>(sg.d_in);
+    T* d_res = reinterpret_cast<T*>(sg.d_res);
+    float* ws = sg.ws;
+    const int M = sg.M, accumulate_dres = sg.accumulate_dres;
+    const T* __restrict__ gelu_aux = reinterpret_cast<const T*>(sg.gelu_aux);
+    const DropArgs d{p_pre, p_post, rng, sg.sid_pre, sg.sid_post};
+    const int blk = blockIdx.x - G.start[si], nblk = G.start[si + 1] - G.start[si];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     uint64_t seed, off;
     rng_load(d.rng, seed, off);
@@ -244,7 +286,7 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ dy, co
         for (int i = 0; i < 4; ++i) pg[v][i] = pb[v][i] = pbias[v][i] = 0.f;
         if (c < H) load4(gamma + c, g4[v]);
     }
-    for (int row = blockIdx.x * WPB + wid; row < M; row += gridDim.x * WPB) {
+    for (int row = blk * WPB + wid; row < M; row += nblk * WPB) {
         const int64_t rb = (int64_t)row * H;
         const float mean = stats[2 * row], rstd = stats[2 * row + 1];
         float dyn[NV][4], xh[NV][4];
@@ -313,7 +355,7 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ dy, co
         }
     }
     extern __shared__ __attribute__((aligned(16))) float red_lds[];
-    float* wsb = ws + (int64_t)blockIdx.x * 3 * H;
+    float* wsb = ws + (int64_t)blk * 3 * H;
     block_store_partial<NV>(pg, red_lds, wsb, H, lane, wid);
     block_store_partial<NV>(pb, red_lds, wsb + H, H, lane, wid);
     block_store_partial<NV>(pbias, red_lds, wsb + 2 * H, H, lane, wid);
@@ -646,18 +688,37 @@ inline int check_row_shape(const char* who, int M, int H) {
 }
 
 template <typename T>
+int ln_fwd_grouped(const xggm_ln_fwd_problem* probs, int n, int H, float eps, float p_pre, float p_post, const uint64_t* rng,
+                   int accumulate, float out_scale, hipStream_t st) {
+    XGGM_REQUIRE(probs && n > 0, "xggm_ln_fwd: no problems");
+    XGGM_REQUIRE((p_pre == 0.f && p_post == 0.f) || rng, "xggm_ln_fwd: dropout needs an rng state");
+    XGGM_REQUIRE(p_pre >= 0.f && p_pre < 1.f && p_post >= 0.f && p_post < 1.f, "xggm_ln_fwd: bad dropout p");
+    for (int i0 = 0; i0 < n; i0 += MAX_SEG) {
+        LnFwdGroup G;
+        G.n = std::min(MAX_SEG, n - i0);
+        int total = 0;
+        for (int i = 0; i < G.n; ++i) {
+            const xggm_ln_fwd_problem& q = probs[i0 + i];
+            if (int e = check_row_shape("xggm_ln_fwd", q.M, H)) return e;
+            XGGM_REQUIRE(q.in && q.gamma && q.beta && q.out, "xggm_ln_fwd: null pointer");
+            G.s[i] = q;
+            G.start[i] = total;
+            total += rows_grid(q.M, 4096);
+        }
+        G.start[G.n] = total;
+        DISPATCH_NV(H, hipLaunchKernelGGL((ln_fwd_kernel<T, NV>), dim3(total), dim3(NT), 0, st, G, H, eps, p_pre, p_post, rng,
+                                           accumulate, out_scale));
+        if (int e = xggm_check_launch("xggm_ln_fwd")) return e;
+    }
+    return XGGM_OK;
+}
+
+template <typename T>
 int ln_fwd(const void* in, const float* bias, const void* residual, const float* gamma, const float* beta, void* out,
            void* z_out, float* stats, int M, int H, float eps, float p_pre, float p_post, const uint64_t* rng,
            uint32_t s_pre, uint32_t s_post, int accumulate, float out_scale, hipStream_t st) {
-    if (int e = check_row_shape("xggm_ln_fwd", M, H)) return e;
-    XGGM_REQUIRE(in && gamma && beta && out, "xggm_ln_fwd: null pointer");
-    XGGM_REQUIRE((p_pre == 0.f && p_post == 0.f) || rng, "xggm_ln_fwd: dropout needs an rng state");
-    XGGM_REQUIRE(p_pre >= 0.f && p_pre < 1.f && p_post >= 0.f && p_post < 1.f, "xggm_ln_fwd: bad dropout p");
-    DropArgs d{p_pre, p_post, rng, s_pre, s_post};
-    DISPATCH_NV(H, hipLaunchKernelGGL((ln_fwd_kernel<T, NV>), dim3(rows_grid(M, 4096)), dim3(NT), 0, st, (const T*)in, bias,
-                                       (const T*)residual, gamma, beta, (T*)out, (T*)z_out, stats, M, H, eps, d, accumulate,
-                                       out_scale));
-    return xggm_check_launch("xggm_ln_fwd");
+    const xggm_ln_fwd_problem q{in, bias, residual, gamma, beta, out, z_out, stats, M, s_pre, s_post};
+    return ln_fwd_grouped<T>(&q, 1, H, eps, p_pre, p_post, rng, accumulate, out_scale, st);
 }
 
 inline size_t bwd_ws_bytes(int M, int H, int K) { return sizeof(float) * (size_t)rows_grid(M, 512) * K * H; }
@@ -667,28 +728,50 @@ inline void launch_reduce(const float* ws, int nblk, int K, int H, const ReduceT
 }
 
 template <typename T>
+int ln_bwd_grouped(const xggm_ln_bwd_problem* probs, int n, int H, float p_pre, float p_post, const uint64_t* rng,
+                   float out_scale, hipStream_t st) {
+    XGGM_REQUIRE(probs && n > 0, "xggm_ln_bwd: no problems");
+    XGGM_REQUIRE((p_pre == 0.f && p_post == 0.f) || rng, "xggm_ln_bwd: dropout needs an rng state");
+    for (int i0 = 0; i0 < n; i0 += MAX_SEG) {
+        LnBwdGroup G;
+        G.n = std::min(MAX_SEG, n - i0);
+        int total = 0;
+        for (int i = 0; i < G.n; ++i) {
+            const xggm_ln_bwd_problem& q = probs[i0 + i];
+            if (int e = check_row_shape("xggm_ln_bwd", q.M, H)) return e;
+            XGGM_REQUIRE(q.dy && q.z && q.stats && q.gamma, "xggm_ln_bwd: null pointer");
+            XGGM_REQUIRE(q.ws && q.ws_bytes >= bwd_ws_bytes(q.M, H, 3), "xggm_ln_bwd: workspace of %zu bytes needed, got %zu",
+                         bwd_ws_bytes(q.M, H, 3), (size_t)q.ws_bytes);
+            G.s[i] = q;
+            G.start[i] = total;
+            total += rows_grid(q.M, 512);
+        }
+        G.start[G.n] = total;
+        DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), dim3(total), dim3(NT), sizeof(float) * WPB * H, st, G, H,
+                                           p_pre, p_post, rng, out_scale));
+        if (int e = xggm_check_launch("xggm_ln_bwd")) return e;
+        for (int i = 0; i < G.n; ++i) {
+            const xggm_ln_bwd_problem& q = G.s[i];
+            if (q.dgamma || q.dbeta || q.dbias) {
+                ReduceTargets tg{};
+                tg.t[0] = q.dgamma; tg.t[1] = q.dbeta; tg.t[2] = q.dbias;
+                tg.stride[0] = tg.stride[1] = tg.stride[2] = 1;
+                launch_reduce(q.ws, G.start[i + 1] - G.start[i], 3, H, tg, st);
+                if (int e = xggm_check_launch("xggm_ln_bwd(reduce)")) return e;
+            }
+        }
+    }
+    return XGGM_OK;
+}
+
+template <typename T>
 int ln_bwd(const void* dy, const void* z, const float* stats, const float* gamma, void* d_in, void* d_res, float* dgamma,
            float* dbeta, float* dbias, int M, int H, float p_pre, float p_post, const uint64_t* rng, uint32_t s_pre,
            uint32_t s_post, float out_scale, int accumulate_dres, const void* gelu_aux, float* ws, size_t ws_bytes,
            hipStream_t st) {
-    if (int e = check_row_shape("xggm_ln_bwd", M, H)) return e;
-    XGGM_REQUIRE(dy && z && stats && gamma, "xggm_ln_bwd: null pointer");
-    XGGM_REQUIRE((p_pre == 0.f && p_post == 0.f) || rng, "xggm_ln_bwd: dropout needs an rng state");
-    XGGM_REQUIRE(ws && ws_bytes >= bwd_ws_bytes(M, H, 3), "xggm_ln_bwd: workspace of %zu bytes needed, got %zu",
-                 bwd_ws_bytes(M, H, 3), ws_bytes);
-    DropArgs d{p_pre, p_post, rng, s_pre, s_post};
-    const int grid = rows_grid(M, 512);
-    DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), dim3(grid), dim3(NT), sizeof(float) * WPB * H, st,
-                                       (const T*)dy, (const T*)z, stats, gamma, (T*)d_in, (T*)d_res, ws, M, H, d,
-                                       out_scale, accumulate_dres, (const T*)gelu_aux));
-    if (int e = xggm_check_launch("xggm_ln_bwd")) return e;
-    if (dgamma || dbeta || dbias) {
-        ReduceTargets tg{};
-        tg.t[0] = dgamma; tg.t[1] = dbeta; tg.t[2] = dbias;
-        tg.stride[0] = tg.stride[1] = tg.stride[2] = 1;
-        launch_reduce(ws, grid, 3, H, tg, st);
-    }
-    return xggm_check_launch("xggm_ln_bwd(reduce)");
+    const xggm_ln_bwd_problem q{dy, z, stats, gamma, d_in, d_res, dgamma, dbeta, dbias, gelu_aux, ws, ws_bytes, M, s_pre, s_post,
+                                accumulate_dres};
+    return ln_bwd_grouped<T>(&q, 1, H, p_pre, p_post, rng, out_scale, st);
 }
 
 template <typename T>
@@ -805,6 +888,15 @@ size_t ws_colsum(int M, int N) { return sizeof(float) * (size_t)ceil_div(M, CS_R
                                      hipStream_t st) {                                                                    \
         return ln_bwd<T>(dy, z, stats, gamma, d_in, d_res, dgamma, dbeta, dbias, M, H, p_pre, p_post, rng, s_pre, s_post,  \
                          out_scale, accumulate_dres, gelu_aux, ws, ws_bytes, st);                                          \
+    }                                                                                                                       \
+    extern "C" int xggm_ln_fwd_grouped_##SUF(const xggm_ln_fwd_problem* probs, int n, int H, float eps, float p_pre,       \
+                                             float p_post, const uint64_t* rng, int accumulate, float out_scale,          \
+                                             hipStream_t st) {                                                            \
+        return ln_fwd_grouped<T>(probs, n, H, eps, p_pre, p_post, rng, accumulate, out_scale, st);                         \
+    }                                                                                                                       \
+    extern "C" int xggm_ln_bwd_grouped_##SUF(const xggm_ln_bwd_problem* probs, int n, int H, float p_pre, float p_post,    \
+                                             const uint64_t* rng, float out_scale, hipStream_t st) {                      \
+        return ln_bwd_grouped<T>(probs, n, H, p_pre, p_post, rng, out_scale, st);                                          \
     }                                                                                                                       \
     extern "C" int xggm_embed_fwd_##SUF(const int64_t* ids, const int64_t* seg, const void* word, const void* pos,         \
                                         const void* type, const float* gamma, const float* beta, void* out, void* z_out,   \

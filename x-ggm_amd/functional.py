@@ -151,15 +151,19 @@ def drive(dt, gens):
     out = [None] * n
     alive = list(range(n))
     while alive:
-        probs, nxt = [], []
+        probs, rows, nxt = [], [], []
         for i in alive:
             try:
                 p = next(gens[i])
-                if p:
+                if isinstance(p, (ops.LnFwdReq, ops.LnBwdReq)):
+                    rows.append(p)  # a row-kernel request: shares its launch with the other stream's
+                elif p:
                     probs.extend(p)
                 nxt.append(i)
             except StopIteration as e:
                 out[i] = e.value
+        if rows:
+            ops.launch_row_requests(rows)
         if probs:
             ops.gemm_group(dt, probs)
         alive = nxt
@@ -195,9 +199,11 @@ def g_attn_fwd(rt, att, outm, xq, xkv, mask, B, Sq, Sk, salt):
     c = ops.attn_fwd(q, k, v, mask, B, heads, Sq, Sk, p_att, rt.rng, att._sid + salt)
     p3, h, _ = ops.p_fwd(c, a.w(outm.dense.weight), None)
     yield [p3]
-    y, z, stats = ops.ln_fwd(h, outm.dense.bias.data, xq, outm.LayerNorm.weight.data, outm.LayerNorm.bias.data,
-                             1e-12, p_pre=p_hid, rng=rt.rng, sid_pre=outm._sid + salt)
-    return y, (att, outm, (B, Sq, Sk, heads, H, p_att, p_hid, self_att, salt), (xq, xkv, mask, qkv, kv, c, z, stats))
+    ln = ops.LnFwdReq(h, outm.dense.bias.data, xq, outm.LayerNorm.weight.data, outm.LayerNorm.bias.data, 1e-12,
+                      p_pre=p_hid, rng=rt.rng, sid_pre=outm._sid + salt)
+    yield ln
+    return ln.out, (att, outm, (B, Sq, Sk, heads, H, p_att, p_hid, self_att, salt),
+                    (xq, xkv, mask, qkv, kv, c, ln.z, ln.stats))
 
 
 def g_attn_bwd(rt, saved, dy, defer_wgrad=False):
@@ -210,10 +216,11 @@ def g_attn_bwd(rt, saved, dy, defer_wgrad=False):
     a = rt.arena
     wq, wk, wv = att.query.weight, att.key.weight, att.value.weight
     bq, bk, bv = att.query.bias, att.key.bias, att.value.bias
-    d_h, d_res = ops.ln_bwd(dy.contiguous(), z, stats, outm.LayerNorm.weight.data,
-                            a.atomic_target(outm.LayerNorm.weight), a.atomic_target(outm.LayerNorm.bias),
-                            a.atomic_target(outm.dense.bias), want_dres=True, p_pre=p_hid, rng=rt.rng,
-                            sid_pre=outm._sid + salt, defer=rt.defer_list())
+    lb = ops.LnBwdReq(dy.contiguous(), z, stats, outm.LayerNorm.weight.data, a.atomic_target(outm.LayerNorm.weight),
+                      a.atomic_target(outm.LayerNorm.bias), a.atomic_target(outm.dense.bias), p_pre=p_hid, rng=rt.rng,
+                      sid_pre=outm._sid + salt, defer=rt.defer_list())
+    yield lb
+    d_h, d_res = lb.d_in, lb.d_res
     pd, d_c = ops.p_dgrad(d_h, a.w(outm.dense.weight))
     if defer_wgrad:
         yield [pd]
@@ -258,18 +265,20 @@ def g_ffn_fwd(rt, inter, outm, x):
     p2, h, _ = ops.p_fwd(act, a.w(outm.dense.weight), None)
     yield [p2]
     p_hid = rt.p(rt.p_hidden)
-    y, z, stats = ops.ln_fwd(h, outm.dense.bias.data, x, outm.LayerNorm.weight.data, outm.LayerNorm.bias.data, 1e-12,
-                             p_pre=p_hid, rng=rt.rng, sid_pre=outm._sid)
-    return y, (inter, outm, p_hid, (x, u, act, z, stats))
+    ln = ops.LnFwdReq(h, outm.dense.bias.data, x, outm.LayerNorm.weight.data, outm.LayerNorm.bias.data, 1e-12,
+                      p_pre=p_hid, rng=rt.rng, sid_pre=outm._sid)
+    yield ln
+    return ln.out, (inter, outm, p_hid, (x, u, act, ln.z, ln.stats))
 
 
 def g_ffn_bwd(rt, saved, dy):
     inter, outm, p_hid, (x, u, act, z, stats) = saved
     a = rt.arena
-    d_h, d_res = ops.ln_bwd(dy.contiguous(), z, stats, outm.LayerNorm.weight.data,
-                            a.atomic_target(outm.LayerNorm.weight), a.atomic_target(outm.LayerNorm.bias),
-                            a.atomic_target(outm.dense.bias), want_dres=True, p_pre=p_hid, rng=rt.rng,
-                            sid_pre=outm._sid, defer=rt.defer_list())
+    lb = ops.LnBwdReq(dy.contiguous(), z, stats, outm.LayerNorm.weight.data, a.atomic_target(outm.LayerNorm.weight),
+                      a.atomic_target(outm.LayerNorm.bias), a.atomic_target(outm.dense.bias), p_pre=p_hid, rng=rt.rng,
+                      sid_pre=outm._sid, defer=rt.defer_list())
+    yield lb
+    d_h, d_res = lb.d_in, lb.d_res
     # d_u = (d_h W_2) * gelu'(u); its column sums (= grad of b_1) are taken in the same epilogue
     pd, d_u = ops.p_dgrad(d_h, a.w(outm.dense.weight), gelu_aux=u, colsum=a.atomic_target(inter.dense.bias))
     yield [_p_wgrad(rt, d_h, act, outm.dense.weight), pd]

@@ -247,6 +247,89 @@ def ln_fwd(x, bias, residual, gamma, beta, eps, p_pre=0.0, p_post=0.0, rng=None,
     return out, z, stats
 
 
+class LnFwdProblem(_ct.Structure):
+    """mirror of ``xggm_ln_fwd_problem`` (include/xggm.h)"""
+    _fields_ = [("inp", _ct.c_void_p), ("bias", _ct.c_void_p), ("residual", _ct.c_void_p), ("gamma", _ct.c_void_p),
+                ("beta", _ct.c_void_p), ("out", _ct.c_void_p), ("z_out", _ct.c_void_p), ("stats", _ct.c_void_p),
+                ("M", _ct.c_int), ("sid_pre", _ct.c_uint32), ("sid_post", _ct.c_uint32)]
+
+
+class LnBwdProblem(_ct.Structure):
+    """mirror of ``xggm_ln_bwd_problem`` (include/xggm.h)"""
+    _fields_ = [("dy", _ct.c_void_p), ("z", _ct.c_void_p), ("stats", _ct.c_void_p), ("gamma", _ct.c_void_p),
+                ("d_in", _ct.c_void_p), ("d_res", _ct.c_void_p), ("dgamma", _ct.c_void_p), ("dbeta", _ct.c_void_p),
+                ("dbias", _ct.c_void_p), ("gelu_aux", _ct.c_void_p), ("ws", _ct.c_void_p), ("ws_bytes", _ct.c_size_t),
+                ("M", _ct.c_int), ("sid_pre", _ct.c_uint32), ("sid_post", _ct.c_uint32), ("accumulate_dres", _ct.c_int)]
+
+
+class LnFwdReq:
+    """a residual-LayerNorm forward a block generator hands to ``functional.drive``: requests of the
+    same round (language + vision stream) are launched together.  Results: ``out``, ``z``, ``stats``."""
+
+    def __init__(self, x, bias, residual, gamma, beta, eps, p_pre=0.0, rng=None, sid_pre=0):
+        _c(x)
+        M, H = x.shape
+        _c(gamma, F32, "gamma"), _c(beta, F32, "beta")
+        assert gamma.numel() == H and beta.numel() == H
+        if bias is not None:
+            _c(bias, F32, "bias")
+            assert bias.numel() == H
+        if residual is not None:
+            _c(residual, x.dtype, "residual")
+            assert residual.shape == x.shape
+        self.key = ("ln_fwd", x.dtype, H, float(eps), float(p_pre))
+        self.rng = rng
+        self.out = torch.empty_like(x)
+        self.z = x
+        self.stats = torch.empty((M, 2), device=x.device, dtype=F32)
+        self.keep = (bias, residual, gamma, beta)
+        self.prob = LnFwdProblem(ptr(x), ptr(bias), ptr(residual), ptr(gamma), ptr(beta), ptr(self.out), ptr(x),
+                                 ptr(self.stats), M, sid_pre, 0)
+
+
+class LnBwdReq:
+    """backward of LnFwdReq; ``defer`` as in ``ln_bwd``.  Results: ``d_in``, ``d_res``."""
+
+    def __init__(self, dy, z, stats, gamma, dgamma, dbeta, dbias, p_pre=0.0, rng=None, sid_pre=0, defer=None):
+        _c(dy), _c(z, dy.dtype)
+        M, H = dy.shape
+        assert z.shape == dy.shape and tuple(stats.shape) == (M, 2)
+        for t in (dgamma, dbeta, dbias):
+            if t is not None:
+                _c(t, F32, "param grad")
+                assert t.numel() == H
+        self.key = ("ln_bwd", dy.dtype, H, float(p_pre))
+        self.rng = rng
+        self.d_in = torch.empty_like(dy)
+        self.d_res = torch.empty_like(dy)
+        ws, nb = _ws(_lib.lib.xggm_ln_bwd_workspace_bytes(M, H), dy.device)
+        now = (dgamma, dbeta, dbias)
+        if defer is not None and any(t is not None for t in now):
+            defer.append((ws, nb // (12 * H), H, now))
+            now = (None, None, None)
+        self.keep = (dy, z, stats, gamma, ws)
+        self.prob = LnBwdProblem(ptr(dy), ptr(z), ptr(stats), ptr(gamma), ptr(self.d_in), ptr(self.d_res), ptr(now[0]),
+                                 ptr(now[1]), ptr(now[2]), None, ptr(ws), nb, M, sid_pre, 0, 0)
+
+
+def launch_row_requests(reqs):
+    """launch LnFwdReq / LnBwdReq objects, grouping those with equal key (same kind, dtype, H, eps, p)."""
+    groups = {}
+    for r in reqs:
+        groups.setdefault(r.key, []).append(r)
+    for key, rs in groups.items():
+        if key[0] == "ln_fwd":
+            _, dt, H, eps, p = key
+            arr = (LnFwdProblem * len(rs))(*[r.prob for r in rs])
+            call("xggm_ln_fwd_grouped_" + sfx(dt), _ct.cast(arr, _ct.c_void_p), len(rs), H, eps, p, 0.0, ptr(rs[0].rng), 0,
+                 1.0, stream())
+        else:
+            _, dt, H, p = key
+            arr = (LnBwdProblem * len(rs))(*[r.prob for r in rs])
+            call("xggm_ln_bwd_grouped_" + sfx(dt), _ct.cast(arr, _ct.c_void_p), len(rs), H, p, 0.0, ptr(rs[0].rng), 1.0,
+                 stream())
+
+
 class ReduceJob(_ct.Structure):
     """mirror of ``xggm_reduce_job`` (include/xggm.h)"""
     _fields_ = [("ws", _ct.c_void_p), ("nblk", _ct.c_int), ("K", _ct.c_int), ("H", _ct.c_int),
