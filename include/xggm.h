@@ -127,6 +127,34 @@ int xggm_attn_bwd_bf16(const void* q, const void* k, const void* v, const float*
                        int64_t v_rs, int64_t o_rs, int64_t dq_rs, int64_t dk_rs, int64_t dv_rs, float scale, float p,
                        const uint64_t* rng, uint32_t sid, float* dbq, float* dbk, float* dbv, xggm_stream_t stream);
 
+/* Grouped form: independent attention problems (the language and the vision stream of a layer, or
+ * the two directions of a cross-attention layer, src/lxrt/modeling.py:485-516) in one launch; two
+ * problems share a grid, more are launched in consecutive pairs.  Fields as the arguments above;
+ * the backward fields are ignored by the forward entry points. */
+typedef struct xggm_attn_problem {
+    const void* q;
+    const void* k;
+    const void* v;
+    const float* mask;
+    void* out;
+    int B, heads, Sq, Sk;
+    int64_t q_rs, k_rs, v_rs, o_rs;
+    float scale, p;
+    uint32_t sid;
+    const void* d_out;
+    void* dq;
+    void* dk;
+    void* dv;
+    int64_t dq_rs, dk_rs, dv_rs;
+    float* dbq;
+    float* dbk;
+    float* dbv;
+} xggm_attn_problem;
+int xggm_attn_fwd_grouped_f32(const xggm_attn_problem* probs, int n, int head_dim, const uint64_t* rng, xggm_stream_t stream);
+int xggm_attn_fwd_grouped_bf16(const xggm_attn_problem* probs, int n, int head_dim, const uint64_t* rng, xggm_stream_t stream);
+int xggm_attn_bwd_grouped_f32(const xggm_attn_problem* probs, int n, int head_dim, const uint64_t* rng, xggm_stream_t stream);
+int xggm_attn_bwd_grouped_bf16(const xggm_attn_problem* probs, int n, int head_dim, const uint64_t* rng, xggm_stream_t stream);
+
 /* HOST: 1 = run bf16 attention on the scalar kernels (A/B tests), 0 = matrix-core kernels */
 int xggm_attn_set_scalar(int on);
 

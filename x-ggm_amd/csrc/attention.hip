@@ -10,14 +10,9 @@
 #include "common.h"
 #include "xggm.h"
 
-// bf16 matrix-core versions (attention_mfma.hip)
-int xggm_attn_fwd_mfma(const void* q, const void* k, const void* v, const float* mask, void* out, int B, int heads, int Sq,
-                       int Sk, int64_t q_rs, int64_t k_rs, int64_t v_rs, int64_t o_rs, float scale, float p,
-                       const uint64_t* rng, uint32_t sid, hipStream_t st);
-int xggm_attn_bwd_mfma(const void* q, const void* k, const void* v, const float* mask, const void* d_out, void* dq, void* dk,
-                       void* dv, int B, int heads, int Sq, int Sk, int64_t q_rs, int64_t k_rs, int64_t v_rs, int64_t o_rs,
-                       int64_t dq_rs, int64_t dk_rs, int64_t dv_rs, float scale, float p, const uint64_t* rng, uint32_t sid,
-                       float* dbq, float* dbk, float* dbv, hipStream_t st);
+// bf16 matrix-core versions (attention_mfma.hip): one or two validated problems per launch
+int xggm_attn_fwd_mfma_group(const xggm_attn_problem* probs, int n, const uint64_t* rng, hipStream_t st);
+int xggm_attn_bwd_mfma_group(const xggm_attn_problem* probs, int n, const uint64_t* rng, hipStream_t st);
 
 namespace {
 
@@ -261,20 +256,76 @@ int check(const char* who, const AttnArgs& a, int head_dim) {
     return XGGM_OK;
 }
 
+inline AttnArgs args_of(const xggm_attn_problem& q, const uint64_t* rng) {
+    return AttnArgs{q.q, q.k, q.v, q.mask, q.q_rs, q.k_rs, q.v_rs, q.o_rs, q.B, q.heads, q.Sq, q.Sk, q.scale, q.p, rng, q.sid};
+}
+
+// problems that can run on the matrix-core kernels are launched in pairs, the rest one by one
+template <typename T>
+int attn_fwd_grouped(const xggm_attn_problem* probs, int n, int head_dim, const uint64_t* rng, hipStream_t st) {
+    XGGM_REQUIRE(probs && n > 0, "xggm_attn_fwd: no problems");
+    xggm_attn_problem pend[2];
+    int np = 0;
+    for (int i = 0; i < n; ++i) {
+        const xggm_attn_problem& q = probs[i];
+        const AttnArgs a = args_of(q, rng);
+        if (int e = check("xggm_attn_fwd", a, head_dim)) return e;
+        XGGM_REQUIRE(q.out, "xggm_attn_fwd: null output");
+        if (sizeof(T) == 2 && mfma_ok(q.q, q.k, q.v, nullptr, q.q_rs, q.k_rs, q.v_rs, 8)) {
+            pend[np++] = q;
+            if (np == 2 || i == n - 1) {
+                if (int e = xggm_attn_fwd_mfma_group(pend, np, rng, st)) return e;
+                np = 0;
+            }
+            continue;
+        }
+        const size_t lds = sizeof(float) * ((size_t)(q.Sq + 2 * q.Sk) * LD + 2 * (size_t)q.Sq * (q.Sk + 1));
+        hipLaunchKernelGGL((attn_fwd_kernel<T>), dim3(q.B * q.heads), dim3(NT), lds, st, a, (T*)q.out);
+        if (int e = xggm_check_launch("xggm_attn_fwd")) return e;
+    }
+    if (np) return xggm_attn_fwd_mfma_group(pend, np, rng, st);
+    return XGGM_OK;
+}
+
+template <typename T>
+int attn_bwd_grouped(const xggm_attn_problem* probs, int n, int head_dim, const uint64_t* rng, hipStream_t st) {
+    XGGM_REQUIRE(probs && n > 0, "xggm_attn_bwd: no problems");
+    xggm_attn_problem pend[2];
+    int np = 0;
+    for (int i = 0; i < n; ++i) {
+        const xggm_attn_problem& q = probs[i];
+        const AttnArgs a = args_of(q, rng);
+        if (int e = check("xggm_attn_bwd", a, head_dim)) return e;
+        XGGM_REQUIRE(q.d_out && q.dq && q.dk && q.dv, "xggm_attn_bwd: null pointer");
+        XGGM_REQUIRE(q.dq_rs % 4 == 0 && q.dk_rs % 4 == 0 && q.dv_rs % 4 == 0, "xggm_attn_bwd: row strides must be multiples of 4");
+        XGGM_REQUIRE((q.dbk == nullptr) == (q.dbv == nullptr), "xggm_attn_bwd: dbk and dbv go together");
+        if (sizeof(T) == 2 && mfma_ok(q.q, q.k, q.v, q.d_out, q.q_rs, q.k_rs, q.v_rs, q.o_rs)) {
+            pend[np++] = q;
+            if (np == 2 || i == n - 1) {
+                if (int e = xggm_attn_bwd_mfma_group(pend, np, rng, st)) return e;
+                np = 0;
+            }
+            continue;
+        }
+        const size_t lds = sizeof(float) * ((size_t)(2 * q.Sq + 2 * q.Sk) * LD + 3 * (size_t)q.Sq * (q.Sk + 1));
+        hipLaunchKernelGGL((attn_bwd_kernel<T>), dim3(q.B * q.heads), dim3(NT), lds, st, a, (const T*)q.d_out, (T*)q.dq, (T*)q.dk,
+                           (T*)q.dv, q.dq_rs, q.dk_rs, q.dv_rs, q.dbq, q.dbk, q.dbv);
+        if (int e = xggm_check_launch("xggm_attn_bwd")) return e;
+    }
+    if (np) return xggm_attn_bwd_mfma_group(pend, np, rng, st);
+    return XGGM_OK;
+}
+
 template <typename T>
 int attn_fwd(const void* q, const void* k, const void* v, const float* mask, void* out, int B, int heads, int Sq, int Sk,
              int head_dim, int64_t q_rs, int64_t k_rs, int64_t v_rs, int64_t o_rs, float scale, float p, const uint64_t* rng,
              uint32_t sid, hipStream_t st) {
-    AttnArgs a{q, k, v, mask, q_rs, k_rs, v_rs, o_rs, B, heads, Sq, Sk, scale, p, rng, sid};
-    if (int e = check("xggm_attn_fwd", a, head_dim)) return e;
-    XGGM_REQUIRE(out, "xggm_attn_fwd: null output");
-    if constexpr (sizeof(T) == 2) {
-        if (mfma_ok(q, k, v, nullptr, q_rs, k_rs, v_rs, 8))
-            return xggm_attn_fwd_mfma(q, k, v, mask, out, B, heads, Sq, Sk, q_rs, k_rs, v_rs, o_rs, scale, p, rng, sid, st);
-    }
-    const size_t lds = sizeof(float) * ((size_t)(Sq + 2 * Sk) * LD + 2 * (size_t)Sq * (Sk + 1));
-    hipLaunchKernelGGL((attn_fwd_kernel<T>), dim3(B * heads), dim3(NT), lds, st, a, (T*)out);
-    return xggm_check_launch("xggm_attn_fwd");
+    xggm_attn_problem pr{};
+    pr.q = q; pr.k = k; pr.v = v; pr.mask = mask; pr.out = out;
+    pr.B = B; pr.heads = heads; pr.Sq = Sq; pr.Sk = Sk;
+    pr.q_rs = q_rs; pr.k_rs = k_rs; pr.v_rs = v_rs; pr.o_rs = o_rs;
+    pr.scale = scale; pr.p = p; pr.sid = sid;
+    return attn_fwd_grouped<T>(&pr, 1, head_dim, rng, st);
 }
 
 template <typename T>
@@ -282,20 +333,15 @@ int attn_bwd(const void* q, const void* k, const void* v, const float* mask, con
              int B, int heads, int Sq, int Sk, int head_dim, int64_t q_rs, int64_t k_rs, int64_t v_rs, int64_t o_rs,
              int64_t dq_rs, int64_t dk_rs, int64_t dv_rs, float scale, float p, const uint64_t* rng, uint32_t sid,
              float* dbq, float* dbk, float* dbv, hipStream_t st) {
-    AttnArgs a{q, k, v, mask, q_rs, k_rs, v_rs, o_rs, B, heads, Sq, Sk, scale, p, rng, sid};
-    if (int e = check("xggm_attn_bwd", a, head_dim)) return e;
-    XGGM_REQUIRE(d_out && dq && dk && dv, "xggm_attn_bwd: null pointer");
-    XGGM_REQUIRE(dq_rs % 4 == 0 && dk_rs % 4 == 0 && dv_rs % 4 == 0, "xggm_attn_bwd: row strides must be multiples of 4");
-    XGGM_REQUIRE((dbk == nullptr) == (dbv == nullptr), "xggm_attn_bwd: dbk and dbv go together");
-    if constexpr (sizeof(T) == 2) {
-        if (mfma_ok(q, k, v, d_out, q_rs, k_rs, v_rs, o_rs))
-            return xggm_attn_bwd_mfma(q, k, v, mask, d_out, dq, dk, dv, B, heads, Sq, Sk, q_rs, k_rs, v_rs, o_rs, dq_rs,
-                                      dk_rs, dv_rs, scale, p, rng, sid, dbq, dbk, dbv, st);
-    }
-    const size_t lds = sizeof(float) * ((size_t)(2 * Sq + 2 * Sk) * LD + 3 * (size_t)Sq * (Sk + 1));
-    hipLaunchKernelGGL((attn_bwd_kernel<T>), dim3(B * heads), dim3(NT), lds, st, a, (const T*)d_out, (T*)dq, (T*)dk, (T*)dv,
-                       dq_rs, dk_rs, dv_rs, dbq, dbk, dbv);
-    return xggm_check_launch("xggm_attn_bwd");
+    xggm_attn_problem pr{};
+    pr.q = q; pr.k = k; pr.v = v; pr.mask = mask;
+    pr.B = B; pr.heads = heads; pr.Sq = Sq; pr.Sk = Sk;
+    pr.q_rs = q_rs; pr.k_rs = k_rs; pr.v_rs = v_rs; pr.o_rs = o_rs;
+    pr.scale = scale; pr.p = p; pr.sid = sid;
+    pr.d_out = d_out; pr.dq = dq; pr.dk = dk; pr.dv = dv;
+    pr.dq_rs = dq_rs; pr.dk_rs = dk_rs; pr.dv_rs = dv_rs;
+    pr.dbq = dbq; pr.dbk = dbk; pr.dbv = dbv;
+    return attn_bwd_grouped<T>(&pr, 1, head_dim, rng, st);
 }
 
 }  // namespace
@@ -314,6 +360,14 @@ int attn_bwd(const void* q, const void* k, const void* v, const float* mask, con
                                        uint32_t sid, float* dbq, float* dbk, float* dbv, hipStream_t st) {                \
         return attn_bwd<T>(q, k, v, mask, d_out, dq, dk, dv, B, heads, Sq, Sk, head_dim, q_rs, k_rs, v_rs, o_rs, dq_rs,    \
                            dk_rs, dv_rs, scale, p, rng, sid, dbq, dbk, dbv, st);                                           \
+    }                                                                                                                      \
+    extern "C" int xggm_attn_fwd_grouped_##SUF(const xggm_attn_problem* probs, int n, int head_dim, const uint64_t* rng,   \
+                                               hipStream_t st) {                                                          \
+        return attn_fwd_grouped<T>(probs, n, head_dim, rng, st);                                                           \
+    }                                                                                                                      \
+    extern "C" int xggm_attn_bwd_grouped_##SUF(const xggm_attn_problem* probs, int n, int head_dim, const uint64_t* rng,   \
+                                               hipStream_t st) {                                                          \
+        return attn_bwd_grouped<T>(probs, n, head_dim, rng, st);                                                           \
     }
 
 ATTN_API(f32, float)

@@ -32,6 +32,20 @@ struct MArgs {
     uint32_t sid;
 };
 
+// one or two independent problems per launch: workgroups [0, start1) run s[0], the rest s[1]
+struct MSeg {
+    MArgs a;
+    bf16* out;
+    const bf16* d_out;
+    bf16 *dq, *dk, *dv;
+    int64_t dq_rs, dk_rs, dv_rs;
+    float *dbq, *dbk, *dbv;
+};
+struct MGroup {
+    MSeg s[2];
+    int start1;
+};
+
 __device__ __forceinline__ int rup(int x, int m) { return (x + m - 1) / m * m; }
 
 // rows (<= 64) x 64 bf16 tile: two 16-byte chunks per thread.  tile_fetch only ISSUES the loads
@@ -125,10 +139,15 @@ __device__ __forceinline__ void softmax_rows(const MArgs& a, float* Sf, int lds_
     }
 }
 
-__global__ __launch_bounds__(NT) void attn_fwd_mfma_kernel(MArgs a, bf16* out) {
+__global__ __launch_bounds__(NT) void attn_fwd_mfma_kernel(MGroup G) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int si = (int)blockIdx.x >= G.start1 ? 1 : 0;
+    const MSeg sg = G.s[si];
+    const MArgs& a = sg.a;
+    bf16* out = sg.out;
+    const int blk = blockIdx.x - (si ? G.start1 : 0);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, fr = lane & 15, fq = lane >> 4;
-    const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+    const int b = blk / a.heads, h = blk % a.heads;
     const int Sq = a.Sq, Sk = a.Sk;
     const int RQ = rup(Sq, 16), RK = rup(Sk, 32);  // Q rows (M of every product), K/V rows (k of P V)
     const int LDP = RK + 8, lds_s = rup(Sk, 16) + 1;
@@ -195,14 +214,20 @@ __device__ __forceinline__ void store_grad_tile(const float4_t& acc, bf16* dst, 
     }
 }
 
-__global__ __launch_bounds__(NT) void attn_bwd_mfma_kernel(MArgs a, const bf16* d_out, bf16* dq, bf16* dk, bf16* dv,
-                                                           int64_t dq_rs, int64_t dk_rs, int64_t dv_rs, float* dbq,
-                                                           float* dbk, float* dbv) {
+__global__ __launch_bounds__(NT) void attn_bwd_mfma_kernel(MGroup G) {
     __shared__ float csum[3][D];
     if (threadIdx.x < 3 * D) (&csum[0][0])[threadIdx.x] = 0.f;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int si = (int)blockIdx.x >= G.start1 ? 1 : 0;
+    const MSeg sg = G.s[si];
+    const MArgs& a = sg.a;
+    const bf16* d_out = sg.d_out;
+    bf16 *dq = sg.dq, *dk = sg.dk, *dv = sg.dv;
+    const int64_t dq_rs = sg.dq_rs, dk_rs = sg.dk_rs, dv_rs = sg.dv_rs;
+    float *dbq = sg.dbq, *dbk = sg.dbk, *dbv = sg.dbv;
+    const int blk = blockIdx.x - (si ? G.start1 : 0);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, fr = lane & 15, fq = lane >> 4;
-    const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+    const int b = blk / a.heads, h = blk % a.heads;
     const int Sq = a.Sq, Sk = a.Sk;
     const int RQ = rup(Sq, 32), RK = rup(Sk, 32);  // both row counts also serve as reduction lengths here
     const int LDP = RK + 8, R16 = rup(Sq, 16), lds_s = rup(Sk, 16) + 1;
@@ -297,36 +322,61 @@ template <typename K> void allow_big_lds(K kernel, size_t lds) {
 
 }  // namespace
 
-// called by attention.hip for bf16 storage (arguments already validated there)
-int xggm_attn_fwd_mfma(const void* q, const void* k, const void* v, const float* mask, void* out, int B, int heads, int Sq,
-                       int Sk, int64_t q_rs, int64_t k_rs, int64_t v_rs, int64_t o_rs, float scale, float p,
-                       const uint64_t* rng, uint32_t sid, hipStream_t st) {
-    XGGM_REQUIRE(q_rs % 8 == 0 && k_rs % 8 == 0 && v_rs % 8 == 0, "xggm_attn_fwd: bf16 row strides must be multiples of 8");
-    XGGM_REQUIRE((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) % 16 == 0,
-                 "xggm_attn_fwd: bf16 operands must be 16-byte aligned");
-    MArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, mask, q_rs, k_rs, v_rs, o_rs, B, heads, Sq, Sk, scale, p, rng, sid};
-    const int RQ = (Sq + 15) / 16 * 16, RK = (Sk + 31) / 32 * 32, lds_s = (Sk + 15) / 16 * 16 + 1;
-    const size_t lds = sizeof(bf16) * ((size_t)(RQ + 2 * RK) * LDT + (size_t)RQ * (RK + 8)) + sizeof(float) * RQ * lds_s;
+// called by attention.hip for bf16 storage (arguments already validated there): n = 1 or 2 problems
+namespace {
+MSeg make_seg(const xggm_attn_problem& q, const uint64_t* rng) {
+    MSeg g;
+    g.a = MArgs{(const bf16*)q.q, (const bf16*)q.k, (const bf16*)q.v, q.mask, q.q_rs, q.k_rs, q.v_rs, q.o_rs,
+                q.B, q.heads, q.Sq, q.Sk, q.scale, q.p, rng, q.sid};
+    g.out = (bf16*)q.out;
+    g.d_out = (const bf16*)q.d_out;
+    g.dq = (bf16*)q.dq; g.dk = (bf16*)q.dk; g.dv = (bf16*)q.dv;
+    g.dq_rs = q.dq_rs; g.dk_rs = q.dk_rs; g.dv_rs = q.dv_rs;
+    g.dbq = q.dbq; g.dbk = q.dbk; g.dbv = q.dbv;
+    return g;
+}
+}  // namespace
+
+int xggm_attn_fwd_mfma_group(const xggm_attn_problem* probs, int n, const uint64_t* rng, hipStream_t st) {
+    MGroup G;
+    size_t lds = 0;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        const xggm_attn_problem& q = probs[i];
+        G.s[i] = make_seg(q, rng);
+        const int RQ = (q.Sq + 15) / 16 * 16, RK = (q.Sk + 31) / 32 * 32, lds_s = (q.Sk + 15) / 16 * 16 + 1;
+        lds = std::max(lds, sizeof(bf16) * ((size_t)(RQ + 2 * RK) * LDT + (size_t)RQ * (RK + 8)) + sizeof(float) * RQ * lds_s);
+        if (i == 1) G.start1 = total;
+        total += q.B * q.heads;
+    }
+    if (n == 1) {
+        G.s[1] = G.s[0];
+        G.start1 = total;
+    }
     allow_big_lds(attn_fwd_mfma_kernel, lds);
-    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(B * heads), dim3(NT), lds, st, a, (bf16*)out);
+    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(total), dim3(NT), lds, st, G);
     return xggm_check_launch("xggm_attn_fwd(mfma)");
 }
 
-int xggm_attn_bwd_mfma(const void* q, const void* k, const void* v, const float* mask, const void* d_out, void* dq, void* dk,
-                       void* dv, int B, int heads, int Sq, int Sk, int64_t q_rs, int64_t k_rs, int64_t v_rs, int64_t o_rs,
-                       int64_t dq_rs, int64_t dk_rs, int64_t dv_rs, float scale, float p, const uint64_t* rng, uint32_t sid,
-                       float* dbq, float* dbk, float* dbv, hipStream_t st) {
-    XGGM_REQUIRE(q_rs % 8 == 0 && k_rs % 8 == 0 && v_rs % 8 == 0 && o_rs % 8 == 0,
-                 "xggm_attn_bwd: bf16 row strides must be multiples of 8");
-    XGGM_REQUIRE((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) |
-                  reinterpret_cast<uintptr_t>(d_out)) % 16 == 0,
-                 "xggm_attn_bwd: bf16 operands must be 16-byte aligned");
-    MArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, mask, q_rs, k_rs, v_rs, o_rs, B, heads, Sq, Sk, scale, p, rng, sid};
-    const int RQ = (Sq + 31) / 32 * 32, RK = (Sk + 31) / 32 * 32, lds_s = (Sk + 15) / 16 * 16 + 1;
-    const int R16 = (Sq + 15) / 16 * 16;
-    const size_t lds = sizeof(bf16) * ((size_t)(2 * RQ + 2 * RK) * LDT + 2 * (size_t)RQ * (RK + 8)) + sizeof(float) * 2 * R16 * lds_s;
+int xggm_attn_bwd_mfma_group(const xggm_attn_problem* probs, int n, const uint64_t* rng, hipStream_t st) {
+    MGroup G;
+    size_t lds = 0;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        const xggm_attn_problem& q = probs[i];
+        G.s[i] = make_seg(q, rng);
+        const int RQ = (q.Sq + 31) / 32 * 32, RK = (q.Sk + 31) / 32 * 32, lds_s = (q.Sk + 15) / 16 * 16 + 1;
+        const int R16 = (q.Sq + 15) / 16 * 16;
+        lds = std::max(lds, sizeof(bf16) * ((size_t)(2 * RQ + 2 * RK) * LDT + 2 * (size_t)RQ * (RK + 8)) +
+                                sizeof(float) * 2 * R16 * lds_s);
+        if (i == 1) G.start1 = total;
+        total += q.B * q.heads;
+    }
+    if (n == 1) {
+        G.s[1] = G.s[0];
+        G.start1 = total;
+    }
     allow_big_lds(attn_bwd_mfma_kernel, lds);
-    hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(B * heads), dim3(NT), lds, st, a, (const bf16*)d_out, (bf16*)dq, (bf16*)dk,
-                       (bf16*)dv, dq_rs, dk_rs, dv_rs, dbq, dbk, dbv);
+    hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(total), dim3(NT), lds, st, G);
     return xggm_check_launch("xggm_attn_bwd(mfma)");
 }

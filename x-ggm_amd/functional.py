@@ -155,7 +155,7 @@ def drive(dt, gens):
         for i in alive:
             try:
                 p = next(gens[i])
-                if isinstance(p, (ops.LnFwdReq, ops.LnBwdReq)):
+                if isinstance(p, ops.ROW_REQUESTS):
                     rows.append(p)  # a row-kernel request: shares its launch with the other stream's
                 elif p:
                     probs.extend(p)
@@ -196,7 +196,9 @@ def g_attn_fwd(rt, att, outm, xq, xkv, mask, B, Sq, Sk, salt):
         yield [p1, p2]
         q, k, v = qkv, kv[:, :H], kv[:, H:]
     p_att, p_hid = rt.p(rt.p_attn), rt.p(rt.p_hidden)
-    c = ops.attn_fwd(q, k, v, mask, B, heads, Sq, Sk, p_att, rt.rng, att._sid + salt)
+    core = ops.AttnFwdReq(q, k, v, mask, B, heads, Sq, Sk, p_att, rt.rng, att._sid + salt)
+    yield core
+    c = core.out
     p3, h, _ = ops.p_fwd(c, a.w(outm.dense.weight), None)
     yield [p3]
     ln = ops.LnFwdReq(h, outm.dense.bias.data, xq, outm.LayerNorm.weight.data, outm.LayerNorm.bias.data, 1e-12,
@@ -231,8 +233,9 @@ def g_attn_bwd(rt, saved, dy, defer_wgrad=False):
     if self_att:
         dqkv = torch.empty_like(qkv)
         gb = a.atomic_target([bq, bk, bv])  # q/k/v bias gradients come out of the attention backward
-        ops.attn_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], mask, d_c, dqkv[:, :H], dqkv[:, H:2 * H],
-                     dqkv[:, 2 * H:], B, heads, Sq, Sk, p_att, rt.rng, att._sid + salt, gb[:H], gb[H:2 * H], gb[2 * H:])
+        yield ops.AttnBwdReq(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], mask, d_c, dqkv[:, :H], dqkv[:, H:2 * H],
+                             dqkv[:, 2 * H:], B, heads, Sq, Sk, p_att, rt.rng, att._sid + salt, gb[:H], gb[H:2 * H],
+                             gb[2 * H:])
         pdx, dxq = ops.p_dgrad(dqkv, a.fused([wq, wk, wv]), residual=d_res)
         dxkv = None
         if defer_wgrad:
@@ -244,8 +247,8 @@ def g_attn_bwd(rt, saved, dy, defer_wgrad=False):
         dq = torch.empty_like(qkv)
         dkv = torch.empty_like(kv)
         gbq, gbkv = a.atomic_target(bq), a.atomic_target([bk, bv])
-        ops.attn_bwd(qkv, kv[:, :H], kv[:, H:], mask, d_c, dq, dkv[:, :H], dkv[:, H:], B, heads, Sq, Sk, p_att, rt.rng,
-                     att._sid + salt, gbq, gbkv[:H], gbkv[H:])
+        yield ops.AttnBwdReq(qkv, kv[:, :H], kv[:, H:], mask, d_c, dq, dkv[:, :H], dkv[:, H:], B, heads, Sq, Sk, p_att,
+                             rt.rng, att._sid + salt, gbq, gbkv[:H], gbkv[H:])
         pdq, dxq = ops.p_dgrad(dq, a.w(wq), residual=d_res)
         pdk, dxkv = ops.p_dgrad(dkv, a.fused([wk, wv]))
         if defer_wgrad:

@@ -221,6 +221,60 @@ def attn_bwd(q, k, v, mask, d_out, dq, dk, dv, B, heads, Sq, Sk, p, rng, sid, db
          dk.stride(0), dv.stride(0), 0.125, float(p), ptr(rng), sid, ptr(dbq), ptr(dbk), ptr(dbv), stream())
 
 
+class AttnProblem(_ct.Structure):
+    """mirror of ``xggm_attn_problem`` (include/xggm.h)"""
+    _fields_ = [("q", _ct.c_void_p), ("k", _ct.c_void_p), ("v", _ct.c_void_p), ("mask", _ct.c_void_p), ("out", _ct.c_void_p),
+                ("B", _ct.c_int), ("heads", _ct.c_int), ("Sq", _ct.c_int), ("Sk", _ct.c_int),
+                ("q_rs", _ct.c_int64), ("k_rs", _ct.c_int64), ("v_rs", _ct.c_int64), ("o_rs", _ct.c_int64),
+                ("scale", _ct.c_float), ("p", _ct.c_float), ("sid", _ct.c_uint32),
+                ("d_out", _ct.c_void_p), ("dq", _ct.c_void_p), ("dk", _ct.c_void_p), ("dv", _ct.c_void_p),
+                ("dq_rs", _ct.c_int64), ("dk_rs", _ct.c_int64), ("dv_rs", _ct.c_int64),
+                ("dbq", _ct.c_void_p), ("dbk", _ct.c_void_p), ("dbv", _ct.c_void_p)]
+
+
+class AttnFwdReq:
+    """attention core forward handed to ``functional.drive`` (see LnFwdReq).  Result: ``out``."""
+
+    def __init__(self, q, k, v, mask, B, heads, Sq, Sk, p, rng, sid):
+        d = 64
+        H = heads * d
+        for t, S in ((q, Sq), (k, Sk), (v, Sk)):
+            _chk(t)
+            if t.dim() != 2 or t.shape[0] != B * S or t.shape[1] != H or t.stride(1) != 1:
+                raise RuntimeError("attn_fwd: bad operand shape %s" % (tuple(t.shape),))
+        if mask is not None:
+            _c(mask, F32, "mask")
+            assert tuple(mask.shape) == (B, Sk)
+        self.key = ("attn_fwd", q.dtype)
+        self.rng = rng
+        self.out = torch.empty((B * Sq, H), device=q.device, dtype=q.dtype)
+        self.keep = (q, k, v, mask)
+        self.prob = AttnProblem(ptr(q), ptr(k), ptr(v), ptr(mask), ptr(self.out), B, heads, Sq, Sk, q.stride(0), k.stride(0),
+                                v.stride(0), H, 0.125, float(p), sid, None, None, None, None, 0, 0, 0, None, None, None)
+
+
+class AttnBwdReq:
+    """attention core backward; gradients are written into the caller's dq/dk/dv views."""
+
+    def __init__(self, q, k, v, mask, d_out, dq, dk, dv, B, heads, Sq, Sk, p, rng, sid, dbq=None, dbk=None, dbv=None):
+        d = 64
+        H = heads * d
+        _c(d_out)
+        assert tuple(d_out.shape) == (B * Sq, H) and d_out.dtype == q.dtype
+        for t, S in ((dq, Sq), (dk, Sk), (dv, Sk)):
+            if t.dim() != 2 or t.shape[0] != B * S or t.shape[1] != H or t.stride(1) != 1 or t.dtype != q.dtype:
+                raise RuntimeError("attn_bwd: bad gradient buffer %s" % (tuple(t.shape),))
+        self.key = ("attn_bwd", q.dtype)
+        self.rng = rng
+        self.keep = (q, k, v, mask, d_out, dq, dk, dv, dbq, dbk, dbv)
+        self.prob = AttnProblem(ptr(q), ptr(k), ptr(v), ptr(mask), None, B, heads, Sq, Sk, q.stride(0), k.stride(0),
+                                v.stride(0), H, 0.125, float(p), sid, ptr(d_out), ptr(dq), ptr(dk), ptr(dv), dq.stride(0),
+                                dk.stride(0), dv.stride(0), ptr(dbq), ptr(dbk), ptr(dbv))
+
+
+ROW_REQUESTS = ()  # filled below: the request classes ``functional.drive`` recognises
+
+
 # ----------------------------------------------------------------------------- row kernels
 def ln_fwd(x, bias, residual, gamma, beta, eps, p_pre=0.0, p_post=0.0, rng=None, sid_pre=0, sid_post=0,
            out=None, accumulate=False, out_scale=1.0, save=True):
@@ -318,7 +372,11 @@ def launch_row_requests(reqs):
     for r in reqs:
         groups.setdefault(r.key, []).append(r)
     for key, rs in groups.items():
-        if key[0] == "ln_fwd":
+        if key[0] in ("attn_fwd", "attn_bwd"):
+            arr = (AttnProblem * len(rs))(*[r.prob for r in rs])
+            call("xggm_%s_grouped_%s" % (key[0], sfx(key[1])), _ct.cast(arr, _ct.c_void_p), len(rs), 64, ptr(rs[0].rng),
+                 stream())
+        elif key[0] == "ln_fwd":
             _, dt, H, eps, p = key
             arr = (LnFwdProblem * len(rs))(*[r.prob for r in rs])
             call("xggm_ln_fwd_grouped_" + sfx(dt), _ct.cast(arr, _ct.c_void_p), len(rs), H, eps, p, 0.0, ptr(rs[0].rng), 0,
@@ -328,6 +386,9 @@ def launch_row_requests(reqs):
             arr = (LnBwdProblem * len(rs))(*[r.prob for r in rs])
             call("xggm_ln_bwd_grouped_" + sfx(dt), _ct.cast(arr, _ct.c_void_p), len(rs), H, p, 0.0, ptr(rs[0].rng), 1.0,
                  stream())
+
+
+ROW_REQUESTS = (LnFwdReq, LnBwdReq, AttnFwdReq, AttnBwdReq)
 
 
 class ReduceJob(_ct.Structure):
