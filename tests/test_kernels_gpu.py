@@ -258,6 +258,68 @@ def test_layernorm_fwd_bwd(ops, dt, M, H):
 
 
 @pytest.mark.parametrize("dt", DTS)
+def test_grouped_row_requests_equal_separate_launches(ops, dt):
+    """the language (640 rows, 20 tokens) and vision (1152 rows, 36 objects) LayerNorms / attention cores
+    launched as ONE group give bit-identical results to separate launches; the deferred second stage of
+    the LN backward adds exactly what the immediate one adds."""
+    H, heads, B = 128, 2, 8
+    rng = ops.make_rng(77, DEV)
+    gen = torch.Generator().manual_seed(5)
+    par = [[t.to(DEV) for t in (torch.randn(H, generator=gen), 1 + 0.1 * torch.randn(H, generator=gen),
+                                0.1 * torch.randn(H, generator=gen))] for _ in range(2)]
+    rows = (B * 20, B * 36)
+    xs = [rnd((m, H), dt, 10 + i)[0] for i, m in enumerate(rows)]
+    rs = [rnd((m, H), dt, 20 + i)[0] for i, m in enumerate(rows)]
+    dys = [rnd((m, H), dt, 30 + i)[0] for i, m in enumerate(rows)]
+    # separate
+    sep = [ops.ln_fwd(x.clone(), par[i][0], rs[i], par[i][1], par[i][2], 1e-12, p_pre=0.1, rng=rng, sid_pre=5 + i)
+           for i, x in enumerate(xs)]
+    gsep = [[torch.zeros(H, device=DEV) for _ in range(3)] for _ in range(2)]
+    bsep = [ops.ln_bwd(dys[i], sep[i][1], sep[i][2], par[i][1], *gsep[i], want_dres=True, p_pre=0.1, rng=rng, sid_pre=5 + i)
+            for i in range(2)]
+    # grouped + deferred
+    reqs = [ops.LnFwdReq(x.clone(), par[i][0], rs[i], par[i][1], par[i][2], 1e-12, p_pre=0.1, rng=rng, sid_pre=5 + i)
+            for i, x in enumerate(xs)]
+    ops.launch_row_requests(reqs)
+    for i in range(2):
+        assert torch.equal(reqs[i].out, sep[i][0]) and torch.equal(reqs[i].z, sep[i][1])
+        assert torch.equal(reqs[i].stats, sep[i][2])
+    ggrp = [[torch.zeros(H, device=DEV) for _ in range(3)] for _ in range(2)]
+    jobs = []
+    breqs = [ops.LnBwdReq(dys[i], reqs[i].z, reqs[i].stats, par[i][1], *ggrp[i], p_pre=0.1, rng=rng, sid_pre=5 + i, defer=jobs)
+             for i in range(2)]
+    ops.launch_row_requests(breqs)
+    assert len(jobs) == 2 and all(float(g.abs().sum()) == 0 for gs in ggrp for g in gs)  # nothing added yet
+    ops.reduce_batch(jobs)
+    for i in range(2):
+        assert torch.equal(breqs[i].d_in, bsep[i][0]) and torch.equal(breqs[i].d_res, bsep[i][1])
+        for a, b in zip(ggrp[i], gsep[i]):
+            assert torch.equal(a, b)
+    # attention: self-attention of both streams in one launch
+    Hh = heads * 64
+    qkv = [rnd((m, 3 * Hh), dt, 40 + i)[0] for i, m in enumerate(rows)]
+    S = (20, 36)
+    outs = [ops.attn_fwd(t[:, :Hh], t[:, Hh:2 * Hh], t[:, 2 * Hh:], None, B, heads, S[i], S[i], 0.1, rng, 9 + i)
+            for i, t in enumerate(qkv)]
+    areqs = [ops.AttnFwdReq(t[:, :Hh], t[:, Hh:2 * Hh], t[:, 2 * Hh:], None, B, heads, S[i], S[i], 0.1, rng, 9 + i)
+             for i, t in enumerate(qkv)]
+    ops.launch_row_requests(areqs)
+    for i in range(2):
+        assert torch.equal(areqs[i].out, outs[i])
+    dos = [rnd((m, Hh), dt, 50 + i)[0] for i, m in enumerate(rows)]
+    d1 = [torch.empty_like(t) for t in qkv]
+    d2 = [torch.empty_like(t) for t in qkv]
+    for i, t in enumerate(qkv):
+        ops.attn_bwd(t[:, :Hh], t[:, Hh:2 * Hh], t[:, 2 * Hh:], None, dos[i], d1[i][:, :Hh], d1[i][:, Hh:2 * Hh],
+                     d1[i][:, 2 * Hh:], B, heads, S[i], S[i], 0.1, rng, 9 + i)
+    ops.launch_row_requests([ops.AttnBwdReq(t[:, :Hh], t[:, Hh:2 * Hh], t[:, 2 * Hh:], None, dos[i], d2[i][:, :Hh],
+                                            d2[i][:, Hh:2 * Hh], d2[i][:, 2 * Hh:], B, heads, S[i], S[i], 0.1, rng, 9 + i)
+                             for i, t in enumerate(qkv)])
+    for i in range(2):
+        assert torch.equal(d1[i], d2[i])
+
+
+@pytest.mark.parametrize("dt", DTS)
 def test_layernorm_dropout_and_accumulate(ops, dt):
     """GNN read-out form: out += drop_.5(LN(x)); pre-dropout form: LN(drop_.1(x+b)+res)."""
     M, H = 108, 768
