@@ -166,6 +166,23 @@ def cpu_baseline(args):
                       "samples, fp32, full 9/5/5 model, torch CPU oracle, %.1f s" % (iters, args.batch, dt)}
 
 
+def pmc_traffic(family):
+    """HBM-side bytes per C-ABI launch of a kernel family, from the committed PMC passes
+    (profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this bench in separate eager
+    runs, gfx950 correction applied by tools/pmc_summary.py); None when no profile covers the family."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    key = {"xggm_gemm_bf16": "gemm_", "xggm_bertadam_f32": "bertadam_kernel", "xggm_ln_bwd_bf16": "ln_bwd_kernel",
+           "xggm_ln_fwd_bf16": "ln_fwd_kernel", "xggm_attn_bwd_bf16": "attn_bwd", "xggm_attn_fwd_bf16": "attn_fwd"}.get(family)
+    if key is None or not os.path.exists(path):
+        return None
+    tot = n = 0.0
+    for name, r in json.load(open(path)).items():
+        if key in name:
+            tot += (r["read_bytes_per_launch"] + r["write_bytes_per_launch"]) * r["launches"]
+            n += r["launches"]
+    return round(tot / n) if n else None
+
+
 def log(msg):
     """progress on stderr (the JSON line is the only thing on stdout)"""
     print("[bench %6.1fs] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
@@ -258,12 +275,12 @@ def main():
         if dom.startswith("xggm_gemm_"):
             ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
             roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(dom),
                         "launches": f["n"], "avg_us": round(1000 * f["ms"] / f["n"], 2)}
         else:
             ach = f["bytes"] / (f["ms"] * 1e-3) / 1e9 if f["bytes"] else 0.0
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
-                        "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
+                        "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": pmc_traffic(dom),
                         "launches": f["n"], "avg_us": round(1000 * f["ms"] / f["n"], 2)}
         # the optimiser is the HBM-bound half of the step: always report it too
         if "xggm_bertadam_f32" in fam and fam["xggm_bertadam_f32"]["ms"] > 0:
