@@ -263,6 +263,16 @@ def main():
             barrier()
             per_branch[br] = round(1000.0 * (time.perf_counter() - t1) / 5, 3)
 
+    # per-pass time: forward + backward + clip + BertAdam of ONE pass (SURVEY section 8d asks for both views)
+    per_pass = {}
+    for kind in ("plain", "rel", "node"):
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            trainer.run_pass(kind)
+        barrier()
+        per_pass[kind] = round(1000.0 * (time.perf_counter() - t1) / 5, 3)
+
     roofline, kernels = None, None
     if rank == 0 and not args.no_kernel_timing:
         log("kernel timing pass")
@@ -305,7 +315,7 @@ def main():
                                                                         args.delta),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "hip_graph": not args.no_graph, "grad_wire": args.wire if world > 1 else None},
-            "ms_per_step_by_branch": per_branch,
+            "ms_per_step_by_branch": per_branch, "ms_per_pass": per_pass,
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

@@ -444,7 +444,7 @@ class MLPFn(Function):
         x2, u, z, stats = ctx.saved
         a = rt.arena
         d_u, _ = ops.ln_bwd(dy.reshape(z.shape).contiguous(), z, stats, ln.weight.data, a.atomic_target(ln.weight),
-                            a.atomic_target(ln.bias), a.atomic_target(lin.bias), gelu_aux=u)
+                            a.atomic_target(ln.bias), a.atomic_target(lin.bias), gelu_aux=u, defer=rt.defer_list())
         probs, dx = [_p_wgrad(rt, d_u, x2, lin.weight)], None
         if ctx.needs_input_grad[4]:
             pd, dx = ops.p_dgrad(d_u, a.w(lin.weight))
@@ -501,7 +501,7 @@ class GCNFn(Function):
             u, z, stats = reads[k]
             d_u, _ = ops.ln_bwd(d_ret, z, stats, mlp[2].weight.data, a.atomic_target(mlp[2].weight),
                                 a.atomic_target(mlp[2].bias), a.atomic_target(mlp[0].bias), p_post=ctx.p, rng=rt.rng,
-                                sid_post=gcn._sid + k, gelu_aux=u)
+                                sid_post=gcn._sid + k, gelu_aux=u, defer=rt.defer_list())
             pd, dhk = ops.p_dgrad(d_u, a.w(mlp[0].weight))
             probs += [_p_wgrad(rt, d_u, h.view(B * N, H), mlp[0].weight), pd]
             dh.append(dhk)
@@ -513,7 +513,7 @@ class GCNFn(Function):
             # dh[k+1] is complete here; its residual branch adds into dh[k]
             d_t, _ = ops.ln_bwd(dh[k + 1], z, stats, conv.layer_norm.weight.data,
                                 a.atomic_target(conv.layer_norm.weight), a.atomic_target(conv.layer_norm.bias), None,
-                                d_res=dh[k])
+                                d_res=dh[k], defer=rt.defer_list())
             pd, d_agg = ops.p_dgrad(d_t, a.w(conv.ctx_layer.weight))
             ops.gemm_group(d_t.dtype, [_p_wgrad(rt, d_t, agg.view(B * N, H), conv.ctx_layer.weight), pd])
             d_agg = d_agg.view(B, N, H)
@@ -568,11 +568,12 @@ class GINFn(Function):
             uk, zk, sk = reads[k]
             d_u, _ = ops.ln_bwd(d_ret, zk, sk, mlp[2].weight.data, a.atomic_target(mlp[2].weight),
                                 a.atomic_target(mlp[2].bias), a.atomic_target(mlp[0].bias), p_post=ctx.p, rng=rt.rng,
-                                sid_post=gin._sid + k, gelu_aux=uk)
+                                sid_post=gin._sid + k, gelu_aux=uk, defer=rt.defer_list())
             _wgrad(rt, d_u, h.view(B * N, H), mlp[0].weight)
             dh.append(ops.linear_dgrad(d_u, a.w(mlp[0].weight)))
         d_u, _ = ops.ln_bwd(dh[1], z1, st1, conv.linear[2].weight.data, a.atomic_target(conv.linear[2].weight),
-                            a.atomic_target(conv.linear[2].bias), a.atomic_target(conv.linear[0].bias), gelu_aux=u)
+                            a.atomic_target(conv.linear[2].bias), a.atomic_target(conv.linear[0].bias), gelu_aux=u,
+                            defer=rt.defer_list())
         _wgrad(rt, d_u, hin.view(B * N, H), conv.linear[0].weight)
         d_hin = ops.linear_dgrad(d_u, a.w(conv.linear[0].weight)).view(B, N, H)
         # hin = x + (1+eps) A x
