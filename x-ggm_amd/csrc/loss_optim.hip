@@ -352,7 +352,8 @@ extern "C" int xggm_bce_fwd(const float* l, const float* t, float* loss, int64_t
 extern "C" int xggm_sqnorm_f32(const float* g, int64_t n, float* out, hipStream_t st) {
     XGGM_REQUIRE(g && out && n > 0, "xggm_sqnorm_f32: bad arguments");
     XGGM_REQUIRE(reinterpret_cast<uintptr_t>(g) % 16 == 0, "xggm_sqnorm_f32: pointer must be 16-byte aligned");
-    hipLaunchKernelGGL(sqnorm_kernel, dim3(grid1d(n / 4 + 1, 2048)), dim3(NT), 0, st, g, n, out);
+    // at least 8 float4 per thread: the per-workgroup atomics all hit ONE address and serialise
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(grid1d(n / 32 + 1, 1024)), dim3(NT), 0, st, g, n, out);
     return xggm_check_launch("xggm_sqnorm_f32");
 }
 

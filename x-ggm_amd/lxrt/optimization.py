@@ -54,9 +54,16 @@ def clip_grad_norm_(parameters, max_norm):
     if arena is None:
         raise RuntimeError("clip_grad_norm_: parameters are not arena-managed; run a forward first")
     arena.sqnorm.zero_()
+    # adjacent active groups are one contiguous range of the flat gradient buffer: one launch
+    spans = []
     for g in arena.active_groups():
         G = arena.groups[g]
-        ops.sqnorm(arena.grads[G.start:G.end], arena.sqnorm)
+        if spans and spans[-1][1] == G.start:
+            spans[-1][1] = G.end
+        else:
+            spans.append([G.start, G.end])
+    for a, b in sorted(spans):
+        ops.sqnorm(arena.grads[a:b], arena.sqnorm)
     arena.pending_clip = float(max_norm)
     return arena.sqnorm.sqrt()
 
