@@ -38,6 +38,9 @@ struct GemmArgs {
     int accumulate;    // C += result
     float alpha;
     int a_mode, b_mode;  // 0 scalar, 1 vector along k, 2 vector along rows
+    // tuned path on shapes that are not 8-aligned (A = 2274 answers, 630 edges), see pick_mode:
+    int a_tail, b_tail;  // k-contiguous operand with K % 8 != 0: the last chunk's elements >= K are zeroed on the way to LDS
+    int a_rows, b_rows;  // rows an operand may be READ at (row-contiguous operands: padded up to a multiple of 8)
     int xcd_swizzle;
     int batch;
 #ifdef XGGM_STAMP
@@ -306,13 +309,21 @@ __device__ __forceinline__ void fast_load(short8_t (&reg)[R / 32], const OpSrc& 
 }
 
 template <int R, bool KMAJ>
-__device__ __forceinline__ void fast_store(bf16* lds, const short8_t (&reg)[R / 32], int tid) {
+__device__ __forceinline__ void fast_store(bf16* lds, const short8_t (&reg)[R / 32], int tid, int k0, int K, int tail) {
 #pragma unroll
     for (int i = 0; i < R / 32; ++i) {
         const int c = tid + NT * i;
         if (KMAJ) {
             const int row = c >> 3, kc = c & 7;
-            *reinterpret_cast<short8_t*>(lds + row * 64 + ((kc ^ ((row >> 1) & 7)) << 3)) = reg[i];
+            short8_t v = reg[i];
+            if (tail) {  // K % 8 != 0 (K even): zero what the chunk straddling K read beyond it
+                const int nv = K - (k0 + kc * 8);  // valid elements of this chunk (>= 8: all, <= 0: loaded as zeros)
+                uint4_t d = __builtin_bit_cast(uint4_t, v);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[j] = (2 * j < nv) ? d[j] : 0u;
+                v = __builtin_bit_cast(short8_t, d);
+            }
+            *reinterpret_cast<short8_t*>(lds + row * 64 + ((kc ^ ((row >> 1) & 7)) << 3)) = v;
         } else {
             const int kl = c / (R / 8), rc = (c % (R / 8)) * 8;
             *reinterpret_cast<short8_t*>(lds + kl * (R + 16) + rc) = reg[i];
@@ -550,8 +561,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile_m, int til
     const bf16* A = reinterpret_cast<const bf16*>(g.A) + (int64_t)bz * g.a_bs;
     const bf16* B = reinterpret_cast<const bf16*>(g.B) + (int64_t)bz * g.b_bs;
     // bytes from the (batch) base to the end of the operand: last row / k-row start + its valid length
-    const OpSrc sa = make_src(A, AK ? ((int64_t)(g.M - 1) * g.a_rs + g.K) * 2 : ((int64_t)(g.K - 1) * g.a_ks + g.M) * 2, g.a_rs, g.a_ks);
-    const OpSrc sb = make_src(B, BKM ? ((int64_t)(g.N - 1) * g.b_ns + g.K) * 2 : ((int64_t)(g.K - 1) * g.b_ks + g.N) * 2, g.b_ns, g.b_ks);
+    const OpSrc sa = make_src(A, AK ? ((int64_t)(g.M - 1) * g.a_rs + (g.K + 7) / 8 * 8) * 2 : ((int64_t)(g.K - 1) * g.a_ks + g.a_rows) * 2,
+                              g.a_rs, g.a_ks);
+    const OpSrc sb = make_src(B, BKM ? ((int64_t)(g.N - 1) * g.b_ns + (g.K + 7) / 8 * 8) * 2 : ((int64_t)(g.K - 1) * g.b_ks + g.b_rows) * 2,
+                              g.b_ns, g.b_ks);
 
     float4_t acc[TM][TN];
 #pragma unroll
@@ -564,11 +577,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile_m, int til
     const int nk = ((g.K + 63) / 64 + UNR - 1) / UNR * UNR;
 #pragma unroll
     for (int s = 0; s < D; ++s) {
-        fast_load<BM, AK>(ra[s], sa, m0, s * 64, g.M, g.K, tid);
-        fast_load<BN, BKM>(rb[s], sb, n0, s * 64, g.N, g.K, tid);
+        fast_load<BM, AK>(ra[s], sa, m0, s * 64, g.a_rows, g.K, tid);
+        fast_load<BN, BKM>(rb[s], sb, n0, s * 64, g.b_rows, g.K, tid);
     }
-    fast_store<BM, AK>(fsm, ra[0], tid);
-    fast_store<BN, BKM>(fsm + LA::ELEMS, rb[0], tid);
+    fast_store<BM, AK>(fsm, ra[0], tid, 0, g.K, g.a_tail);
+    fast_store<BN, BKM>(fsm + LA::ELEMS, rb[0], tid, 0, g.K, g.b_tail);
     lds_barrier();
     STAMP(g, 1);
     for (int t0 = 0; t0 < nk; t0 += UNR) {
@@ -579,8 +592,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile_m, int til
             const bf16* Bc = Ac + LA::ELEMS;
             bf16* An = fsm + ((u + 1) & 1) * STAGE;
             // stage (t % D) was copied to LDS one step ago: refill it with tile t + D
-            fast_load<BM, AK>(ra[u % D], sa, m0, (t + D) * 64, g.M, g.K, tid);
-            fast_load<BN, BKM>(rb[u % D], sb, n0, (t + D) * 64, g.N, g.K, tid);
+            fast_load<BM, AK>(ra[u % D], sa, m0, (t + D) * 64, g.a_rows, g.K, tid);
+            fast_load<BN, BKM>(rb[u % D], sb, n0, (t + D) * 64, g.b_rows, g.K, tid);
 #pragma unroll
             for (int ks = 0; ks < 64; ks += 32) {
                 bf16x8_t a[TM], b[TN];
@@ -596,8 +609,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile_m, int til
                         // row fr, columns 4 fq .. 4 fq + 3 -- four values that are contiguous in C
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
             }
-            fast_store<BM, AK>(An, ra[(u + 1) % D], tid);
-            fast_store<BN, BKM>(An + LA::ELEMS, rb[(u + 1) % D], tid);
+            fast_store<BM, AK>(An, ra[(u + 1) % D], tid, (t + 1) * 64, g.K, g.a_tail);
+            fast_store<BN, BKM>(An + LA::ELEMS, rb[(u + 1) % D], tid, (t + 1) * 64, g.K, g.b_tail);
             lds_barrier();
         }
     }
@@ -746,11 +759,31 @@ inline int launch_fast(const GemmArgs& g, int batch, hipStream_t stream) {
     }
 }
 
-template <typename T> int pick_mode(const void* base, int64_t rs, int64_t ks, int64_t bs, int R, int K) {
+// How an operand can be loaded by the tuned kernels: 1 = 16-byte chunks along k, 2 = along rows, 0 = neither.
+// A dimension that is not a multiple of 8 is accepted when the operand's own leading stride leaves room to
+// read the chunk that straddles the edge (caller-padded buffers: the 2274-answer and 630-edge heads):
+// k-contiguous with K % 8 != 0 needs rs >= roundup(K, 8) (the excess is zeroed in fast_store: `tail`),
+// row-contiguous with R % 8 != 0 needs ks >= roundup(R, 8) (the excess rows only feed outputs that are
+// never stored: `rows` = the padded count).
+template <typename T> int pick_mode(const void* base, int64_t rs, int64_t ks, int64_t bs, int R, int K, int* tail, int* rows) {
     constexpr int VEC = Tile<T>::VEC;
+    *tail = 0;
+    *rows = R;
     const bool base_ok = (reinterpret_cast<uintptr_t>(base) % 16 == 0) && (bs % VEC == 0);
-    if (ks == 1 && base_ok && rs % VEC == 0 && K % VEC == 0) return 1;
-    if (rs == 1 && base_ok && ks % VEC == 0 && R % VEC == 0) return 2;
+    if (ks == 1 && base_ok && rs % VEC == 0) {
+        if (K % VEC == 0) return 1;
+        if (sizeof(T) == 2 && K % 2 == 0 && rs >= (K + VEC - 1) / VEC * VEC) {
+            *tail = 1;
+            return 1;
+        }
+    }
+    if (rs == 1 && base_ok && ks % VEC == 0) {
+        if (R % VEC == 0) return 2;
+        if (sizeof(T) == 2 && ks >= (R + VEC - 1) / VEC * VEC) {
+            *rows = (R + VEC - 1) / VEC * VEC;
+            return 2;
+        }
+    }
     return 0;
 }
 
@@ -761,13 +794,16 @@ template <typename T> int launch(GemmArgs g, int batch, hipStream_t stream) {
     XGGM_REQUIRE(g.act >= 0 && g.act <= XGGM_ACT_GELU_GRAD, "xggm_gemm: bad activation %d", g.act);
     XGGM_REQUIRE(g.act != XGGM_ACT_GELU_GRAD || g.aux, "xggm_gemm: GELU_GRAD needs aux");
     XGGM_REQUIRE(g.ldc >= g.N, "xggm_gemm: ldc %lld < N %d", (long long)g.ldc, g.N);
-    g.a_mode = pick_mode<T>(g.A, g.a_rs, g.a_ks, g.a_bs, g.M, g.K);
-    g.b_mode = pick_mode<T>(g.B, g.b_ns, g.b_ks, g.b_bs, g.N, g.K);
+    g.a_mode = pick_mode<T>(g.A, g.a_rs, g.a_ks, g.a_bs, g.M, g.K, &g.a_tail, &g.a_rows);
+    g.b_mode = pick_mode<T>(g.B, g.b_ns, g.b_ks, g.b_bs, g.N, g.K, &g.b_tail, &g.b_rows);
     dim3 grid(ceil_div(g.N, BN), ceil_div(g.M, BM), batch);
     XGGM_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "xggm_gemm: grid too large");
     if constexpr (sizeof(T) == 2) {
         if (g.a_mode != 0 && g.b_mode != 0 && !g_force_generic) return launch_fast(g, batch, stream);
     }
+    // the generic kernel's vector loads assume exact multiples: padded-edge operands load element-wise there
+    if (g.a_tail || g.a_rows != g.M) g.a_mode = 0;
+    if (g.b_tail || g.b_rows != g.N) g.b_mode = 0;
     hipLaunchKernelGGL(gemm_kernel<T>, grid, dim3(NT), 0, stream, g);
     return xggm_check_launch("xggm_gemm");
 }
@@ -825,8 +861,8 @@ template <typename T> int grouped(const xggm_gemm_problem* probs, int n, hipStre
     for (int i = 0; i < n && fast; ++i) {
         GemmArgs g = from_problem(probs[i]);
         if (!(g.M > 0 && g.N > 0 && g.K > 0 && g.batch > 0 && g.A && g.B && g.C)) fast = false;
-        g.a_mode = pick_mode<T>(g.A, g.a_rs, g.a_ks, g.a_bs, g.M, g.K);
-        g.b_mode = pick_mode<T>(g.B, g.b_ns, g.b_ks, g.b_bs, g.N, g.K);
+        g.a_mode = pick_mode<T>(g.A, g.a_rs, g.a_ks, g.a_bs, g.M, g.K, &g.a_tail, &g.a_rows);
+        g.b_mode = pick_mode<T>(g.B, g.b_ns, g.b_ks, g.b_bs, g.N, g.K, &g.b_tail, &g.b_rows);
         if (g.a_mode == 0 || g.b_mode == 0) fast = false;
         ga.p[i] = g;
     }

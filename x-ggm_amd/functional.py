@@ -410,6 +410,11 @@ class LinearActFn(Function):
             g = ops.tanh_bwd(dy, y)
         else:
             g = ops.cast_from_f32(dy, dt) if dy.dtype == F32 and dt != F32 else dy
+        if g.shape[1] % 8 and dt != F32:
+            # an output width that is not a multiple of 8 (2274 answers, 630 edges): zero-pad the row stride so the
+            # backward products run on the tuned GEMM path (see pick_mode in gemm.hip) instead of the generic kernel
+            N = g.shape[1]
+            g = torch.nn.functional.pad(g, (0, (-N) % 8))[:, :N]
         if lin.bias is not None:
             _colsum(rt, g, lin.bias)
         probs, dx = [_p_wgrad(rt, g, x2, lin.weight)], None

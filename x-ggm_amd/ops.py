@@ -123,8 +123,12 @@ class GemmProblem(_ct.Structure):
 
 def _problem(A, B, C, M, N, K, a_rs, a_ks, b_ns, b_ks, ldc, bias=None, residual=None, preact=None, aux=None,
              act=ACT_NONE, c_f32=False, accumulate=False, colsum=None):
-    return GemmProblem(ptr(A), ptr(B), ptr(C), M, N, K, a_rs, a_ks, b_ns, b_ks, ldc, 1, 0, 0, 0, ptr(bias),
-                       ptr(residual), ptr(preact), ptr(aux), ptr(colsum), act, int(c_f32), int(accumulate), 1.0)
+    p = GemmProblem(ptr(A), ptr(B), ptr(C), M, N, K, a_rs, a_ks, b_ns, b_ks, ldc, 1, 0, 0, 0, ptr(bias),
+                    ptr(residual), ptr(preact), ptr(aux), ptr(colsum), act, int(c_f32), int(accumulate), 1.0)
+    # the descriptor holds raw pointers and may be launched later (grouped with other problems): it keeps its
+    # operands alive, otherwise the caching allocator can hand their memory to the next torch.empty
+    p.keep = (A, B, C, bias, residual, preact, aux, colsum)
+    return p
 
 
 def p_fwd(x, w, bias=None, act=ACT_NONE, want_preact=False, out_f32=False):
