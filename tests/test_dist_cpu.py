@@ -40,6 +40,12 @@ def _worker(rank, world, port, q):
         g2 = base * (rank + 1)
         GradSync(g2, wire_dtype=torch.bfloat16, bucket_elems=4096).sync([(0, n)])
         ok &= bool(((g2 - mean).abs() <= 8e-3 * mean.abs() + 1e-6).all())
+        # many small buckets: both wire buffers are reused several times; untouched gaps stay untouched
+        g3 = base * (rank + 1)
+        GradSync(g3, wire_dtype=torch.bfloat16, bucket_elems=700).sync(ranges)
+        for s, e in ranges:
+            ok &= bool(((g3[s:e] - mean[s:e]).abs() <= 8e-3 * mean[s:e].abs() + 1e-6).all())
+        ok &= torch.equal(g3[:8], base[:8] * (rank + 1)) and torch.equal(g3[1000:2000], base[1000:2000] * (rank + 1))
         # every rank follows rank 0's branch
         br = sync_branch(rank == 0, "cpu")
         ok &= (br is True)

@@ -53,15 +53,29 @@ class GradSync:
         use_avg = self.backend == "nccl"
         op = dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM
         if self.wire_dtype is not None and self.wire_dtype != self.g.dtype:
-            if self._wire is None or self._wire.numel() < self.bucket_elems:
-                self._wire = torch.empty(self.bucket_elems, device=self.g.device, dtype=self.wire_dtype)
-            for s, e in buckets:
-                w = self._wire[:e - s]
-                w.copy_(self.g[s:e])
-                dist.all_reduce(w, op=op, group=self.group)
-                self.g[s:e].copy_(w)
+            # two wire buffers: the cast of bucket i+1 and the copy-back of bucket i-1 run on the compute
+            # stream while bucket i is on the links (RCCL's stream); a buffer is reused only after the
+            # copy-back of its previous occupant has been enqueued behind that bucket's completion
+            if self._wire is None or self._wire[0].numel() < self.bucket_elems:
+                self._wire = [torch.empty(self.bucket_elems, device=self.g.device, dtype=self.wire_dtype)
+                              for _ in range(2)]
+
+            def finish(i):
+                s, e = buckets[i]
+                works[i].wait()
+                self.g[s:e].copy_(self._wire[i % 2][:e - s])
                 if not use_avg:
                     self.g[s:e].div_(self.world)
+
+            works = []
+            for i, (s, e) in enumerate(buckets):
+                if i >= 2:
+                    finish(i - 2)  # frees wire[i % 2]
+                w = self._wire[i % 2][:e - s]
+                w.copy_(self.g[s:e])
+                works.append(dist.all_reduce(w, op=op, group=self.group, async_op=True))
+            for i in range(max(0, len(buckets) - 2), len(buckets)):
+                finish(i)
             return
         works = [dist.all_reduce(self.g[s:e], op=op, group=self.group, async_op=True) for s, e in buckets]
         for w in works:
