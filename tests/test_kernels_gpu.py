@@ -637,6 +637,14 @@ def test_sqnorm_and_clip(ops):
     ops.sqnorm(gp[:n], out)
     ref = float((g.double() ** 2).sum())
     assert abs(float(out) - ref) < 1e-5 * ref
+    # fixed summation order: repeated calls (and hence data-parallel replicas) agree bit for bit
+    big = torch.randn(20_000_001, generator=torch.Generator().manual_seed(2)).to(DEV)[:20_000_000]
+    vals = []
+    for _ in range(6):
+        o = torch.zeros(1, device=DEV)
+        ops.sqnorm(big, o)
+        vals.append(float(o))
+    assert len(set(vals)) == 1 and abs(vals[0] - float((big.double() ** 2).sum())) < 1e-5 * vals[0]
     # clip: grads 100x too large are scaled to norm 5 before the update
     p = torch.ones(8, device=DEV)
     G = torch.full((8,), 100.0, device=DEV)

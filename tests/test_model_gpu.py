@@ -265,6 +265,50 @@ def test_gqa_order_iteration_matches_oracle_fp32(gnn):
         assert rel_err(sd[n], P[n]) < 1e-4, n
 
 
+@pytest.mark.parametrize("kind", ["plain", "rel", "node"])
+def test_two_stage_backward_gives_the_same_gradients(kind):
+    """the data-parallel overlap cuts the autograd graph below the cross-modality layers and runs the
+    backward in two stages (Runtime.backward): every gradient must equal the one-stage result, and at the
+    cut the gradients of everything above it (x-layer matrices, heads, generator) must already be final."""
+    from oracle import shapes
+    from xggm_amd.runtime import runtime_of
+    from xggm_amd.dist import split_ranges, active_ranges
+    from xggm_amd.vqa.vqacpv2 import forward_backward_plain, forward_backward_ggm, BCEWithLogitsLoss
+    cfg, A, B, seed = shapes.TINY, 29, 4, 6
+    bn = synth.vqa_batch(B, A=A, F=cfg["feat_dim"], vocab=cfg["vocab"], seed=seed)
+    bn["randn_node"] = synth.randn_nodes(B, 36, cfg["hidden"], seed)
+    b = batch_tensors(bn, DEV)
+    sent = (b["input_ids"], b["input_mask"], b["segment_ids"])
+    bce = BCEWithLogitsLoss()
+    res = []
+    for cut in (False, True):
+        m = build_model(cfg, A, seed=seed, dt=F32).eval()
+        m(b["feats"], b["boxes"], sent)  # builds the arena
+        rt = runtime_of(m)
+        rt.cut_enabled = cut
+        seen = {}
+
+        def between():
+            up, _ = split_ranges(rt.arena, active_ranges(rt.arena))
+            seen["upper"] = [(s, e, rt.arena.grads[s:e].clone()) for s, e in up]
+
+        if kind == "plain":
+            forward_backward_plain(m, bce, b["feats"], b["boxes"], sent, b["target"], between=between)
+        else:
+            forward_backward_ggm(m, bce, b["feats"], b["boxes"], sent, b["target"], b["adj_true"], kind,
+                                 randn=b["randn_adj"] if kind == "rel" else b["randn_node"], between=between)
+        torch.cuda.synchronize()
+        if cut:
+            assert seen["upper"] and sum(e - s for s, e, _ in seen["upper"]) > 0
+            for s, e, g in seen["upper"]:
+                assert torch.equal(g, rt.arena.grads[s:e]), "a gradient above the cut changed after the cut"
+        res.append(grads_by_name(m))
+    assert res[0].keys() == res[1].keys()
+    for n in res[0]:  # (key-bias gradients are mathematically zero: absolute floor)
+        d = float((res[1][n] - res[0][n]).norm())
+        assert d < 1e-5 * float(res[0][n].norm()) + 1e-8, (n, d)
+
+
 def test_train_iteration_bf16_matches_oracle_trend():
     """bf16 execution of one full iteration (both passes) on the tiny model: losses within
     2 % of the fp32 oracle trajectory and the model keeps improving on the fixed batch."""

@@ -1,0 +1,74 @@
+"""Rehearsal of the data-parallel engine paths on ONE GPU: world size 2 over gloo, both ranks on cuda:0, a tiny
+model, DIFFERENT batches per rank.  Checks (a) replicas stay identical (the exchange really happens), (b) the
+overlapped three-graph path gives the same parameters as the plain two-graph path.
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 tools/dp_rehearsal.py"""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def run(overlap, rank, use_graph=True, iters=("rel", "node", "rel")):
+    from oracle import shapes
+    from xggm_amd import synth
+    from xggm_amd.engine import CapturedTrainer
+    from xggm_amd.vqa.vqacpv2 import enable_data_parallel, make_optimizer
+    from test_model_gpu import build_model, batch_tensors
+    cfg, A, B = shapes.TINY, 29, 4
+    m = build_model(cfg, A, seed=5, dt=torch.bfloat16)
+    bn = synth.vqa_batch(B, A=A, F=cfg["feat_dim"], vocab=cfg["vocab"], seed=100 + rank)  # rank-specific data
+    b = batch_tensors(bn, "cuda")
+    m(b["feats"], b["boxes"], (b["input_ids"], b["input_mask"], b["segment_ids"]))
+    opt = make_optimizer(m, 1e-3, 20)
+    enable_data_parallel(m, wire_dtype=torch.bfloat16, overlap=overlap)
+    tr = CapturedTrainer(m, opt, b, sigma=1.0, order="vqa", use_graph=use_graph, warmup_iters=1)
+    for br in iters:
+        tr.iteration(br)
+    torch.cuda.synchronize()
+    run.names = [(n, p.numel()) for n, p in m.named_parameters()]
+    return torch.cat([p.detach().float().flatten() for p in m.parameters()])
+
+
+def report(v, rank, tag):
+    other = [torch.empty_like(v) for _ in range(2)]
+    dist.all_gather(other, v)
+    if rank == 0:
+        d = (other[0] - other[1]).abs()
+        print("%s: max |rank0 - rank1| = %.3e" % (tag, float(d.max())), flush=True)
+        o, worst = 0, []
+        for n, k in run.names:
+            worst.append((float(d[o:o + k].max()), n))
+            o += k
+        worst.sort(reverse=True)
+        print("   worst:", worst[:6], flush=True)
+
+
+def main():
+    rank = int(os.environ["RANK"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    out = {}
+    report(run(False, rank, use_graph=False, iters=("rel",)), rank, "eager, 1 iteration")
+    for overlap in (False, True):
+        v = run(overlap, rank)
+        other = [torch.empty_like(v) for _ in range(2)]
+        dist.all_gather(other, v)
+        same = bool(torch.equal(other[0], other[1]))
+        out[overlap] = v
+        if rank == 0:
+            print("overlap=%s: replicas identical: %s, |params| = %.6f" % (overlap, same, float(v.double().norm())), flush=True)
+        assert same, "replicas diverged: the gradient exchange did not happen"
+    d = float((out[True] - out[False]).double().norm() / out[False].double().norm())
+    if rank == 0:
+        print("overlapped vs plain exchange: relative parameter difference %.2e" % d, flush=True)
+    assert d < 2e-3
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(NT) void bce_bwd_kernel(const float* __restrict__ l
 }
 
 // ------------------------------------------------------------------------------- optimiser
-__global__ __launch_bounds__(NT) void sqnorm_kernel(const float* __restrict__ g, int64_t n, float* out) {
+__global__ __launch_bounds__(NT) void sqnorm_kernel(const float* __restrict__ g, int64_t n, float* out, float* ws) {
     float acc = 0.f;
     const int64_t n4 = n >> 2;
     typedef float __attribute__((ext_vector_type(4))) f4;
@@ -169,7 +169,25 @@ __global__ __launch_bounds__(NT) void sqnorm_kernel(const float* __restrict__ g,
         acc += v * v;
     }
     acc = block_sum(acc);
-    if (threadIdx.x == 0) atomicAdd(out, acc);
+    // fixed-order finish: every workgroup parks its partial, the LAST one to arrive adds them up in index
+    // order (no floating-point atomics: replicas holding the same gradients get the same bits)
+    unsigned* counter = reinterpret_cast<unsigned*>(ws + 1024);
+    __shared__ bool last;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(ws + blockIdx.x, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last = atomicAdd(counter, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    float t = 0.f;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += NT) t += __hip_atomic_load(ws + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = block_sum(t);
+    if (threadIdx.x == 0) {
+        *out += t;
+        *counter = 0u;
+    }
 }
 
 struct AdamArgs {
@@ -349,11 +367,11 @@ extern "C" int xggm_bce_fwd(const float* l, const float* t, float* loss, int64_t
     return xggm_check_launch("xggm_bce_fwd");
 }
 
-extern "C" int xggm_sqnorm_f32(const float* g, int64_t n, float* out, hipStream_t st) {
-    XGGM_REQUIRE(g && out && n > 0, "xggm_sqnorm_f32: bad arguments");
+extern "C" int xggm_sqnorm_f32(const float* g, int64_t n, float* out, float* ws, hipStream_t st) {
+    XGGM_REQUIRE(g && out && ws && n > 0, "xggm_sqnorm_f32: bad arguments");
     XGGM_REQUIRE(reinterpret_cast<uintptr_t>(g) % 16 == 0, "xggm_sqnorm_f32: pointer must be 16-byte aligned");
     // at least 8 float4 per thread: the per-workgroup atomics all hit ONE address and serialise
-    hipLaunchKernelGGL(sqnorm_kernel, dim3(grid1d(n / 32 + 1, 1024)), dim3(NT), 0, st, g, n, out);
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(grid1d(n / 32 + 1, 1024)), dim3(NT), 0, st, g, n, out, ws);
     return xggm_check_launch("xggm_sqnorm_f32");
 }
 

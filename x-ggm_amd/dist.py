@@ -44,6 +44,7 @@ class GradSync:
         self.bucket_elems = bucket_elems
         self.backend = dist.get_backend(group) if dist.is_initialized() else None
         self._wire = None
+        self._flight = None
 
     def sync(self, ranges):
         """average ``flat_grads[s:e]`` over ranks for every (s, e) in ``ranges``."""
@@ -83,6 +84,72 @@ class GradSync:
         if not use_avg:
             for s, e in buckets:
                 self.g[s:e].div_(self.world)
+
+
+    # ---- split form: ``begin`` puts the ranges on the wire and returns at once, ``finish`` waits and writes back
+    def begin(self, ranges):
+        if self.world == 1 or not ranges:
+            return None
+        buckets = ranges_to_buckets(ranges, self.bucket_elems)
+        use_avg = self.backend == "nccl"
+        op = dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM
+        wire = None
+        if self.wire_dtype is not None and self.wire_dtype != self.g.dtype:
+            total = sum(e - s for s, e in buckets)
+            # a dedicated buffer for everything in flight (nothing may be reused before ``finish``)
+            if self._flight is None or self._flight.numel() < total:
+                self._flight = torch.empty(total, device=self.g.device, dtype=self.wire_dtype)
+            wire, o = [], 0
+            for s, e in buckets:
+                w = self._flight[o:o + e - s]
+                w.copy_(self.g[s:e])
+                wire.append(w)
+                o += e - s
+            works = [dist.all_reduce(w, op=op, group=self.group, async_op=True) for w in wire]
+        else:
+            works = [dist.all_reduce(self.g[s:e], op=op, group=self.group, async_op=True) for s, e in buckets]
+        return (buckets, wire, works, use_avg)
+
+    def finish(self, handle):
+        if handle is None:
+            return
+        buckets, wire, works, use_avg = handle
+        for i, (s, e) in enumerate(buckets):
+            works[i].wait()
+            if wire is not None:
+                self.g[s:e].copy_(wire[i])
+            if not use_avg:
+                self.g[s:e].div_(self.world)
+
+
+def split_ranges(arena, ranges):
+    """(upper, lower) parts of the active ``ranges``: upper = everything whose gradient is final once the
+    backward has passed the cut below the cross-modality layers -- the x-layer weight matrices inside
+    ``enc_main`` and all groups after it (enc_tail, heads, generator); lower = the rest of ``enc_main``
+    (embeddings, single-modality layers, pooler, and its vector region)."""
+    main = arena.groups.get("enc_main")
+    if main is None:
+        return [], list(ranges)
+    xs = [(o, o + k) for n, (o, k, g, atomic) in arena.info.items()
+          if g == "enc_main" and not atomic and ".x_layers." in n]
+    if not xs:
+        return [], list(ranges)
+    x0, x1 = min(a for a, _ in xs), max(b for _, b in xs)
+    inside = [(o, o + k) for n, (o, k, g, atomic) in arena.info.items()
+              if g == "enc_main" and not atomic and x0 <= o < x1 and ".x_layers." not in n]
+    if inside:  # the x-layer matrices are not one contiguous run: do not split
+        return [], list(ranges)
+    upper, lower = [], []
+    for s, e in ranges:
+        if s >= main.end:
+            upper.append((s, e))
+        elif s == main.start and e == main.end:
+            lower.append((s, x0))
+            upper.append((x0, x1))
+            lower.append((x1, e))
+        else:
+            lower.append((s, e))
+    return [r for r in upper if r[1] > r[0]], [r for r in lower if r[1] > r[0]]
 
 
 def sync_branch(branch_is_rel, device, group=None):

@@ -9,8 +9,12 @@ replay needs to differ from the previous one lives in device memory: the batch (
 buffers), the Philox offset, the per-group step counters and schedule values.
 
 With data parallelism each pass is captured as two graphs (forward+backward | clip+update)
-and the gradient all-reduce runs between them on the live RCCL communicator.
+and the gradient all-reduce runs between them on the live RCCL communicator; with the overlap
+option (default) the backward is cut below the cross-modality layers into a third graph, and the
+gradients above the cut are already on the wire while the lower backward graph replays.
 """
+import gc
+
 import torch
 
 from .runtime import runtime_of
@@ -38,14 +42,15 @@ class CapturedTrainer:
             self._capture(warmup_iters)
 
     # ------------------------------------------------------------------ the two halves of a pass
-    def _fwd_bwd(self, kind):
+    def _fwd_bwd(self, kind, between=None):
         s = self.static
         sent = (s["input_ids"], s["input_mask"], s["segment_ids"])
         if kind == "plain":
-            loss, logit = forward_backward_plain(self.model, self.bce, s["feats"], s["boxes"], sent, s["target"])
+            loss, logit = forward_backward_plain(self.model, self.bce, s["feats"], s["boxes"], sent, s["target"],
+                                                 between=between)
         else:
             loss, logit, _ = forward_backward_ggm(self.model, self.bce, s["feats"], s["boxes"], sent, s["target"],
-                                                  s["adj_true"], kind, self.sigma, self.kl_weight)
+                                                  s["adj_true"], kind, self.sigma, self.kl_weight, between=between)
         return loss, logit
 
     def _update(self):
@@ -54,8 +59,22 @@ class CapturedTrainer:
         return total
 
     def _eager_pass(self, kind):
-        loss, logit = self._fwd_bwd(kind)
-        _sync_grads(self.model)
+        if self.split and self.rt.cut_enabled:
+            from .dist import active_ranges, split_ranges
+            gs, st = self.model._grad_sync, {}
+
+            def between():  # gradients above the cut are final: put them on the wire
+                st["upper"] = split_ranges(self.rt.arena, active_ranges(self.rt.arena))[0]
+                st["h"] = gs.begin(st["upper"])
+
+            loss, logit = self._fwd_bwd(kind, between)
+            lower = split_ranges(self.rt.arena, active_ranges(self.rt.arena))[1] if st.get("upper") else \
+                active_ranges(self.rt.arena)
+            gs.sync(lower)
+            gs.finish(st.get("h"))
+        else:
+            loss, logit = self._fwd_bwd(kind)
+            _sync_grads(self.model)
         total = self._update()
         return loss, logit, total
 
@@ -78,7 +97,7 @@ class CapturedTrainer:
                 pool = g.pool()
                 self.graphs[kind] = (g,)
                 self.outputs[kind] = out
-            else:
+            elif not self.rt.cut_enabled:
                 g1 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g1, pool=pool):
                     loss, logit = self._fwd_bwd(kind)
@@ -90,6 +109,39 @@ class CapturedTrainer:
                 with torch.cuda.graph(g2, pool=pool):
                     total = self._update()
                 self.graphs[kind] = (g1, g2, ranges)
+                self.outputs[kind] = (loss, logit, total)
+            else:
+                # three graphs: forward + backward above the cut | backward below the cut | clip + update.
+                # The capture is switched from the first to the second graph inside Runtime.backward.
+                from .dist import active_ranges, split_ranges
+                ga, gb, gc_ = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                st = {}
+
+                def switch():
+                    ga.capture_end()
+                    st["upper"] = split_ranges(self.rt.arena, active_ranges(self.rt.arena))[0]
+                    gb.capture_begin(pool=ga.pool())
+
+                torch.cuda.synchronize()
+                gc.collect()
+                torch.cuda.empty_cache()
+                cap = torch.cuda.Stream()
+                cap.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(cap):
+                    if pool is None:
+                        ga.capture_begin()
+                    else:
+                        ga.capture_begin(pool=pool)
+                    loss, logit = self._fwd_bwd(kind, switch)
+                    gb.capture_end()
+                torch.cuda.current_stream().wait_stream(cap)
+                pool = ga.pool()
+                upper, lower = split_ranges(self.rt.arena, active_ranges(self.rt.arena))
+                if not st.get("upper"):
+                    upper, lower = [], active_ranges(self.rt.arena)
+                with torch.cuda.graph(gc_, pool=pool):
+                    total = self._update()
+                self.graphs[kind] = (ga, gb, gc_, upper, lower)
                 self.outputs[kind] = (loss, logit, total)
         torch.cuda.synchronize()
 
@@ -105,10 +157,19 @@ class CapturedTrainer:
         gs = self.graphs[kind]
         if len(gs) == 1:
             gs[0].replay()
-        else:
+        elif len(gs) == 3:
             gs[0].replay()
             self.model._grad_sync.sync(gs[2])
             gs[1].replay()
+        else:
+            ga, gb, gc_, upper, lower = gs
+            sync = self.model._grad_sync
+            ga.replay()
+            h = sync.begin(upper)   # on the links while the lower backward graph runs
+            gb.replay()
+            sync.sync(lower)
+            sync.finish(h)
+            gc_.replay()
         return self.outputs[kind]
 
     def iteration(self, branch):

@@ -28,6 +28,33 @@ class Runtime:
         self.p_readout = 0.5  # GCN/GIN read-out dropout (src/module/gcn.py:33)
         self.pending = []     # deferred second stages of the LN backwards of the running backward pass
         self._task = -1       # autograd graph task the pending jobs belong to
+        # two-stage backward (data parallelism): the autograd graph is cut between the single-modality layers
+        # and the cross-modality layers so the gradients of everything above the cut can be on the wire
+        # while the backward below it still runs
+        self.cut_enabled = False
+        self._cut = None
+
+    def make_cut(self, *tensors):
+        """called by LXRTEncoder.forward at the cut: returns detached leaves to continue with"""
+        leaves = [t.detach().requires_grad_(True) for t in tensors]
+        self._cut = (list(tensors), leaves)
+        return leaves
+
+    def backward(self, loss, between=None):
+        """loss.backward(), in two stages when the forward recorded a cut: stage 1 stops at the cut leaves,
+        ``between()`` runs (gradients above the cut are final), stage 2 continues below the cut."""
+        cut, self._cut = self._cut, None
+        loss.backward()
+        if cut is None:
+            if between is not None:
+                between()
+            return
+        if between is not None:
+            between()
+        outs, leaves = cut
+        pairs = [(o, l.grad) for o, l in zip(outs, leaves) if l.grad is not None]
+        if pairs:
+            torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
 
     def defer_list(self):
         """list the LN backwards of the running autograd backward append their reduce jobs to; the

@@ -356,6 +356,9 @@ class LXRTEncoder(nn.Module):
             lang_feats = layer_module(lang_feats, lang_attention_mask)
         for layer_module in self.r_layers[n_pair:]:
             visn_feats = layer_module(visn_feats, visn_attention_mask)
+        rt = runtime_of(self)
+        if rt.cut_enabled and torch.is_grad_enabled() and lang_feats.requires_grad and visn_feats.requires_grad:
+            lang_feats, visn_feats = rt.make_cut(lang_feats, visn_feats)  # see Runtime.backward
         for layer_module in self.x_layers:
             lang_feats, visn_feats = layer_module(lang_feats, lang_attention_mask, visn_feats, visn_attention_mask)
         return lang_feats, visn_feats

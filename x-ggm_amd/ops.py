@@ -663,9 +663,16 @@ def bce_bwd(logit, target, gout, coef, dt):
 
 
 # ----------------------------------------------------------------------------- optimiser / utils
+_SQNORM_WS = {}
+
+
 def sqnorm(g, out):
+    """out += sum g^2 (fixed summation order: see xggm.h)."""
     _c(g, F32), _c(out, F32)
-    call("xggm_sqnorm_f32", ptr(g), g.numel(), ptr(out), stream())
+    ws = _SQNORM_WS.get(g.device)
+    if ws is None:  # zeroed once; the kernel leaves its arrival counter at zero
+        ws = _SQNORM_WS[g.device] = torch.zeros(1028, device=g.device, dtype=F32)
+    call("xggm_sqnorm_f32", ptr(g), g.numel(), ptr(out), ptr(ws), stream())
 
 
 def bertadam(p, g, m, v, shadow, sqn, max_norm, lr, lr_scale, b1, b2, eps, wd):

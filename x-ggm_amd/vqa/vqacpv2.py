@@ -41,13 +41,20 @@ def remove_diagonal(adj_true):
     return adj_true.triu(1) + adj_true.tril(-1)
 
 
-def enable_data_parallel(model, group=None, wire_dtype=None):
+def enable_data_parallel(model, group=None, wire_dtype=None, overlap=None):
     """one process per GPU: average the flat gradient arena over ``group`` between backward and
-    the fused clip + BertAdam of every pass (xggm_amd.dist.GradSync); replicas start equal."""
+    the fused clip + BertAdam of every pass (xggm_amd.dist.GradSync); replicas start equal.
+    ``overlap`` (default on; XGGM_DP_OVERLAP=0 turns it off): cut the backward between the single-modality
+    and the cross-modality layers so the all-reduce of the upper 60 % of the gradients runs under the
+    backward of the lower layers (engine.CapturedTrainer)."""
+    import os
     from ..dist import GradSync, broadcast_params
-    arena = runtime_of(model).arena
-    broadcast_params(arena, group)
-    object.__setattr__(model, "_grad_sync", GradSync(arena.grads, group, wire_dtype))
+    rt = runtime_of(model)
+    broadcast_params(rt.arena, group)
+    object.__setattr__(model, "_grad_sync", GradSync(rt.arena.grads, group, wire_dtype))
+    if overlap is None:
+        overlap = os.environ.get("XGGM_DP_OVERLAP", "1") != "0"
+    rt.cut_enabled = bool(overlap)
     return model
 
 
@@ -58,18 +65,19 @@ def _sync_grads(model):
         gs.sync(active_ranges(runtime_of(model).arena))
 
 
-def forward_backward_plain(model, bce_loss, feats, boxes, sent, target):
-    """step A up to backward: src/vqa/vqacpv2.py:170-174"""
+def forward_backward_plain(model, bce_loss, feats, boxes, sent, target, between=None):
+    """step A up to backward: src/vqa/vqacpv2.py:170-174.  ``between``: callback between the two backward
+    stages when the runtime cuts the graph (Runtime.backward)."""
     model.zero_grad()
     _, _, x = model(feats, boxes, sent)
     logit = model.logit_fc(x)
     loss = bce_loss(logit, target) * target.size(1)
-    loss.backward()
+    runtime_of(model).backward(loss, between)
     return loss.detach(), logit.detach()
 
 
 def forward_backward_ggm(model, bce_loss, feats, boxes, sent, target, adj_true, branch, sigma=1.0, kl_weight=8.0,
-                         randn=None):
+                         randn=None, between=None):
     """step B up to backward: relation generation (branch 'rel', src/vqa/vqacpv2.py:195-222) or
     representation generation ('node', :228-251).  ``randn`` injects the Gaussian draw
     (parity tests); None = in-kernel Philox."""
@@ -102,7 +110,7 @@ def forward_backward_ggm(model, bce_loss, feats, boxes, sent, target, adj_true, 
     logit = model.logit_fc(x_gen)
     loss = bce_loss(logit, target) * A
     loss = loss + w_sm * loss_sm
-    loss.backward()
+    rt.backward(loss, between)
     return loss.detach(), logit.detach(), dict(d_loss=d_loss.detach(), loss_grad=loss_grad.detach())
 
 
