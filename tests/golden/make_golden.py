@@ -349,8 +349,42 @@ def train_case(tag, cfg, B, A, seed, gnn="GCN"):
     np.savez_compressed(os.path.join(HERE, tag + ".npz"), **res)
 
 
+# ---- host tokeniser + feature conversion (src/lxrt/tokenization.py:72-348, entry.py:37-72) ----------------------
+TOK_VOCAB = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", "what", "is", "the", "man", "woman", "hold", "##ing", "##s",
+             "a", "an", "of", "on", "in", "color", "colour", "dog", "cat", "##like", "un", "##aff", "##able", ",", ".",
+             "?", "!", "'", "-", "cafe", "how", "many", "people", "are", "there", "two", "2", "##0", "##1", "19",
+             "table", "left", "right", "to", "red", "blue", "green", "bus", "street", "sign", "play", "##ed", "##er",
+             "tennis", "racket", "snow", "##board", "skate", "kite", "fly", "water", "sky", "yes", "no", "it", "s",
+             "t", "don", "\u4eba", "\u5c71", "##ly", "quick", "why", "who", "where", "wear", "hat", "umbrella"]
+TOK_SENTS = ["What is the man HOLDING?", "unaffable, caf\u00e9 zzz", "How many people are there?", "  is   it a dog-like cat?! ",
+             "What color is the bus on the left of the street sign", "don't fly the kite in the sky.",
+             "\u4eba\u5c71 what", "Who played tennis 2019?", "", "?", "the " * 40,
+             "snowboarder skateboarding quickly on water", "Where's the woman's hat\tand\numbrella",
+             "colour\u0301 of the table", "Why is the man wearing an umbrellahatumbrellahat" + "x" * 120]
+
+
+def tokenizer_case():
+    import json
+    from lxrt.tokenization import BertTokenizer
+    from lxrt.entry import convert_sents_to_features
+    vocab = [w.encode().decode("unicode_escape") for w in TOK_VOCAB]
+    sents = [w.encode().decode("unicode_escape") for w in TOK_SENTS]
+    vpath = os.path.join(HERE, "vocab_small.txt")
+    with open(vpath, "w", encoding="utf-8") as f:
+        f.write("\n".join(vocab) + "\n")
+    tok = BertTokenizer(vpath, do_lower_case=True)
+    out = {"sents": sents, "tokens": [tok.tokenize(x.strip()) for x in sents], "features": {}}
+    for L in (20, 8):
+        feats = convert_sents_to_features(sents, L, tok)
+        out["features"][str(L)] = [[f.input_ids, f.input_mask, f.segment_ids] for f in feats]
+    with open(os.path.join(HERE, "tokenizer.json"), "w", encoding="utf-8") as f:
+        json.dump(out, f, ensure_ascii=True, indent=0)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["all"]
+    if "all" in which or "tok" in which:
+        tokenizer_case()
     torch.manual_seed(0)
     if "all" in which or "enc" in which:
         encoder_case("enc_tiny", TINY, 3, 1)

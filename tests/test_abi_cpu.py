@@ -2,6 +2,7 @@
 include/xggm.h declares, validates arguments before launching anything, and the host-side
 mirror keeps the reference's state_dict contract.  No kernel runs here."""
 import ctypes
+import os
 import re
 
 import pytest
@@ -133,3 +134,22 @@ def test_wordpiece_tokenizer(tmp_path):
     assert tok.tokenize("unaffable, café zzz") == ["un", "##aff", "##able", ",", "cafe", "[UNK]"]
     feats = convert_sents_to_features(["What is the man holding?"], 20, tok)
     assert feats[0].input_ids[:9] == [2, 5, 6, 7, 8, 9, 10, 11, 3] and sum(feats[0].input_mask) == 9
+
+
+def test_tokenizer_and_features_match_reference_golden():
+    """host tokeniser + [CLS]/[SEP]/padding (src/lxrt/tokenization.py:72-348, entry.py:37-72) against what the
+    reference's own BertTokenizer / convert_sents_to_features produced over a synthetic vocabulary
+    (tests/golden/make_golden.py tokenizer_case): lower-casing, accent stripping, punctuation and CJK
+    splitting, greedy WordPiece, [UNK] for unknown / over-long words, truncation, empty input."""
+    import json
+    from xggm_amd.lxrt.tokenization import BertTokenizer
+    from xggm_amd.lxrt.entry import convert_sents_to_features
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = json.load(open(os.path.join(here, "tokenizer.json"), encoding="utf-8"))
+    tok = BertTokenizer(os.path.join(here, "vocab_small.txt"), do_lower_case=True)
+    for sent, want in zip(g["sents"], g["tokens"]):
+        assert tok.tokenize(sent.strip()) == want, sent
+    for L, want in g["features"].items():
+        feats = convert_sents_to_features(g["sents"], int(L), tok)
+        got = [[f.input_ids, f.input_mask, f.segment_ids] for f in feats]
+        assert got == want, L
