@@ -371,6 +371,11 @@ int xggm_bertadam_f32(float* p, const float* g, float* m, float* v, void* shadow
 /* *lr_scale = warmup_linear(*step / t_total, warmup); *step += 1 (optimization.py:42-48) */
 int xggm_sched_step(int64_t* step, float* lr_scale, int64_t t_total, float warmup, xggm_stream_t stream);
 
+/* zero up to 16 element ranges [offset[i], offset[i] + length[i]) of one fp32 buffer in ONE launch: the
+ * atomically accumulated gradient ranges of all parameter groups at the start of a backward pass.
+ * offsets / lengths are HOST arrays (copied into the kernel arguments); both multiples of 4. */
+int xggm_zero_ranges_f32(float* base, const int64_t* offsets, const int64_t* lengths, int n, xggm_stream_t stream);
+
 /* ---- small element-wise kernels ---------------------------------------------------------
  * out = scale * (1 + *scale_ptr) * x   (GIN's (1+eps), src/module/gin.py:32) */
 int xggm_scale_f32(const void* x, void* out, int64_t n, float scale, const float* scale_ptr, xggm_stream_t stream);

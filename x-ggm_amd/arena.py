@@ -188,9 +188,7 @@ class ParamArena:
             # atomically accumulated gradient is live
             self.all_dirty = not all(q.grad is None for q in self._atomic_params)
             if not self.all_dirty:
-                for G in self.groups.values():
-                    if G.end > G.vec_start:
-                        self.grads[G.vec_start:G.end].zero_()
+                ops.zero_ranges(self.grads, [(G.vec_start, G.end) for G in self.groups.values()])  # one launch
                 self.touched.clear()
             self.vec_zeroed = True
         if self.all_dirty or not p._xg[4] or name in self.touched:

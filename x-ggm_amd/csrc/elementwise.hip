@@ -65,5 +65,44 @@ template <typename T> __global__ __launch_bounds__(NT) void cast_kernel(const fl
         return xggm_check_launch("xggm_cast_from_f32");                                                                 \
     }
 
+namespace {
+constexpr int MAX_RANGES = 16;
+struct Ranges {
+    int64_t off[MAX_RANGES], len4[MAX_RANGES];  // element offset, length in float4
+    int64_t start[MAX_RANGES + 1];              // prefix sum of len4
+    int n;
+};
+__global__ __launch_bounds__(NT) void zero_ranges_kernel(float* base, Ranges r) {
+    const int64_t total = r.start[r.n];
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        int k = 0;
+#pragma unroll
+        for (int j = 1; j < MAX_RANGES; ++j)
+            if (j < r.n && i >= r.start[j]) k = j;
+        reinterpret_cast<float4*>(base + r.off[k])[i - r.start[k]] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+}  // namespace
+
+extern "C" int xggm_zero_ranges_f32(float* base, const int64_t* offsets, const int64_t* lengths, int n, hipStream_t st) {
+    XGGM_REQUIRE(base && offsets && lengths && n > 0 && n <= MAX_RANGES, "xggm_zero_ranges_f32: bad arguments (n = %d)", n);
+    XGGM_REQUIRE(reinterpret_cast<uintptr_t>(base) % 16 == 0, "xggm_zero_ranges_f32: base must be 16-byte aligned");
+    Ranges r;
+    r.n = n;
+    int64_t tot = 0;
+    for (int i = 0; i < n; ++i) {
+        XGGM_REQUIRE(offsets[i] >= 0 && lengths[i] >= 0 && offsets[i] % 4 == 0 && lengths[i] % 4 == 0,
+                     "xggm_zero_ranges_f32: range %d is not float4-aligned", i);
+        r.off[i] = offsets[i];
+        r.len4[i] = lengths[i] / 4;
+        r.start[i] = tot;
+        tot += r.len4[i];
+    }
+    r.start[n] = tot;
+    if (tot == 0) return XGGM_OK;
+    hipLaunchKernelGGL(zero_ranges_kernel, dim3((int)std::min<int64_t>(ceil_div64(tot, NT), 4096)), dim3(NT), 0, st, base, r);
+    return xggm_check_launch("xggm_zero_ranges_f32");
+}
+
 EW_API(f32, float)
 EW_API(bf16, bf16)

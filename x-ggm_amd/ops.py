@@ -663,6 +663,17 @@ def bce_bwd(logit, target, gout, coef, dt):
 
 
 # ----------------------------------------------------------------------------- optimiser / utils
+def zero_ranges(buf, ranges):
+    """zero buf[s:e] for up to 16 (s, e) element ranges per launch (all float4-aligned)."""
+    _c(buf, F32)
+    rs = [(s, e) for s, e in ranges if e > s]
+    for i in range(0, len(rs), 16):
+        chunk = rs[i:i + 16]
+        offs = (_ct.c_int64 * len(chunk))(*[s for s, _ in chunk])
+        lens = (_ct.c_int64 * len(chunk))(*[e - s for s, e in chunk])
+        call("xggm_zero_ranges_f32", ptr(buf), _ct.cast(offs, _ct.c_void_p), _ct.cast(lens, _ct.c_void_p), len(chunk), stream())
+
+
 _SQNORM_WS = {}
 
 
