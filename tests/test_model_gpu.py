@@ -309,6 +309,36 @@ def test_two_stage_backward_gives_the_same_gradients(kind):
         assert d < 1e-5 * float(res[0][n].norm()) + 1e-8, (n, d)
 
 
+def test_lxrt_snapshot_save_load_round_trip(tmp_path):
+    """LXRTEncoderFeature.save / .load (src/lxrt/entry.py:208-238): a snapshot written by one model -- re-keyed with
+    the ``module.`` prefix of a DataParallel-trained LXMERT file and carrying a pre-training head the VQA model
+    lacks -- loads non-strictly into another model, refreshes the bf16 shadow weights the GEMMs read, and a
+    training pass then runs from the loaded state."""
+    from oracle import shapes
+    from xggm_amd.vqa.vqacpv2 import plain_pass, BCEWithLogitsLoss, make_optimizer
+    cfg, A, B = shapes.TINY, 17, 4
+    bn = synth.vqa_batch(B, A=A, F=cfg["feat_dim"], vocab=cfg["vocab"], seed=2)
+    b = batch_tensors(bn, DEV)
+    sent = (b["input_ids"], b["input_mask"], b["segment_ids"])
+    src = build_model(cfg, A, seed=21, dt=BF16).eval()
+    (l0, v0), _, x0 = src(b["feats"], b["boxes"], sent)
+    path = str(tmp_path / "snap")
+    src.lxrt_encoder.save(path)
+    sd = torch.load(path + "_LXRT.pth", map_location="cpu", weights_only=True)
+    sd = {"module." + k: v for k, v in sd.items()}
+    sd["module.cls.predictions.bias"] = torch.zeros(7)  # present in LXMERT snapshots, absent here
+    torch.save(sd, path + "_LXRT.pth")
+    dst = build_model(cfg, A, seed=22, dt=BF16).eval()
+    (l1, v1), _, x1 = dst(b["feats"], b["boxes"], sent)
+    assert not torch.equal(x0, x1)
+    dst.lxrt_encoder.load(path)
+    (l2, v2), _, x2 = dst(b["feats"], b["boxes"], sent)
+    assert torch.equal(l2, l0) and torch.equal(v2, v0) and torch.equal(x2, x0)
+    opt = make_optimizer(dst, 1e-3, 8)
+    loss, _ = plain_pass(dst, opt, BCEWithLogitsLoss(), b["feats"], b["boxes"], sent, b["target"])
+    assert np.isfinite(float(loss))
+
+
 def test_train_iteration_bf16_matches_oracle_trend():
     """bf16 execution of one full iteration (both passes) on the tiny model: losses within
     2 % of the fp32 oracle trajectory and the model keeps improving on the fixed batch."""
