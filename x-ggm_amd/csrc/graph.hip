@@ -25,10 +25,18 @@ namespace {
 constexpr int NT = 256;
 
 // ------------------------------------------------------------------------------- aggregate
+// One workgroup = 64 feature columns x SPLIT groups of output rows (SPLIT = 4): thread (col, part) keeps
+// NP / SPLIT outputs of its column in registers and walks the N input rows once.  The adjacency tile sits
+// transposed in LDS (every lane of a wave reads the same address: broadcast).  Splitting the output rows over
+// four threads quarters the serial FMA chain per thread and gives 4x the workgroups (B * H / 64) -- at B = 32
+// the one-thread-per-column form left 160 of 256 CUs idle and was bound by its own 1440-FMA chain.
+constexpr int AGG_SPLIT = 4, AGG_COLS = NT / AGG_SPLIT;
 template <typename T, int NP>
 __global__ __launch_bounds__(NT) void aggregate_kernel(const float* __restrict__ Mx, const T* __restrict__ x, T* out, int N,
                                                        int H, int mode, float scale, const float* scale_ptr, float self_w,
                                                        int accumulate) {
+    constexpr int RP = NP / AGG_SPLIT;  // output rows per thread
+    static_assert(NP % (4 * AGG_SPLIT) == 0, "row split must keep float4 reads of the adjacency rows");
     __shared__ __attribute__((aligned(16))) float Mt[NP * NP];  // Mt[j][i] = M'[i][j]
     const int b = blockIdx.y, tid = threadIdx.x;
     const float* Mb = Mx + (int64_t)b * N * N;
@@ -43,32 +51,48 @@ __global__ __launch_bounds__(NT) void aggregate_kernel(const float* __restrict__
         Mt[e] = v;
     }
     __syncthreads();
-    const int c = blockIdx.x * NT + tid;
+    const int part = tid / AGG_COLS, i0 = part * RP;  // a wave = one part: the Mt reads stay wave-uniform
+    const int c = blockIdx.x * AGG_COLS + (tid % AGG_COLS);
     if (c >= H) return;
     if (scale_ptr) scale *= (1.0f + *scale_ptr);  // GIN: (1 + eps)
     const T* xb = x + (int64_t)b * N * H + c;
-    float acc[NP];
+    float acc[RP];
 #pragma unroll
-    for (int i = 0; i < NP; ++i) acc[i] = 0.f;
-    for (int j = 0; j < N; ++j) {
-        const float xj = to_f32(xb[(int64_t)j * H]);
+    for (int i = 0; i < RP; ++i) acc[i] = 0.f;
+    // x rows in chunks of 8 with the next chunk's loads in flight: one memory round trip per chunk instead of
+    // one per row (the rows of Mt beyond N are zero, so over-read rows -- clamped to row N-1 -- add nothing)
+    constexpr int CH = 8;
+    float cur[CH], nxt[CH];
 #pragma unroll
-        for (int i = 0; i < NP; i += 4) {
-            const float4 m = *reinterpret_cast<const float4*>(Mt + j * NP + i);
-            acc[i] += m.x * xj;
-            acc[i + 1] += m.y * xj;
-            acc[i + 2] += m.z * xj;
-            acc[i + 3] += m.w * xj;
+    for (int u = 0; u < CH; ++u) cur[u] = to_f32(xb[(int64_t)min(u, N - 1) * H]);
+    for (int j0 = 0; j0 < N; j0 += CH) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) nxt[u] = to_f32(xb[(int64_t)min(j0 + CH + u, N - 1) * H]);
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const float xj = cur[u];
+            const float* mrow = Mt + (j0 + u) * NP + i0;  // j0 + u < NP because NP is a multiple of CH
+#pragma unroll
+            for (int i = 0; i < RP; i += 4) {
+                const float4 m = *reinterpret_cast<const float4*>(mrow + i);
+                acc[i] += m.x * xj;
+                acc[i + 1] += m.y * xj;
+                acc[i + 2] += m.z * xj;
+                acc[i + 3] += m.w * xj;
+            }
         }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) cur[u] = nxt[u];
     }
     T* ob = out + (int64_t)b * N * H + c;
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        if (i < N) {
+    for (int i = 0; i < RP; ++i) {
+        const int r = i0 + i;
+        if (r < N) {
             float v = scale * acc[i];
-            if (self_w != 0.f) v += self_w * to_f32(xb[(int64_t)i * H]);
-            if (accumulate) v += to_f32(ob[(int64_t)i * H]);
-            ob[(int64_t)i * H] = from_f32<T>(v);
+            if (self_w != 0.f) v += self_w * to_f32(xb[(int64_t)r * H]);
+            if (accumulate) v += to_f32(ob[(int64_t)r * H]);
+            ob[(int64_t)r * H] = from_f32<T>(v);
         }
     }
 }
@@ -287,9 +311,9 @@ int aggregate(const float* M, const void* x, void* out, int B, int N, int H, int
     XGGM_REQUIRE(N <= 64, "xggm_aggregate: N=%d exceeds the 64x64 LDS adjacency tile", N);
     XGGM_REQUIRE(mode >= 0 && mode <= XGGM_AGG_SYMMETRIZE, "xggm_aggregate: bad mode %d", mode);
     XGGM_REQUIRE(B <= 65535, "xggm_aggregate: batch too large");
-    dim3 grid(ceil_div(H, NT), B);
-    if (N <= 40)
-        hipLaunchKernelGGL((aggregate_kernel<T, 40>), grid, dim3(NT), 0, st, M, (const T*)x, (T*)out, N, H, mode, scale,
+    dim3 grid(ceil_div(H, AGG_COLS), B);
+    if (N <= 48)
+        hipLaunchKernelGGL((aggregate_kernel<T, 48>), grid, dim3(NT), 0, st, M, (const T*)x, (T*)out, N, H, mode, scale,
                            scale_ptr, self_w, accumulate);
     else
         hipLaunchKernelGGL((aggregate_kernel<T, 64>), grid, dim3(NT), 0, st, M, (const T*)x, (T*)out, N, H, mode, scale,

@@ -88,6 +88,11 @@ class CapturedTrainer:
                     self._eager_pass(kind)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if self.split:
+            # nothing of the eager warm-up exchanges may still be in flight (or polled) while graphs are captured
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
         pool = None
         for kind in ("plain", "rel", "node"):
             if not self.split:
