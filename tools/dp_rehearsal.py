@@ -14,12 +14,12 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def run(overlap, rank, use_graph=True, iters=("rel", "node", "rel")):
-    from oracle import shapes
     from xggm_amd import synth
     from xggm_amd.engine import CapturedTrainer
     from xggm_amd.vqa.vqacpv2 import enable_data_parallel, make_optimizer
     from test_model_gpu import build_model, batch_tensors
-    cfg, A, B = shapes.TINY, 29, 4
+    cfg = dict(hidden=128, heads=2, inter=256, vocab=64, max_pos=32, feat_dim=64, l_layers=2, x_layers=2, r_layers=1)
+    A, B = 29, 4
     m = build_model(cfg, A, seed=5, dt=torch.bfloat16)
     bn = synth.vqa_batch(B, A=A, F=cfg["feat_dim"], vocab=cfg["vocab"], seed=100 + rank)  # rank-specific data
     b = batch_tensors(bn, "cuda")
