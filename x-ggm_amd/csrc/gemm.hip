@@ -543,7 +543,8 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, const float4_
 }
 
 template <int BM, int BN, bool AK, bool BKM, int D>
-__device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile_m, int tile_n, int bz, bf16* fsm) {
+__device__ __forceinline__ void gemm_kloop(const GemmArgs& g, int tile_m, int tile_n, int bz, bf16* fsm,
+                                           float4_t (&acc)[BM / 32][BN / 32]) {
     // D = prefetch depth: D k-tiles of both operands are in flight in registers while one tile
     // is consumed from LDS.  These GEMMs are skinny (one k-chain per CU), so the k-loop would
     // otherwise run at one L2/HBM round trip per iteration.
@@ -566,7 +567,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile_m, int til
     const OpSrc sb = make_src(B, BKM ? ((int64_t)(g.N - 1) * g.b_ns + (g.K + 7) / 8 * 8) * 2 : ((int64_t)(g.K - 1) * g.b_ks + g.b_rows) * 2,
                               g.b_ns, g.b_ks);
 
-    float4_t acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -616,17 +616,34 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile_m, int til
     }
     // the k-loop ended with a barrier: LDS is free for the staged epilogue
     STAMP(g, 2);
+}
+
+// epilogue of one tile (shared by every operand-layout variant of the k-loop: ONE copy of its code per kernel)
+template <int BM, int BN>
+__device__ __forceinline__ void gemm_finish(const GemmArgs& g, int tile_m, int tile_n, int bz, bf16* fsm,
+                                            const float4_t (&acc)[BM / 32][BN / 32]) {
+    constexpr int TM = BM / 32, TN = BN / 32;
+    const int wid = threadIdx.x >> 6;
+    const int wm = (wid >> 1) * (BM / 2), wn = (wid & 1) * (BN / 2);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
     if (ABLATE(g, 2)) {
         float keep = 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-        if (keep == 123.456f) reinterpret_cast<float*>(g.C)[tid] = keep;
+        if (keep == 123.456f) reinterpret_cast<float*>(g.C)[threadIdx.x] = keep;
         return;
     }
     epilogue_staged<BM, BN, TM, TN>(g, acc, m0, n0, bz, reinterpret_cast<float*>(fsm), wm, wn);
     STAMP(g, 4);
+}
+
+template <int BM, int BN, bool AK, bool BKM, int D>
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile_m, int tile_n, int bz, bf16* fsm) {
+    float4_t acc[BM / 32][BN / 32];
+    gemm_kloop<BM, BN, AK, BKM, D>(g, tile_m, tile_n, bz, fsm, acc);
+    gemm_finish<BM, BN>(g, tile_m, tile_n, bz, fsm, acc);
 }
 
 
@@ -679,13 +696,15 @@ template <int BM, int BN> __global__ __launch_bounds__(NT, (min_waves<BM, BN>())
     const int gx = (g.N + BN - 1) / BN, gy = (g.M + BM - 1) / BM;
     const int tile_n = local % gx, tile_m = (local / gx) % gy, bz = local / (gx * gy);
     constexpr int DK = (BM * BN <= 64 * 64) ? 4 : 2;  // prefetch depth when an operand is k-major
+    float4_t acc[BM / 32][BN / 32];
     if (g.a_mode == 1) {
-        if (g.b_mode == 1) gemm_tile<BM, BN, true, true, DK>(g, tile_m, tile_n, bz, fsm);
-        else gemm_tile<BM, BN, true, false, DK>(g, tile_m, tile_n, bz, fsm);
+        if (g.b_mode == 1) gemm_kloop<BM, BN, true, true, DK>(g, tile_m, tile_n, bz, fsm, acc);
+        else gemm_kloop<BM, BN, true, false, DK>(g, tile_m, tile_n, bz, fsm, acc);
     } else {
-        if (g.b_mode == 1) gemm_tile<BM, BN, false, true, DK>(g, tile_m, tile_n, bz, fsm);
-        else gemm_tile<BM, BN, false, false, 2>(g, tile_m, tile_n, bz, fsm);
+        if (g.b_mode == 1) gemm_kloop<BM, BN, false, true, DK>(g, tile_m, tile_n, bz, fsm, acc);
+        else gemm_kloop<BM, BN, false, false, 2>(g, tile_m, tile_n, bz, fsm, acc);
     }
+    gemm_finish<BM, BN>(g, tile_m, tile_n, bz, fsm, acc);
 }
 
 template <int BM, int BN> int launch_grouped_tile(GroupArgs& ga, hipStream_t stream) {
