@@ -265,16 +265,18 @@ def test_gqa_order_iteration_matches_oracle_fp32(gnn):
         assert rel_err(sd[n], P[n]) < 1e-4, n
 
 
+@pytest.mark.parametrize("layers", [(2, 2, 1), (5, 4, 4)])
 @pytest.mark.parametrize("kind", ["plain", "rel", "node"])
-def test_two_stage_backward_gives_the_same_gradients(kind):
-    """the data-parallel overlap cuts the autograd graph below the cross-modality layers and runs the
-    backward in two stages (Runtime.backward): every gradient must equal the one-stage result, and at the
-    cut the gradients of everything above it (x-layer matrices, heads, generator) must already be final."""
+def test_two_stage_backward_gives_the_same_gradients(kind, layers):
+    """the data-parallel overlap cuts the autograd graph (one cut for the tiny model, three for the 5/4/4 one)
+    and runs the backward in stages (Runtime.backward): every gradient must equal the one-stage result, at
+    every cut the gradients of the ranges handed to the exchange must already be final, and the stages'
+    ranges tile the active part of the gradient buffer exactly."""
     from oracle import shapes
     from xggm_amd.runtime import runtime_of
-    from xggm_amd.dist import split_ranges, active_ranges
+    from xggm_amd.dist import stage_ranges, active_ranges
     from xggm_amd.vqa.vqacpv2 import forward_backward_plain, forward_backward_ggm, BCEWithLogitsLoss
-    cfg, A, B, seed = shapes.TINY, 29, 4, 6
+    cfg, A, B, seed = dict(shapes.TINY, l_layers=layers[0], x_layers=layers[1], r_layers=layers[2]), 29, 4, 6
     bn = synth.vqa_batch(B, A=A, F=cfg["feat_dim"], vocab=cfg["vocab"], seed=seed)
     bn["randn_node"] = synth.randn_nodes(B, 36, cfg["hidden"], seed)
     b = batch_tensors(bn, DEV)
@@ -288,9 +290,9 @@ def test_two_stage_backward_gives_the_same_gradients(kind):
         rt.cut_enabled = cut
         seen = {}
 
-        def between():
-            up, _ = split_ranges(rt.arena, active_ranges(rt.arena))
-            seen["upper"] = [(s, e, rt.arena.grads[s:e].clone()) for s, e in up]
+        def between(k):
+            rs = stage_ranges(rt.arena, active_ranges(rt.arena), rt.cut_layout, rt.n_stages)[k]
+            seen.setdefault("upper", []).extend((s, e, rt.arena.grads[s:e].clone()) for s, e in rs)
 
         if kind == "plain":
             forward_backward_plain(m, bce, b["feats"], b["boxes"], sent, b["target"], between=between)
@@ -299,9 +301,14 @@ def test_two_stage_backward_gives_the_same_gradients(kind):
                                  randn=b["randn_adj"] if kind == "rel" else b["randn_node"], between=between)
         torch.cuda.synchronize()
         if cut:
+            assert rt.n_stages == (2 if layers[1] < 4 else 4)
             assert seen["upper"] and sum(e - s for s, e, _ in seen["upper"]) > 0
             for s, e, g in seen["upper"]:
                 assert torch.equal(g, rt.arena.grads[s:e]), "a gradient above the cut changed after the cut"
+            act = active_ranges(rt.arena)
+            tiles = sorted(r for st in stage_ranges(rt.arena, act, rt.cut_layout, rt.n_stages) for r in st)
+            assert all(a[1] <= b_[0] for a, b_ in zip(tiles, tiles[1:])), "stage ranges overlap"
+            assert sum(e - s for s, e in tiles) == sum(e - s for s, e in act), "stage ranges do not tile the active ranges"
         res.append(grads_by_name(m))
     assert res[0].keys() == res[1].keys()
     for n in res[0]:  # (key-bias gradients are mathematically zero: absolute floor)

@@ -13,12 +13,13 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def run(overlap, rank, use_graph=True, iters=("rel", "node", "rel")):
+def run(overlap, rank, use_graph=True, iters=("rel", "node", "rel"), layers=(2, 2, 1)):
     from xggm_amd import synth
     from xggm_amd.engine import CapturedTrainer
     from xggm_amd.vqa.vqacpv2 import enable_data_parallel, make_optimizer
     from test_model_gpu import build_model, batch_tensors
-    cfg = dict(hidden=128, heads=2, inter=256, vocab=64, max_pos=32, feat_dim=64, l_layers=2, x_layers=2, r_layers=1)
+    cfg = dict(hidden=128, heads=2, inter=256, vocab=64, max_pos=32, feat_dim=64, l_layers=layers[0], x_layers=layers[1],
+               r_layers=layers[2])
     A, B = 29, 4
     m = build_model(cfg, A, seed=5, dt=torch.bfloat16)
     bn = synth.vqa_batch(B, A=A, F=cfg["feat_dim"], vocab=cfg["vocab"], seed=100 + rank)  # rank-specific data
@@ -52,22 +53,28 @@ def main():
     rank = int(os.environ["RANK"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo")
-    out = {}
     report(run(False, rank, use_graph=False, iters=("rel",)), rank, "eager, 1 iteration")
+    for layers in ((2, 2, 1), (5, 4, 4)):  # one cut (two backward stages) / three cuts (four stages)
+        check(rank, layers)
+    dist.destroy_process_group()
+
+
+def check(rank, layers):
+    out = {}
     for overlap in (False, True):
-        v = run(overlap, rank)
+        v = run(overlap, rank, layers=layers)
         other = [torch.empty_like(v) for _ in range(2)]
         dist.all_gather(other, v)
         same = bool(torch.equal(other[0], other[1]))
         out[overlap] = v
         if rank == 0:
-            print("overlap=%s: replicas identical: %s, |params| = %.6f" % (overlap, same, float(v.double().norm())), flush=True)
+            print("layers %s overlap=%s: replicas identical: %s, |params| = %.6f" % (layers, overlap, same, float(v.double().norm())),
+                  flush=True)
         assert same, "replicas diverged: the gradient exchange did not happen"
     d = float((out[True] - out[False]).double().norm() / out[False].double().norm())
     if rank == 0:
         print("overlapped vs plain exchange: relative parameter difference %.2e" % d, flush=True)
     assert d < 2e-3
-    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

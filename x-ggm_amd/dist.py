@@ -87,7 +87,7 @@ class GradSync:
 
 
     # ---- split form: ``begin`` puts the ranges on the wire and returns at once, ``finish`` waits and writes back
-    def begin(self, ranges):
+    def begin(self, ranges, slot=0):
         if self.world == 1 or not ranges:
             return None
         buckets = ranges_to_buckets(ranges, self.bucket_elems)
@@ -96,12 +96,15 @@ class GradSync:
         wire = None
         if self.wire_dtype is not None and self.wire_dtype != self.g.dtype:
             total = sum(e - s for s, e in buckets)
-            # a dedicated buffer for everything in flight (nothing may be reused before ``finish``)
-            if self._flight is None or self._flight.numel() < total:
-                self._flight = torch.empty(total, device=self.g.device, dtype=self.wire_dtype)
+            # a dedicated buffer per exchange in flight (nothing may be reused before its ``finish``)
+            if self._flight is None:
+                self._flight = {}
+            buf = self._flight.get(slot)
+            if buf is None or buf.numel() < total:
+                buf = self._flight[slot] = torch.empty(total, device=self.g.device, dtype=self.wire_dtype)
             wire, o = [], 0
             for s, e in buckets:
-                w = self._flight[o:o + e - s]
+                w = buf[o:o + e - s]
                 w.copy_(self.g[s:e])
                 wire.append(w)
                 o += e - s
@@ -122,34 +125,62 @@ class GradSync:
                 self.g[s:e].div_(self.world)
 
 
-def split_ranges(arena, ranges):
-    """(upper, lower) parts of the active ``ranges``: upper = everything whose gradient is final once the
-    backward has passed the cut below the cross-modality layers -- the x-layer weight matrices inside
-    ``enc_main`` and all groups after it (enc_tail, heads, generator); lower = the rest of ``enc_main``
-    (embeddings, single-modality layers, pooler, and its vector region)."""
+def stage_ranges(arena, ranges, layout, n_stages):
+    """the active ``ranges`` of the flat gradient buffer split by backward stage: element k of the result holds
+    the ranges whose gradients are FINAL once stage k of Runtime.backward has run (stage 0 = above the last cut).
+    ``layout`` = Runtime.cut_layout (where LXRTEncoder.forward cuts), ``n_stages`` = cuts recorded + 1.
+    Forward regions of ``enc_main``: 0 = embeddings, visn_fc, layer pairs below ``pair_cut``; 1 = the other
+    single-modality layers; 2 = cross layers below ``x_mid``; 3 = the remaining cross layers and the pooler.
+    Every other arena group (enc_tail, heads, generator) is final after stage 0; the vector region of
+    ``enc_main`` (biases, LayerNorm parameters, embedding tables of ALL layers) only after the last stage."""
+    import re
+    last = n_stages - 1
     main = arena.groups.get("enc_main")
-    if main is None:
-        return [], list(ranges)
-    xs = [(o, o + k) for n, (o, k, g, atomic) in arena.info.items()
-          if g == "enc_main" and not atomic and ".x_layers." in n]
-    if not xs:
-        return [], list(ranges)
-    x0, x1 = min(a for a, _ in xs), max(b for _, b in xs)
-    inside = [(o, o + k) for n, (o, k, g, atomic) in arena.info.items()
-              if g == "enc_main" and not atomic and x0 <= o < x1 and ".x_layers." not in n]
-    if inside:  # the x-layer matrices are not one contiguous run: do not split
-        return [], list(ranges)
-    upper, lower = [], []
+    pair_cut, x_mid = layout.get("pair_cut"), layout.get("x_mid")
+    # which cuts exist (in forward order) decides how regions map to stages
+    borders = []  # region index below which a cut sits
+    if pair_cut is not None:
+        borders.append(1)
+    borders.append(2)
+    if x_mid is not None:
+        borders.append(3)
+    if len(borders) + 1 != n_stages:  # the forward recorded other cuts than the layout predicts: no split
+        return [[] for _ in range(last)] + [list(ranges)]
+
+    def region(name):
+        m = re.search(r"\.x_layers\.(\d+)\.", name)
+        if m:
+            return 3 if (x_mid is not None and int(m.group(1)) >= x_mid) else 2
+        m = re.search(r"\.(?:layer|r_layers)\.(\d+)\.", name)
+        if m:
+            return 1 if (pair_cut is not None and int(m.group(1)) >= pair_cut) else (0 if pair_cut is not None else 1)
+        if ".pooler." in name:
+            return 3
+        return 0 if pair_cut is not None else 1
+
+    def stage_of_region(r):
+        return sum(1 for b in borders if b > r)  # cuts after the region = stages that run before it is final
+
+    out = [[] for _ in range(n_stages)]
     for s, e in ranges:
-        if s >= main.end:
-            upper.append((s, e))
-        elif s == main.start and e == main.end:
-            lower.append((s, x0))
-            upper.append((x0, x1))
-            lower.append((x1, e))
-        else:
-            lower.append((s, e))
-    return [r for r in upper if r[1] > r[0]], [r for r in lower if r[1] > r[0]]
+        if main is None or s >= main.end or e <= main.start:
+            out[0].append((s, e))
+            continue
+        # inside enc_main: matrices by region (runs of equal stage, alignment gaps included), vectors last
+        items = sorted((o, k, n) for n, (o, k, g, atomic) in arena.info.items() if g == "enc_main" and not atomic)
+        run_s, run_stage = None, None
+        for idx, (o, k, n) in enumerate(items):
+            st = min(stage_of_region(region(n)), last)
+            if run_stage is None:
+                run_s, run_stage = max(o, s), st
+            elif st != run_stage:
+                out[run_stage].append((run_s, o))
+                run_s, run_stage = o, st
+        if run_stage is not None:
+            out[run_stage].append((run_s, min(main.vec_start, e)))
+        if e > main.vec_start:
+            out[last].append((max(main.vec_start, s), e))
+    return [[r for r in rs if r[1] > r[0]] for rs in out]
 
 
 def sync_branch(branch_is_rel, device, group=None):

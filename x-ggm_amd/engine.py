@@ -58,20 +58,21 @@ class CapturedTrainer:
         self.rt.advance()
         return total
 
+    def _stage_ranges(self):
+        from .dist import active_ranges, stage_ranges
+        return stage_ranges(self.rt.arena, active_ranges(self.rt.arena), self.rt.cut_layout, self.rt.n_stages)
+
     def _eager_pass(self, kind):
         if self.split and self.rt.cut_enabled:
-            from .dist import active_ranges, split_ranges
-            gs, st = self.model._grad_sync, {}
+            gs, handles = self.model._grad_sync, []
 
-            def between():  # gradients above the cut are final: put them on the wire
-                st["upper"] = split_ranges(self.rt.arena, active_ranges(self.rt.arena))[0]
-                st["h"] = gs.begin(st["upper"])
+            def between(k):  # gradients above cut k are final: put them on the wire
+                handles.append(gs.begin(self._stage_ranges()[k], slot=k))
 
             loss, logit = self._fwd_bwd(kind, between)
-            lower = split_ranges(self.rt.arena, active_ranges(self.rt.arena))[1] if st.get("upper") else \
-                active_ranges(self.rt.arena)
-            gs.sync(lower)
-            gs.finish(st.get("h"))
+            gs.sync(self._stage_ranges()[-1])
+            for h in handles:
+                gs.finish(h)
         else:
             loss, logit = self._fwd_bwd(kind)
             _sync_grads(self.model)
@@ -116,16 +117,15 @@ class CapturedTrainer:
                 self.graphs[kind] = (g1, g2, ranges)
                 self.outputs[kind] = (loss, logit, total)
             else:
-                # three graphs: forward + backward above the cut | backward below the cut | clip + update.
-                # The capture is switched from the first to the second graph inside Runtime.backward.
-                from .dist import active_ranges, split_ranges
-                ga, gb, gc_ = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                st = {}
+                # one graph per backward stage: forward + stage 0 | stage 1 | ... | clip + update.  The capture is
+                # switched from one graph to the next inside Runtime.backward (the ``between`` callback).
+                graphs, early = [torch.cuda.CUDAGraph()], []
 
-                def switch():
-                    ga.capture_end()
-                    st["upper"] = split_ranges(self.rt.arena, active_ranges(self.rt.arena))[0]
-                    gb.capture_begin(pool=ga.pool())
+                def switch(k):
+                    graphs[-1].capture_end()
+                    early.append(self._stage_ranges()[k])
+                    graphs.append(torch.cuda.CUDAGraph())
+                    graphs[-1].capture_begin(pool=graphs[0].pool())
 
                 torch.cuda.synchronize()
                 gc.collect()
@@ -134,19 +134,21 @@ class CapturedTrainer:
                 cap.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(cap):
                     if pool is None:
-                        ga.capture_begin()
+                        graphs[0].capture_begin()
                     else:
-                        ga.capture_begin(pool=pool)
+                        graphs[0].capture_begin(pool=pool)
                     loss, logit = self._fwd_bwd(kind, switch)
-                    gb.capture_end()
+                    graphs[-1].capture_end()
                 torch.cuda.current_stream().wait_stream(cap)
-                pool = ga.pool()
-                upper, lower = split_ranges(self.rt.arena, active_ranges(self.rt.arena))
-                if not st.get("upper"):
-                    upper, lower = [], active_ranges(self.rt.arena)
-                with torch.cuda.graph(gc_, pool=pool):
+                pool = graphs[0].pool()
+                final = self._stage_ranges()[-1] if early else None
+                if final is None:
+                    from .dist import active_ranges
+                    final = active_ranges(self.rt.arena)
+                gu = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gu, pool=pool):
                     total = self._update()
-                self.graphs[kind] = (ga, gb, gc_, upper, lower)
+                self.graphs[kind] = ("staged", graphs, early, final, gu)
                 self.outputs[kind] = (loss, logit, total)
         torch.cuda.synchronize()
 
@@ -162,19 +164,22 @@ class CapturedTrainer:
         gs = self.graphs[kind]
         if len(gs) == 1:
             gs[0].replay()
-        elif len(gs) == 3:
+        elif gs[0] != "staged":
             gs[0].replay()
             self.model._grad_sync.sync(gs[2])
             gs[1].replay()
         else:
-            ga, gb, gc_, upper, lower = gs
+            _, graphs, early, final, gu = gs
             sync = self.model._grad_sync
-            ga.replay()
-            h = sync.begin(upper)   # on the links while the lower backward graph runs
-            gb.replay()
-            sync.sync(lower)
-            sync.finish(h)
-            gc_.replay()
+            handles = []
+            for k, g in enumerate(graphs):
+                g.replay()
+                if k < len(early):
+                    handles.append(sync.begin(early[k], slot=k))  # on the links while the next stage replays
+            sync.sync(final)
+            for h in handles:
+                sync.finish(h)
+            gu.replay()
         return self.outputs[kind]
 
     def iteration(self, branch):

@@ -32,29 +32,29 @@ class Runtime:
         # and the cross-modality layers so the gradients of everything above the cut can be on the wire
         # while the backward below it still runs
         self.cut_enabled = False
-        self._cut = None
+        self.n_stages = 1
+        self._cuts = []       # cuts recorded by the running forward, in forward order: (tag, outputs, leaves)
+        self.cut_layout = {}  # filled by LXRTEncoder.forward: where the cuts of this model sit (dist.stage_ranges)
 
-    def make_cut(self, *tensors):
-        """called by LXRTEncoder.forward at the cut: returns detached leaves to continue with"""
+    def make_cut(self, tag, *tensors):
+        """called by LXRTEncoder.forward at a cut: returns detached leaves to continue with"""
         leaves = [t.detach().requires_grad_(True) for t in tensors]
-        self._cut = (list(tensors), leaves)
+        self._cuts.append((tag, list(tensors), leaves))
         return leaves
 
     def backward(self, loss, between=None):
-        """loss.backward(), in two stages when the forward recorded a cut: stage 1 stops at the cut leaves,
-        ``between()`` runs (gradients above the cut are final), stage 2 continues below the cut."""
-        cut, self._cut = self._cut, None
+        """loss.backward(), in stages when the forward recorded cuts: stage 0 stops at the leaves of the last
+        cut, ``between(k)`` runs after stage k (every gradient above that cut is final), the next stage
+        continues below it, ... -- ``between`` is not called after the final stage."""
+        cuts, self._cuts = self._cuts, []
+        self.n_stages = len(cuts) + 1
         loss.backward()
-        if cut is None:
+        for k, (_, outs, leaves) in enumerate(reversed(cuts)):
             if between is not None:
-                between()
-            return
-        if between is not None:
-            between()
-        outs, leaves = cut
-        pairs = [(o, l.grad) for o, l in zip(outs, leaves) if l.grad is not None]
-        if pairs:
-            torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
+                between(k)
+            pairs = [(o, l.grad) for o, l in zip(outs, leaves) if l.grad is not None]
+            if pairs:
+                torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
 
     def defer_list(self):
         """list the LN backwards of the running autograd backward append their reduce jobs to; the

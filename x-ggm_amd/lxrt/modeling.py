@@ -349,17 +349,35 @@ class LXRTEncoder(nn.Module):
         # language layers and relational (vision) layers are independent chains: the first
         # min(l, r) layers of both run pairwise in lockstep, the rest alone
         n_pair = min(self.num_l_layers, self.num_r_layers)
+        # data-parallel overlap: the autograd graph is cut at up to three places so the backward runs in stages
+        # and the gradients above a cut go on the wire while the stage below it computes (Runtime.backward,
+        # dist.stage_ranges).  Positions: after the first two layer pairs, before the first and before the
+        # second-to-last cross-modality layer.
+        rt = runtime_of(self)
+        cutting = rt.cut_enabled and torch.is_grad_enabled()
+        pair_cut = 2 if n_pair >= 4 else None
+        x_mid = self.num_x_layers - 2 if self.num_x_layers >= 4 else None
+        rt.cut_layout = dict(pair_cut=pair_cut, x_mid=x_mid)
+        rt._cuts = []  # cuts of an earlier forward that never saw its backward are dropped
+
+        def cut(tag, a, b):
+            if cutting and a.requires_grad and b.requires_grad:
+                return rt.make_cut(tag, a, b)
+            return a, b
+
         for i in range(n_pair):
+            if i == pair_cut:
+                lang_feats, visn_feats = cut("lower", lang_feats, visn_feats)
             lang_feats, visn_feats = bert_layer_pair(self.layer[i], self.r_layers[i], lang_feats,
                                                      lang_attention_mask, visn_feats, visn_attention_mask)
         for layer_module in self.layer[n_pair:]:
             lang_feats = layer_module(lang_feats, lang_attention_mask)
         for layer_module in self.r_layers[n_pair:]:
             visn_feats = layer_module(visn_feats, visn_attention_mask)
-        rt = runtime_of(self)
-        if rt.cut_enabled and torch.is_grad_enabled() and lang_feats.requires_grad and visn_feats.requires_grad:
-            lang_feats, visn_feats = rt.make_cut(lang_feats, visn_feats)  # see Runtime.backward
-        for layer_module in self.x_layers:
+        lang_feats, visn_feats = cut("x0", lang_feats, visn_feats)
+        for k, layer_module in enumerate(self.x_layers):
+            if k == x_mid:
+                lang_feats, visn_feats = cut("xmid", lang_feats, visn_feats)
             lang_feats, visn_feats = layer_module(lang_feats, lang_attention_mask, visn_feats, visn_attention_mask)
         return lang_feats, visn_feats
 
