@@ -202,7 +202,12 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    force_dp = world == 1 and bool(os.environ.get("XGGM_DP_FORCE"))  # one-rank RCCL rehearsal of the N > 1 path
+    if force_dp:
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("XGGM_DIST_BACKEND", "nccl")  # "gloo": logic check of the N>1 path on one GPU
@@ -218,7 +223,7 @@ def main():
     log("model on %s" % device)
     # first forward creates the arena; data parallel hooks need it
     rt = runtime_of(model)
-    if world > 1:
+    if world > 1 or force_dp:
         from xggm_amd.vqa.vqacpv2 import enable_data_parallel
         enable_data_parallel(model, wire_dtype=torch.bfloat16 if args.wire == "bf16" else None)
     trainer = CapturedTrainer(model, optim, batch, sigma=1.0, order="vqa", use_graph=not args.no_graph)
@@ -319,7 +324,7 @@ def main():
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or force_dp:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -40,6 +40,10 @@ class GradSync:
         self.g = flat_grads
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # XGGM_DP_FORCE=1: issue the collectives even in a one-rank group (rehearses the RCCL stream / graph
+        # interplay on a single GPU: the reduction itself is then the identity)
+        import os
+        self.force = bool(os.environ.get("XGGM_DP_FORCE")) and dist.is_initialized()
         self.wire_dtype = wire_dtype
         self.bucket_elems = bucket_elems
         self.backend = dist.get_backend(group) if dist.is_initialized() else None
@@ -48,7 +52,7 @@ class GradSync:
 
     def sync(self, ranges):
         """average ``flat_grads[s:e]`` over ranks for every (s, e) in ``ranges``."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         buckets = ranges_to_buckets(ranges, self.bucket_elems)
         use_avg = self.backend == "nccl"
@@ -88,7 +92,7 @@ class GradSync:
 
     # ---- split form: ``begin`` puts the ranges on the wire and returns at once, ``finish`` waits and writes back
     def begin(self, ranges, slot=0):
-        if self.world == 1 or not ranges:
+        if (self.world == 1 and not self.force) or not ranges:
             return None
         buckets = ranges_to_buckets(ranges, self.bucket_elems)
         use_avg = self.backend == "nccl"

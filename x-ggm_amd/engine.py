@@ -37,6 +37,11 @@ class CapturedTrainer:
         self.graphs = {}
         self.outputs = {}
         self.split = getattr(model, "_grad_sync", None) is not None
+        self._comm = None
+        # With a process group alive its watchdog thread polls events at any time; under the default "global"
+        # capture mode HIP rejects that ("operation not permitted when stream is capturing") and the process
+        # aborts.  "thread_local" only polices the capturing thread.
+        self.capture_mode = "thread_local" if self.split else "global"
         model.train()
         if use_graph:
             self._capture(warmup_iters)
@@ -98,21 +103,21 @@ class CapturedTrainer:
         for kind in ("plain", "rel", "node"):
             if not self.split:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool):
+                with torch.cuda.graph(g, pool=pool, capture_error_mode=self.capture_mode):
                     out = self._eager_pass(kind)
                 pool = g.pool()
                 self.graphs[kind] = (g,)
                 self.outputs[kind] = out
             elif not self.rt.cut_enabled:
                 g1 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g1, pool=pool):
+                with torch.cuda.graph(g1, pool=pool, capture_error_mode=self.capture_mode):
                     loss, logit = self._fwd_bwd(kind)
                 pool = g1.pool()
                 ranges = None
                 from .dist import active_ranges
                 ranges = active_ranges(self.rt.arena)
                 g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2, pool=pool):
+                with torch.cuda.graph(g2, pool=pool, capture_error_mode=self.capture_mode):
                     total = self._update()
                 self.graphs[kind] = (g1, g2, ranges)
                 self.outputs[kind] = (loss, logit, total)
@@ -125,7 +130,7 @@ class CapturedTrainer:
                     graphs[-1].capture_end()
                     early.append(self._stage_ranges()[k])
                     graphs.append(torch.cuda.CUDAGraph())
-                    graphs[-1].capture_begin(pool=graphs[0].pool())
+                    graphs[-1].capture_begin(pool=graphs[0].pool(), capture_error_mode=self.capture_mode)
 
                 torch.cuda.synchronize()
                 gc.collect()
@@ -134,9 +139,9 @@ class CapturedTrainer:
                 cap.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(cap):
                     if pool is None:
-                        graphs[0].capture_begin()
+                        graphs[0].capture_begin(capture_error_mode=self.capture_mode)
                     else:
-                        graphs[0].capture_begin(pool=pool)
+                        graphs[0].capture_begin(pool=pool, capture_error_mode=self.capture_mode)
                     loss, logit = self._fwd_bwd(kind, switch)
                     graphs[-1].capture_end()
                 torch.cuda.current_stream().wait_stream(cap)
@@ -146,7 +151,7 @@ class CapturedTrainer:
                     from .dist import active_ranges
                     final = active_ranges(self.rt.arena)
                 gu = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gu, pool=pool):
+                with torch.cuda.graph(gu, pool=pool, capture_error_mode=self.capture_mode):
                     total = self._update()
                 self.graphs[kind] = ("staged", graphs, early, final, gu)
                 self.outputs[kind] = (loss, logit, total)
@@ -169,16 +174,23 @@ class CapturedTrainer:
             self.model._grad_sync.sync(gs[2])
             gs[1].replay()
         else:
+            # the exchange of stage k (cast to the wire type, all-reduce, copy back) is queued on a side stream
+            # right behind graph k and runs under graph k + 1; the update waits for all of it
             _, graphs, early, final, gu = gs
             sync = self.model._grad_sync
-            handles = []
+            main = torch.cuda.current_stream()
+            if self._comm is None:
+                self._comm = torch.cuda.Stream()
+            comm = self._comm
             for k, g in enumerate(graphs):
                 g.replay()
-                if k < len(early):
-                    handles.append(sync.begin(early[k], slot=k))  # on the links while the next stage replays
-            sync.sync(final)
-            for h in handles:
-                sync.finish(h)
+                comm.wait_stream(main)
+                with torch.cuda.stream(comm):
+                    if k < len(early):
+                        sync.finish(sync.begin(early[k], slot=k))
+                    else:
+                        sync.sync(final)
+            main.wait_stream(comm)
             gu.replay()
         return self.outputs[kind]
 
