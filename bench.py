@@ -279,9 +279,12 @@ def main():
         per_pass[kind] = round(1000.0 * (time.perf_counter() - t1) / 5, 3)
 
     roofline, kernels = None, None
-    if rank == 0 and not args.no_kernel_timing:
+    if not args.no_kernel_timing:
+        # EVERY rank runs the instrumented passes (they contain the gradient exchange: a rank that skipped them
+        # would leave the others waiting in a collective); rank 0 reports
         log("kernel timing pass")
         fam = kernel_timing(trainer, ["rel", "node"])
+    if rank == 0 and not args.no_kernel_timing:
         tot = sum(f["ms"] for f in fam.values())
         kernels = {k: {"ms": round(f["ms"], 3), "launches": f["n"], "share": round(f["ms"] / tot, 4)}
                    for k, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])[:8]}
