@@ -72,7 +72,9 @@ int xggm_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, i
 /* Up to 4 independent products in ONE launch (forward of both modalities, dgrad + wgrad of a layer):
  * skinny problems that cannot fill 256 CUs alone share a grid.  `probs` is a HOST array; fields as
  * the arguments of xggm_gemm_*.  Falls back to one launch per problem for shapes the tuned kernel
- * does not take (unaligned strides, fp32). */
+ * does not take (unaligned strides, fp32).  A dimension that is not a multiple of 8 (2274 answers, 630 edges)
+ * stays on the tuned path when the operand's leading stride is padded to a multiple of 8 (whatever the
+ * padding holds). */
 typedef struct xggm_gemm_problem {
     const void* A;
     const void* B;
@@ -95,8 +97,8 @@ int xggm_gemm_grouped_bf16(const xggm_gemm_problem* probs, int n, xggm_stream_t 
 int xggm_gemm_set_group_tile(int v);
 /* HOST: 1 = run bf16 GEMMs on the generic 64x64 kernel, 0 = tuned kernels (default); A/B tests */
 int xggm_gemm_set_generic(int on);
-/* HOST: pin the tuned bf16 kernel variant (1: 64x64 depth 2, 2: 64x64 depth 4, 3: 128x64 depth 2,
- * 4: 128x64 depth 3, 5: 128x128 depth 2, 6: 32x64 depth 4, 7: 32x32 depth 4; 0: heuristic;
+/* HOST: pin the tuned bf16 kernel variant of single launches (1: 64x64 depth 2, 2: 64x64 depth 4,
+ * 3: 128x64 depth 2, 5: 128x128 depth 2, 6/7/8: 64x64 / 128x64 / 128x128 depth 1; 0: heuristic;
  * | 0x100 turns the XCD-aware tile order off) */
 int xggm_gemm_set_tile(int variant);
 /* out[n] += sum_m x[m*ld + n]  (bias gradients; `out` must hold the running value) */
