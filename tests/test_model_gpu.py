@@ -265,6 +265,68 @@ def test_gqa_order_iteration_matches_oracle_fp32(gnn):
         assert rel_err(sd[n], P[n]) < 1e-4, n
 
 
+@pytest.mark.parametrize("case", ["batch1", "shortest_question", "gin64", "objects64", "tokens8"])
+def test_edge_configurations_match_oracle_fp32(case):
+    """whole passes (forward + backward + clip + BertAdam) against the CPU oracle at the corners of the domain:
+    a single sample; questions that are only [CLS] x [SEP] (17 of 20 key positions masked); the 64-object stress
+    configuration (C4: 64 x 64 adjacency, 2016 edge logits) with the GCN and with the GIN generator; a shorter
+    token window.  (The GAT generator has no whole-pass case: its two concatenated heads give 2H-wide node features,
+    which the reference's own fusion_fc(cat[x, mean nodes]) of width 2H rejects -- src/vqa/vqacpv2.py:216 cannot run
+    with gnn='GAT'; GAT is covered at generator level against the reference golden.)"""
+    from oracle import shapes, xggm_oracle as O
+    from helpers import seeded_params
+    from xggm_amd import param
+    from xggm_amd.lxrt.modeling import BertConfig, VISUAL_CONFIG
+    from xggm_amd.vqa.vqacpv2_model import VQAModel
+    from xggm_amd.vqa.vqacpv2 import plain_pass, ggm_pass, BCEWithLogitsLoss, make_optimizer
+    cfg, A, seed = shapes.TINY, 19, 12
+    B, N, T, gnn, n_layers = 3, 36, 20, "GCN", 2
+    if case == "batch1":
+        B = 1
+    elif case == "gin64":
+        gnn, n_layers, N, B = "GIN", 1, 64, 2
+    elif case == "objects64":
+        N, B = 64, 2
+    elif case == "tokens8":
+        T = 8
+    VISUAL_CONFIG.set_visual_dims(cfg["feat_dim"], 4)
+    a = param.parse_args(["--llayers", str(cfg["l_layers"]), "--xlayers", str(cfg["x_layers"]), "--rlayers",
+                          str(cfg["r_layers"])])
+    bc_ = BertConfig(cfg["vocab"], hidden_size=cfg["hidden"], num_attention_heads=cfg["heads"],
+                     intermediate_size=cfg["inter"], max_position_embeddings=cfg["max_pos"])
+    m = VQAModel(A, gnn=gnn, n_layers=n_layers, args=a, config=bc_, compute_dtype=F32, n_objects=N)
+    m.load_state_dict({k: torch.from_numpy(synth.seeded_param(k, v.shape, seed)) for k, v in m.state_dict().items()})
+    m = m.to(DEV).eval()
+    opt = make_optimizer(m, 1e-3, 8)
+    bn = synth.vqa_batch(B, A=A, N=N, T=T, F=cfg["feat_dim"], vocab=cfg["vocab"], seed=seed)
+    if case == "shortest_question":
+        bn["input_ids"][:, 1] = 7
+        bn["input_ids"][:, 2] = min(102, cfg["vocab"] - 1)  # [SEP] of synth.vqa_batch
+        bn["input_ids"][:, 3:] = 0
+        bn["input_mask"][:, :3] = 1
+        bn["input_mask"][:, 3:] = 0
+    bn["randn_node"] = synth.randn_nodes(B, N, cfg["hidden"], seed)
+    b, bc = batch_tensors(bn, DEV), batch_tensors(bn)
+    P = seeded_params(shapes.model_shapes(cfg, A, gnn=gnn, n_layers=n_layers, n_adj=N * (N - 1) // 2), seed)
+    Mo = {k: torch.zeros_like(v) for k, v in P.items()}
+    Vo = {k: torch.zeros_like(v) for k, v in P.items()}
+    step = {k: 0 for k in P}
+    sent = (b["input_ids"], b["input_mask"], b["segment_ids"])
+    bce = BCEWithLogitsLoss()
+    for kind in ["plain", "rel", "node", "plain"]:
+        kw = {} if kind == "plain" else dict(sigma=1.0, kl_weight=8.0, gnn=gnn, n_layers=n_layers)
+        lo, _, _, _ = O.train_pass(P, Mo, Vo, step, bc, cfg, kind, 1e-3, 8, **kw)
+        if kind == "plain":
+            l, _ = plain_pass(m, opt, bce, b["feats"], b["boxes"], sent, b["target"])
+        else:
+            l, _, _ = ggm_pass(m, opt, bce, b["feats"], b["boxes"], sent, b["target"], b["adj_true"], kind, sigma=1.0,
+                               kl_weight=8.0, randn=b["randn_adj"] if kind == "rel" else b["randn_node"])
+        assert abs(float(l) - float(lo)) < 1e-3 * abs(float(lo)), (case, kind, float(l), float(lo))
+    sd = m.state_dict()
+    for n in ("logit_fc.3.weight", "encoder_adj.0.weight", "lxrt_encoder.model.bert.encoder.layer.0.attention.self.query.weight"):
+        assert rel_err(sd[n], P[n]) < 1e-4, (case, n)
+
+
 @pytest.mark.parametrize("layers", [(2, 2, 1), (5, 4, 4)])
 @pytest.mark.parametrize("kind", ["plain", "rel", "node"])
 def test_two_stage_backward_gives_the_same_gradients(kind, layers):
