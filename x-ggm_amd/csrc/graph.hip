@@ -25,74 +25,78 @@ namespace {
 constexpr int NT = 256;
 
 // ------------------------------------------------------------------------------- aggregate
-// One workgroup = 64 feature columns x SPLIT groups of output rows (SPLIT = 4): thread (col, part) keeps
-// NP / SPLIT outputs of its column in registers and walks the N input rows once.  The adjacency tile sits
-// transposed in LDS (every lane of a wave reads the same address: broadcast).  Splitting the output rows over
-// four threads quarters the serial FMA chain per thread and gives 4x the workgroups (B * H / 64) -- at B = 32
-// the one-thread-per-column form left 160 of 256 CUs idle and was bound by its own 1440-FMA chain.
-constexpr int AGG_SPLIT = 4, AGG_COLS = NT / AGG_SPLIT;
+// out[b] = scale * M'[b] x[b] (+ self_w x[b]) (+ out[b]) on the matrix cores, fp32 in and fp32 accumulate
+// (v_mfma_f32_16x16x4_f32: exact in fp32 storage mode as well).  One workgroup = one sample x 64 feature
+// columns: the adjacency M' (plain / transposed / symmetrised, <= 64 x 64) and the x slab [N, 64] sit in LDS as
+// fp32, wave w owns columns 16 w .. 16 w + 15 and all N / 16 row tiles.  The MFMA operands are swapped
+// (D^T = x^T M'^T) so a lane ends up with FOUR CONSECUTIVE columns of one output row: 8-byte (bf16) / 16-byte
+// (fp32) stores.  LDS strides: NP + 2 for M' and 80 for x make both fragment reads bank-conflict-free.
+// HBM traffic is one read of x and M, one write of out; B * H / 64 workgroups (768 at the 64-object stress
+// configuration, 384 in training).
+typedef __attribute__((ext_vector_type(4))) float float4_t;
+constexpr int AGG_COLS = 64, AGG_LDX = 80;
 template <typename T, int NP>
 __global__ __launch_bounds__(NT) void aggregate_kernel(const float* __restrict__ Mx, const T* __restrict__ x, T* out, int N,
                                                        int H, int mode, float scale, const float* scale_ptr, float self_w,
                                                        int accumulate) {
-    constexpr int RP = NP / AGG_SPLIT;  // output rows per thread
-    static_assert(NP % (4 * AGG_SPLIT) == 0, "row split must keep float4 reads of the adjacency rows");
-    __shared__ __attribute__((aligned(16))) float Mt[NP * NP];  // Mt[j][i] = M'[i][j]
-    const int b = blockIdx.y, tid = threadIdx.x;
+    constexpr int LDM = NP + 2;
+    __shared__ float Mp[NP * LDM];       // Mp[i][j] = M'[i][j]
+    __shared__ float xs[NP * AGG_LDX];   // xs[j][c]
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int cb = blockIdx.x * AGG_COLS;
     const float* Mb = Mx + (int64_t)b * N * N;
     for (int e = tid; e < NP * NP; e += NT) {
-        const int j = e / NP, i = e % NP;
+        const int i = e / NP, j = e % NP;
         float v = 0.f;
         if (i < N && j < N) {
             if (mode == XGGM_AGG_PLAIN) v = Mb[i * N + j];
             else if (mode == XGGM_AGG_TRANSPOSE) v = Mb[j * N + i];
             else v = Mb[i * N + j] + Mb[j * N + i];
         }
-        Mt[e] = v;
+        Mp[i * LDM + j] = v;
+    }
+    const T* xb = x + (int64_t)b * N * H + cb;
+    for (int e = tid; e < NP * (AGG_COLS / 4); e += NT) {  // 4 columns per thread
+        const int j = e / (AGG_COLS / 4), c = (e % (AGG_COLS / 4)) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (j < N && cb + c < H) load4(xb + (int64_t)j * H + c, v);  // H % 4 == 0
+        *reinterpret_cast<float4*>(xs + j * AGG_LDX + c) = make_float4(v[0], v[1], v[2], v[3]);
     }
     __syncthreads();
-    const int part = tid / AGG_COLS, i0 = part * RP;  // a wave = one part: the Mt reads stay wave-uniform
-    const int c = blockIdx.x * AGG_COLS + (tid % AGG_COLS);
-    if (c >= H) return;
     if (scale_ptr) scale *= (1.0f + *scale_ptr);  // GIN: (1 + eps)
-    const T* xb = x + (int64_t)b * N * H + c;
-    float acc[RP];
+    const int fr = lane & 15, fq = lane >> 4, c0 = wid * 16;
+    float4_t acc[NP / 16];
 #pragma unroll
-    for (int i = 0; i < RP; ++i) acc[i] = 0.f;
-    // x rows in chunks of 8 with the next chunk's loads in flight: one memory round trip per chunk instead of
-    // one per row (the rows of Mt beyond N are zero, so over-read rows -- clamped to row N-1 -- add nothing)
-    constexpr int CH = 8;
-    float cur[CH], nxt[CH];
+    for (int t = 0; t < NP / 16; ++t) acc[t] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int j0 = 0; j0 < NP; j0 += 4) {
+        const float xa = xs[(j0 + fq) * AGG_LDX + c0 + fr];  // A operand: x^T, row = column c0 + fr, k = j0 + fq
 #pragma unroll
-    for (int u = 0; u < CH; ++u) cur[u] = to_f32(xb[(int64_t)min(u, N - 1) * H]);
-    for (int j0 = 0; j0 < N; j0 += CH) {
-#pragma unroll
-        for (int u = 0; u < CH; ++u) nxt[u] = to_f32(xb[(int64_t)min(j0 + CH + u, N - 1) * H]);
-#pragma unroll
-        for (int u = 0; u < CH; ++u) {
-            const float xj = cur[u];
-            const float* mrow = Mt + (j0 + u) * NP + i0;  // j0 + u < NP because NP is a multiple of CH
-#pragma unroll
-            for (int i = 0; i < RP; i += 4) {
-                const float4 m = *reinterpret_cast<const float4*>(mrow + i);
-                acc[i] += m.x * xj;
-                acc[i + 1] += m.y * xj;
-                acc[i + 2] += m.z * xj;
-                acc[i + 3] += m.w * xj;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < CH; ++u) cur[u] = nxt[u];
+        for (int t = 0; t < NP / 16; ++t)                     // B operand: M'^T, k = j0 + fq, column = row t*16 + fr
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, Mp[(t * 16 + fr) * LDM + j0 + fq], acc[t], 0, 0, 0);
     }
+    // lane holds out[i = t*16 + fr][c = c0 + 4 fq .. + 3]
+    const int c = cb + c0 + 4 * fq;
+    if (c >= H) return;
     T* ob = out + (int64_t)b * N * H + c;
 #pragma unroll
-    for (int i = 0; i < RP; ++i) {
-        const int r = i0 + i;
-        if (r < N) {
-            float v = scale * acc[i];
-            if (self_w != 0.f) v += self_w * to_f32(xb[(int64_t)r * H]);
-            if (accumulate) v += to_f32(ob[(int64_t)r * H]);
-            ob[(int64_t)r * H] = from_f32<T>(v);
+    for (int t = 0; t < NP / 16; ++t) {
+        const int i = t * 16 + fr;
+        if (i < N) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = scale * acc[t][r];
+            if (self_w != 0.f) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += self_w * xs[i * AGG_LDX + c0 + 4 * fq + r];
+            }
+            if (accumulate) {
+                float o[4];
+                load4(ob + (int64_t)i * H, o);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += o[r];
+            }
+            store4(ob + (int64_t)i * H, v);
         }
     }
 }
@@ -311,6 +315,7 @@ int aggregate(const float* M, const void* x, void* out, int B, int N, int H, int
     XGGM_REQUIRE(N <= 64, "xggm_aggregate: N=%d exceeds the 64x64 LDS adjacency tile", N);
     XGGM_REQUIRE(mode >= 0 && mode <= XGGM_AGG_SYMMETRIZE, "xggm_aggregate: bad mode %d", mode);
     XGGM_REQUIRE(B <= 65535, "xggm_aggregate: batch too large");
+    XGGM_REQUIRE(H % 4 == 0, "xggm_aggregate: H=%d must be a multiple of 4", H);
     dim3 grid(ceil_div(H, AGG_COLS), B);
     if (N <= 48)
         hipLaunchKernelGGL((aggregate_kernel<T, 48>), grid, dim3(NT), 0, st, M, (const T*)x, (T*)out, N, H, mode, scale,
