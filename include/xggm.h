@@ -360,10 +360,10 @@ int xggm_bce_bwd_bf16(const float* logit, const float* target, const float* gout
 
 /* ---- optimiser ---------------------------------------------------------------------------
  * *out += sum g^2 over a flat fp32 range (clip_grad_norm_, src/vqa/vqacpv2.py:175).  The sum is taken in a
- * fixed order (per-workgroup partials, summed by the last workgroup to finish), so data-parallel replicas
- * that hold identical gradients compute bit-identical norms and stay bit-identical.  `ws`: caller-owned
- * XGGM_SQNORM_WS_FLOATS floats, zeroed once before the first call (the kernel leaves its counter at zero). */
-#define XGGM_SQNORM_WS_FLOATS 1028
+ * fixed order (per-workgroup partials in `ws`, added up by a second one-workgroup launch), so data-parallel
+ * replicas that hold identical gradients compute bit-identical norms and stay bit-identical.  `ws`: caller-owned
+ * scratch of XGGM_SQNORM_WS_FLOATS floats (contents irrelevant before, undefined after). */
+#define XGGM_SQNORM_WS_FLOATS 4100
 int xggm_sqnorm_f32(const float* g, int64_t n, float* out, float* ws, xggm_stream_t stream);
 /* BertAdam.step (src/lxrt/optimization.py:159-193) fused with the clip scale
  * min(1, max_norm/(sqrt(*sqnorm)+1e-6)) and the bf16 shadow-weight write. */

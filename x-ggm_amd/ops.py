@@ -682,7 +682,7 @@ def sqnorm(g, out):
     _c(g, F32), _c(out, F32)
     ws = _SQNORM_WS.get(g.device)
     if ws is None:  # zeroed once; the kernel leaves its arrival counter at zero
-        ws = _SQNORM_WS[g.device] = torch.zeros(1028, device=g.device, dtype=F32)
+        ws = _SQNORM_WS[g.device] = torch.zeros(4100, device=g.device, dtype=F32)
     call("xggm_sqnorm_f32", ptr(g), g.numel(), ptr(out), ptr(ws), stream())
 
 
