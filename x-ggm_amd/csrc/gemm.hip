@@ -484,8 +484,11 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, const float4_
                             o0.x += p0[b].x; o0.y += p0[b].y; o0.z += p0[b].z; o0.w += p0[b].w;
                             o1.x += p1[b].x; o1.y += p1[b].y; o1.z += p1[b].z; o1.w += p1[b].w;
                         }
-                        *reinterpret_cast<float4*>(c) = o0;
-                        *reinterpret_cast<float4*>(c + 4) = o1;
+                        // fp32 outputs are weight gradients (860 MB per pass, next read by the norm / update
+                        // passes from HBM anyway): non-temporal, so they do not evict activations and weights
+                        typedef float __attribute__((ext_vector_type(4))) f4;
+                        __builtin_nontemporal_store((f4){o0.x, o0.y, o0.z, o0.w}, reinterpret_cast<f4*>(c));
+                        __builtin_nontemporal_store((f4){o1.x, o1.y, o1.z, o1.w}, reinterpret_cast<f4*>(c + 4));
                     } else {
                         if (g.accumulate) {
 #pragma unroll

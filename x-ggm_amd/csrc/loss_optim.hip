@@ -156,7 +156,8 @@ __global__ __launch_bounds__(NT) void sqnorm_kernel(const float* __restrict__ g,
     int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
     // four independent 16-byte loads in flight per thread
     for (; i + 3 * stride < n4; i += 4 * stride) {
-        const f4 a = g4[i], b = g4[i + stride], c = g4[i + 2 * stride], d = g4[i + 3 * stride];
+        const f4 a = __builtin_nontemporal_load(g4 + i), b = __builtin_nontemporal_load(g4 + i + stride),
+                 c = __builtin_nontemporal_load(g4 + i + 2 * stride), d = __builtin_nontemporal_load(g4 + i + 3 * stride);
         acc += (a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w) + (b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w) +
                (c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w) + (d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w);
     }
