@@ -47,7 +47,9 @@ __device__ __forceinline__ void block_store_partial(const float (&p)[NV][4], flo
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < H; c += NT) dst[c] = lds[c] + lds[H + c] + lds[2 * H + c] + lds[3 * H + c];
+    // the partial rows are read once, by the reduce launch at the end of the backward pass: keep them out of the caches
+    for (int c = threadIdx.x; c < H; c += NT)
+        __builtin_nontemporal_store(lds[c] + lds[H + c] + lds[2 * H + c] + lds[3 * H + c], dst + c);
 }
 
 struct ReduceTargets {
