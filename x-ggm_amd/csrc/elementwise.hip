@@ -79,7 +79,8 @@ __global__ __launch_bounds__(NT) void zero_ranges_kernel(float* base, Ranges r) 
 #pragma unroll
         for (int j = 1; j < MAX_RANGES; ++j)
             if (j < r.n && i >= r.start[j]) k = j;
-        reinterpret_cast<float4*>(base + r.off[k])[i - r.start[k]] = make_float4(0.f, 0.f, 0.f, 0.f);
+        typedef float __attribute__((ext_vector_type(4))) f4;
+        __builtin_nontemporal_store((f4){0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f4*>(base + r.off[k]) + (i - r.start[k]));
     }
 }
 }  // namespace

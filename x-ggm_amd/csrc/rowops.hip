@@ -111,13 +111,13 @@ __global__ __launch_bounds__(NT) void partial_reduce_batch_kernel(BatchJobs bj) 
         const float* p = job.ws + idx;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         int b = sl;
-        for (; b + 12 < job.nblk; b += 16) {
-            a0 += p[(int64_t)b * KH];
-            a1 += p[(int64_t)(b + 4) * KH];
-            a2 += p[(int64_t)(b + 8) * KH];
-            a3 += p[(int64_t)(b + 12) * KH];
+        for (; b + 12 < job.nblk; b += 16) {  // read once: non-temporal
+            a0 += __builtin_nontemporal_load(p + (int64_t)b * KH);
+            a1 += __builtin_nontemporal_load(p + (int64_t)(b + 4) * KH);
+            a2 += __builtin_nontemporal_load(p + (int64_t)(b + 8) * KH);
+            a3 += __builtin_nontemporal_load(p + (int64_t)(b + 12) * KH);
         }
-        for (; b < job.nblk; b += 4) a0 += p[(int64_t)b * KH];
+        for (; b < job.nblk; b += 4) a0 += __builtin_nontemporal_load(p + (int64_t)b * KH);
         s = (a0 + a1) + (a2 + a3);
     }
     red[sl][ci] = s;
