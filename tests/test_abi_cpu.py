@@ -149,7 +149,15 @@ def test_tokenizer_and_features_match_reference_golden():
     tok = BertTokenizer(os.path.join(here, "vocab_small.txt"), do_lower_case=True)
     for sent, want in zip(g["sents"], g["tokens"]):
         assert tok.tokenize(sent.strip()) == want, sent
+    from xggm_amd.lxrt.entry import SentenceBatcher
     for L, want in g["features"].items():
         feats = convert_sents_to_features(g["sents"], int(L), tok)
         got = [[f.input_ids, f.input_mask, f.segment_ids] for f in feats]
         assert got == want, L
+        # the cached, single-buffer batch path of the training loop gives the same tensors (twice: cold and cached)
+        sb = SentenceBatcher(tok, int(L))
+        for _ in range(2):
+            hb = sb.host_batch(g["sents"])
+            assert hb.shape == (3, len(want), int(L))
+            assert hb[0].tolist() == [w[0] for w in want] and hb[1].tolist() == [w[1] for w in want]
+            assert hb[2].tolist() == [w[2] for w in want]

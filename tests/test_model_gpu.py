@@ -378,6 +378,39 @@ def test_two_stage_backward_gives_the_same_gradients(kind, layers):
         assert d < 1e-5 * float(res[0][n].norm()) + 1e-8, (n, d)
 
 
+def test_string_questions_equal_token_tensors():
+    """``model(feats, boxes, list_of_strings)`` (the reference's calling convention, src/vqa/vqacpv2.py:171) runs the
+    host tokeniser + cached single-copy batcher and gives the outputs of the same batch passed as id tensors."""
+    import os
+    from oracle import shapes
+    from xggm_amd import param
+    from xggm_amd.lxrt.modeling import BertConfig, VISUAL_CONFIG
+    from xggm_amd.lxrt.tokenization import BertTokenizer
+    from xggm_amd.lxrt.entry import convert_sents_to_features
+    from xggm_amd.vqa.vqacpv2_model import VQAModel
+    cfg = dict(shapes.TINY, vocab=96)
+    tok = BertTokenizer(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vocab_small.txt"),
+                        do_lower_case=True)
+    VISUAL_CONFIG.set_visual_dims(cfg["feat_dim"], 4)
+    a = param.parse_args(["--llayers", "2", "--xlayers", "2", "--rlayers", "1"])
+    bc_ = BertConfig(cfg["vocab"], hidden_size=cfg["hidden"], num_attention_heads=cfg["heads"],
+                     intermediate_size=cfg["inter"], max_position_embeddings=cfg["max_pos"])
+    m = VQAModel(11, args=a, config=bc_, compute_dtype=BF16, tokenizer=tok)
+    m.load_state_dict({k: torch.from_numpy(synth.seeded_param(k, v.shape, 3)) for k, v in m.state_dict().items()})
+    m = m.to(DEV).eval()
+    sents = ["What is the man holding?", "how many people are there", "is it a dog-like cat?!", ""]
+    bn = synth.vqa_batch(len(sents), A=11, F=cfg["feat_dim"], vocab=cfg["vocab"], seed=1)
+    b = batch_tensors(bn, DEV)
+    for _ in range(2):  # second call: cached sentences
+        (l1, v1), mask1, x1 = m(b["feats"], b["boxes"], sents)
+    f = convert_sents_to_features(sents, 20, tok)
+    ids = torch.tensor([q.input_ids for q in f], device=DEV)
+    msk = torch.tensor([q.input_mask for q in f], device=DEV)
+    seg = torch.tensor([q.segment_ids for q in f], device=DEV)
+    (l2, v2), mask2, x2 = m(b["feats"], b["boxes"], (ids, msk, seg))
+    assert torch.equal(mask1, mask2) and torch.equal(l1, l2) and torch.equal(v1, v2) and torch.equal(x1, x2)
+
+
 def test_lxrt_snapshot_save_load_round_trip(tmp_path):
     """LXRTEncoderFeature.save / .load (src/lxrt/entry.py:208-238): a snapshot written by one model -- re-keyed with
     the ``module.`` prefix of a DataParallel-trained LXMERT file and carrying a pre-training head the VQA model
