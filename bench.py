@@ -217,6 +217,9 @@ def main():
             dist.init_process_group(backend)
     from xggm_amd.engine import CapturedTrainer
     from xggm_amd.runtime import runtime_of
+    if os.environ.get("XGGM_GROUP_TILE"):  # A/B hook: pin the tile of grouped GEMM launches (1: 64x64, 2: 128x64, 3: 128x128)
+        from xggm_amd import _lib
+        _lib.lib.xggm_gemm_set_group_tile(int(os.environ["XGGM_GROUP_TILE"]))
 
     log("building the model (rank %d/%d)" % (rank, world))
     model, optim, batch = build(args, device)
