@@ -906,11 +906,26 @@ template <typename T> int grouped(const xggm_gemm_problem* probs, int n, hipStre
     static const TileModel models[3] = {{64, 64, 3.3f, 1.2f, 0.19f, 5.0f, 0.28f},
                                         {128, 64, 4.2f, 2.0f, 0.37f, 5.6f, 0.56f},
                                         {128, 128, 2.3f, 6.1f, 0.71f, 8.4f, 0.75f}};
+    static TileModel tuned[3];
+    static bool tuned_init = false;
+    if (!tuned_init) {  // A/B hook: XGGM_TILE_MODEL="a,b,s,f,k;a,b,s,f,k;a,b,s,f,k" overrides the fitted constants
+        for (int c = 0; c < 3; ++c) tuned[c] = models[c];
+        if (const char* e = getenv("XGGM_TILE_MODEL")) {
+            float q[15];
+            if (sscanf(e, "%f,%f,%f,%f,%f;%f,%f,%f,%f,%f;%f,%f,%f,%f,%f", q, q + 1, q + 2, q + 3, q + 4, q + 5, q + 6, q + 7,
+                       q + 8, q + 9, q + 10, q + 11, q + 12, q + 13, q + 14) == 15)
+                for (int c = 0; c < 3; ++c) {
+                    tuned[c].a = q[5 * c]; tuned[c].b = q[5 * c + 1]; tuned[c].s = q[5 * c + 2];
+                    tuned[c].f = q[5 * c + 3]; tuned[c].k = q[5 * c + 4];
+                }
+        }
+        tuned_init = true;
+    }
     int v = g_group_tile;
     if (v == 0) {
         float best = 0.f;
         for (int c = 0; c < 3; ++c) {
-            const TileModel& tm = models[c];
+            const TileModel& tm = tuned[c];
             double tiles = 0, work = 0;
             int nkmax = 0;
             for (int i = 0; i < n; ++i) {
