@@ -78,3 +78,78 @@ def test_single_process_is_noop():
     g = torch.ones(16)
     GradSync(g).sync([(0, 16)])
     assert torch.equal(g, torch.ones(16))
+
+
+def test_stage_ranges_tile_the_full_size_arena():
+    """dist.stage_ranges on the layout of the full 9/5/5 model (names and sizes from oracle.shapes, offsets laid out
+    the way ParamArena does): the four backward stages tile every active range exactly, the cross-layer matrices of
+    the last two x-layers and all head groups are in stage 0, nothing of enc_main's vector region before the last."""
+    from oracle import shapes
+    from xggm_amd import arena as A
+    from xggm_amd.dist import stage_ranges
+
+    class G:
+        pass
+
+    class FakeModel:
+        _enc_tail_prefixes = tuple("lxrt_encoder.model.bert.encoder.x_layers.4." + s
+                                   for s in ("visn_self_att.", "visn_inter.", "visn_output."))
+
+    class FakeParam:
+        def __init__(self, shape):
+            self.shape = tuple(shape)
+
+        def dim(self):
+            return len(self.shape)
+
+        def numel(self):
+            n = 1
+            for d in self.shape:
+                n *= d
+            return n
+
+    named = [(k, FakeParam(v)) for k, v in shapes.model_shapes(shapes.FULL, 2274).items()]
+    order, groups, info, off = [], {}, {}, 0
+    for n, p in named:
+        g = A.default_group_of(n, FakeModel)
+        if g not in order:
+            order.append(g)
+    for gname in order:
+        grp = G()
+        grp.start = off = A._align(off)
+        members = [(n, p) for n, p in named if A.default_group_of(n, FakeModel) == gname]
+        for atomic in (False, True):
+            if atomic:
+                grp.vec_start = off
+            for n, p in members:
+                if A.is_atomic(n, p) == atomic:
+                    info[n] = (off, p.numel(), gname, atomic)
+                    off = A._align(off + p.numel())
+        grp.end = off
+        groups[gname] = grp
+    fake = G()
+    fake.groups, fake.info = groups, info
+    active = [(g.start, g.end) for g in groups.values()]
+    st = stage_ranges(fake, active, dict(pair_cut=2, x_mid=3), 4)
+    assert len(st) == 4 and all(st)
+    tiles = sorted(r for s_ in st for r in s_)
+    assert all(a[1] <= b[0] for a, b in zip(tiles, tiles[1:]))
+    assert sum(e - s_ for s_, e in tiles) == sum(e - s_ for s_, e in active)
+
+    def stage_of(name):
+        o = info[name][0]
+        return next(k for k, rs in enumerate(st) if any(a <= o < b for a, b in rs))
+
+    pre = "lxrt_encoder.model.bert.encoder."
+    assert stage_of(pre + "x_layers.4.visual_attention.att.query.weight") == 0
+    assert stage_of(pre + "x_layers.3.lang_inter.dense.weight") == 0
+    assert stage_of(pre + "x_layers.2.lang_inter.dense.weight") == 1
+    assert stage_of(pre + "x_layers.0.visual_attention.att.query.weight") == 1
+    assert stage_of(pre + "layer.8.output.dense.weight") == 2 and stage_of(pre + "r_layers.2.output.dense.weight") == 2
+    assert stage_of(pre + "layer.1.output.dense.weight") == 3 and stage_of(pre + "r_layers.0.output.dense.weight") == 3
+    assert stage_of(pre + "visn_fc.visn_fc.weight") == 3
+    assert stage_of("logit_fc.3.weight") == 0 and stage_of("generator.gnn_layers.0.gnn_layers.0.ctx_layer.weight") == 0
+    assert stage_of(pre + "x_layers.4.visual_attention.output.LayerNorm.weight") == 3  # vectors: only after the last stage
+    assert stage_of("lxrt_encoder.model.bert.embeddings.word_embeddings.weight") == 3
+    sizes = [sum(e - s_ for s_, e in rs) for rs in st]
+    assert sum(sizes) > 2.2e8 and all(4e7 < z < 8e7 for z in sizes)  # 46 / 50 / 71 / 54 M parameters
