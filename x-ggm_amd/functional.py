@@ -235,10 +235,13 @@ def g_attn_fwd(rt, att, outm, xq, xkv, mask, B, Sq, Sk, salt):
                     (xq, xkv, mask, qkv, kv, c, ln.z, ln.stats))
 
 
-def g_attn_bwd(rt, saved, dy, defer_wgrad=False):
+def g_attn_bwd(rt, saved, dy, defer_wgrad=False, link=None):
     """backward of g_attn_fwd -> (dxq, dxkv).  ``defer_wgrad``: issue the weight-gradient products
     one round later (second use of SHARED weights in a lockstep pair: its read-modify-write of the
-    gradient must not share a launch with the first use's write)."""
+    gradient must not share a launch with the first use's write).  ``link``: dict shared by the two
+    directions of one cross-attention layer; the direction that runs second adds its input gradients into
+    the first one's buffers (x_l receives a gradient as query of one direction and as key/value of the
+    other) in the GEMM epilogue instead of a separate add kernel."""
     att, outm, dims, tens = saved
     B, Sq, Sk, heads, H, p_att, p_hid, self_att, salt = dims
     xq, xkv, mask, qkv, kv, c, z, stats = tens
@@ -276,8 +279,18 @@ def g_attn_bwd(rt, saved, dy, defer_wgrad=False):
         gbq, gbkv = a.atomic_target(bq), a.atomic_target([bk, bv])
         yield ops.AttnBwdReq(qkv, kv[:, :H], kv[:, H:], mask, d_c, dq, dkv[:, :H], dkv[:, H:], B, heads, Sq, Sk, p_att,
                              rt.rng, att._sid + salt, gbq, gbkv[:H], gbkv[H:])
+        if defer_wgrad and link is not None and "dxq" in link:
+            # second direction: its gradient w.r.t. its query input is the other direction's key/value input
+            # and vice versa -- accumulate there, one round after the first direction wrote them
+            yield late
+            pdq, dxq = ops.p_dgrad(dq, a.w(wq), residual=d_res, into=link["dxkv"])
+            pdk, dxkv = ops.p_dgrad(dkv, a.fused([wk, wv]), into=link["dxq"])
+            yield [_p_wgrad(rt, dq, xq, wq), _p_wgrad(rt, dkv, xkv, [wk, wv]), pdq, pdk]
+            return dxq, dxkv
         pdq, dxq = ops.p_dgrad(dq, a.w(wq), residual=d_res)
         pdk, dxkv = ops.p_dgrad(dkv, a.fused([wk, wv]))
+        if link is not None:
+            link["dxq"], link["dxkv"] = dxq, dxkv
         if defer_wgrad:
             yield late + [pdq, pdk]
             yield [_p_wgrad(rt, dq, xq, wq), _p_wgrad(rt, dkv, xkv, [wk, wv])]
@@ -351,6 +364,9 @@ class FFNFn(Function):
         return (None, None, None, dx) + (None,) * ctx.np
 
 
+_NO_LINK = bool(__import__("os").environ.get("XGGM_NO_LINK"))  # A/B hook: separate add kernels as before
+
+
 class PairFn(Function):
     """two independent blocks (the same layer of the language and of the vision stream, or the two
     directions of a cross-attention layer) advanced in lockstep so that their GEMMs share launches.
@@ -383,12 +399,14 @@ class PairFn(Function):
         # a stream whose output is not used downstream (the vision side of the last cross layer
         # in the plain-VQA pass) receives no gradient: autograd hands a None / never calls us
         gens, who = [], []
+        both = dy_l is not None and dy_v is not None
+        link = {} if (kind == "cross" and both and not _NO_LINK) else None
         if dy_l is not None:
-            gens.append(g_ffn_bwd(rt, s_l, dy_l) if kind == "ffn" else g_attn_bwd(rt, s_l, dy_l))
+            gens.append(g_ffn_bwd(rt, s_l, dy_l) if kind == "ffn" else g_attn_bwd(rt, s_l, dy_l, link=link))
             who.append("l")
         if dy_v is not None:
             gens.append(g_ffn_bwd(rt, s_v, dy_v) if kind == "ffn"
-                        else g_attn_bwd(rt, s_v, dy_v, defer_wgrad=(kind == "cross" and dy_l is not None)))
+                        else g_attn_bwd(rt, s_v, dy_v, defer_wgrad=(kind == "cross" and dy_l is not None), link=link))
             who.append("v")
         res = dict(zip(who, drive((dy_l if dy_l is not None else dy_v).dtype, gens)))
         dx_l = dx_v = None
@@ -402,8 +420,11 @@ class PairFn(Function):
                 dx_l, dx_v = res["l"]
             if "v" in res:
                 dv_q, dv_kv = res["v"]
-                dx_v = dv_q if dx_v is None else dx_v.add_(dv_q)
-                dx_l = dv_kv if dx_l is None else dx_l.add_(dv_kv)
+                if link is not None:  # the vision direction accumulated into the language direction's buffers
+                    assert dv_q is dx_v and dv_kv is dx_l
+                else:
+                    dx_v = dv_q if dx_v is None else dx_v.add_(dv_q)
+                    dx_l = dv_kv if dx_l is None else dx_l.add_(dv_kv)
         return (None, None, None, dx_l, dx_v, None, None, None, None) + (None,) * ctx.np
 
 

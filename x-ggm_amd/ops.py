@@ -141,12 +141,17 @@ def p_fwd(x, w, bias=None, act=ACT_NONE, want_preact=False, out_f32=False):
     return _problem(x, w, y, M, N, K, a_rs, 1, K, 1, N, bias=bias, preact=pre, act=act, c_f32=out_f32), y, pre
 
 
-def p_dgrad(dy, w, residual=None, gelu_aux=None, colsum=None):
+def p_dgrad(dy, w, residual=None, gelu_aux=None, colsum=None, into=None):
     """problem for dx = dy @ w (+ residual) (* gelu'(aux)); ``colsum`` (fp32 [K]) += column sums of dx
-    (the bias gradient of the Linear that produced the activation); returns (problem, dx)."""
+    (the bias gradient of the Linear that produced the activation); ``into``: an existing gradient of the
+    same input, the result is ADDED to it (second consumer of one tensor); returns (problem, dx)."""
     M, N, a_rs = _rows(_chk(dy))
     K = w.shape[1]
     assert w.shape[0] == N and w.dtype == dy.dtype and w.is_contiguous()
+    if into is not None:
+        assert tuple(into.shape) == (M, K) and into.dtype == dy.dtype and into.is_contiguous()
+        assert gelu_aux is None and colsum is None
+        return _problem(dy, w, into, M, K, N, a_rs, 1, 1, K, K, residual=residual, accumulate=True), into
     dx = torch.empty((M, K), device=dy.device, dtype=dy.dtype)
     if colsum is not None:
         _c(colsum, F32, "colsum")
