@@ -143,8 +143,10 @@ struct LnFwdGroup {
     int n;
 };
 
+// rows in flight per workgroup; same-box A/B per iteration: 4 -> 8 rows -0.05 ms, 8 -> 16 rows +0.07 ms
+constexpr int LN_FWD_W = 8;
 template <typename T, int NV>
-__global__ __launch_bounds__(NT) void ln_fwd_kernel(LnFwdGroup G, int H, float eps, float p_pre, float p_post,
+__global__ __launch_bounds__(LN_FWD_W * 64) void ln_fwd_kernel(LnFwdGroup G, int H, float eps, float p_pre, float p_post,
                                                     const uint64_t* rng, int accumulate, float out_scale) {
     int si = 0;
 #pragma unroll
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(NT) void ln_fwd_kernel(LnFwdGroup G, int H, float e
     rng_load(d.rng, seed, off);
     const float ik_pre = d.p_pre > 0.f ? 1.f / (1.f - d.p_pre) : 1.f;
     const float ik_post = d.p_post > 0.f ? 1.f / (1.f - d.p_post) : 1.f;
-    for (int row = blk * WPB + wid; row < M; row += nblk * WPB) {
+    for (int row = blk * LN_FWD_W + wid; row < M; row += nblk * LN_FWD_W) {
         const int64_t rb = (int64_t)row * H;
         float z[NV][4];
         float sum = 0.f;
@@ -712,10 +714,10 @@ int ln_fwd_grouped(const xggm_ln_fwd_problem* probs, int n, int H, float eps, fl
             XGGM_REQUIRE(q.in && q.gamma && q.beta && q.out, "xggm_ln_fwd: null pointer");
             G.s[i] = q;
             G.start[i] = total;
-            total += rows_grid(q.M, 4096);
+            total += std::min(ceil_div(q.M, LN_FWD_W), 4096);
         }
         G.start[G.n] = total;
-        DISPATCH_NV(H, hipLaunchKernelGGL((ln_fwd_kernel<T, NV>), dim3(total), dim3(NT), 0, st, G, H, eps, p_pre, p_post, rng,
+        DISPATCH_NV(H, hipLaunchKernelGGL((ln_fwd_kernel<T, NV>), dim3(total), dim3(LN_FWD_W * 64), 0, st, G, H, eps, p_pre, p_post, rng,
                                            accumulate, out_scale));
         if (int e = xggm_check_launch("xggm_ln_fwd")) return e;
     }
