@@ -40,6 +40,7 @@ for name in ["boto3", "botocore", "botocore.exceptions", "tensorboardX", "h5py",
 sys.modules["botocore.exceptions"].ClientError = type("ClientError", (Exception,), {})
 sys.modules["tensorboardX"].SummaryWriter = object
 sys.modules["prefetch_generator"].BackgroundGenerator = object
+_WHICH = sys.argv[1:]
 sys.argv = ["x"]
 sys.path.insert(0, REF)
 
@@ -381,10 +382,72 @@ def tokenizer_case():
         json.dump(out, f, ensure_ascii=True, indent=0)
 
 
+# ---- LXMERT snapshot loading with answer-head surgery (src/pretrain/qa_answer_table.py:125-198) ----
+ANS_TABLE = [("man", ["vqa", "gqa"]), ("woman", ["vqa"]), ("1", ["vqa", "gqa"]), ("2", ["vqa"]), ("gray", ["gqa"]),
+             ("cat", ["vqa", "gqa"]), ("dog", ["vqa"]), ("yes", ["vqa", "gqa"]), ("no", ["vqa", "gqa"]),
+             ("red", ["vqa"]), ("apple", ["visual7w"]), ("tree", ["gqa"])]
+ANS_LABELS = ["yes", "The man.", "a cat", "an apple", "two", "grey", "unicorn", "", "no", "the Woman", "one", "A dog.",
+              "tree", "blue"]
+
+
+def answer_table_case(seed=11):
+    """runs the reference's load_lxmert_qa on a synthetic snapshot / answer table in a scratch directory and
+    records what it left in the model; the snapshot is regenerated from the seed recipe by the test."""
+    import json
+    import tempfile
+    from pretrain import qa_answer_table as QA
+    cfg = TINY
+    A, hid = len(ANS_LABELS), cfg["hidden"]
+    enc = make_encoder(cfg, seed)
+    heads = make_heads(hid, A, 630, seed)
+
+    class Holder(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lxrt_encoder = nn.Module()
+            self.lxrt_encoder.model = enc
+            self.logit_fc = heads["logit_fc"]
+
+    model = Holder()
+    n_pre = len(ANS_TABLE)
+    snap = {"module." + k: t(synth.seeded_param("snap." + k, v.shape, seed + 1)) for k, v in enc.state_dict().items()}
+    pre_head = nn.Sequential(nn.Linear(hid, hid * 2), M.GeLU(), M.BertLayerNorm(hid * 2, eps=1e-12),
+                             nn.Linear(hid * 2, n_pre))
+    for k, v in pre_head.state_dict().items():
+        snap["module.answer_head.logit_fc." + k] = t(synth.seeded_param("snap.answer_head." + k, v.shape, seed + 1))
+    snap["module.obj_predict_head.decoder.weight"] = torch.zeros(3, 3)  # a key the fine-tuning model does not have
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(os.path.join(d, "data", "lxmert"))
+        with open(os.path.join(d, "data", "lxmert", "all_ans.json"), "w") as f:
+            json.dump([{"ans": a, "dsets": ds} for a, ds in ANS_TABLE], f)
+        torch.save(snap, os.path.join(d, "snap_LXRT.pth"))
+        os.chdir(d)
+        try:
+            QA.load_lxmert_qa(os.path.join(d, "snap"), model, ANS_LABELS)
+            table = QA.AnswerTable()
+            converted = [table.convert_ans(a) for a in ANS_LABELS]
+            gqa_only = QA.AnswerTable(dsets=["gqa"]).all_answers()
+        finally:
+            os.chdir(cwd)
+    out = {"head." + k: v.numpy() for k, v in model.logit_fc.state_dict().items()}
+    sd = enc.state_dict()
+    names = sorted(sd)
+    out["enc_names"] = np.array(names)
+    out["enc_norms"] = np.array([float(sd[k].double().norm()) for k in names])
+    out["enc_dots"] = np.array([float((sd[k].double() * t(probe(k, sd[k].shape, seed)).double()).sum()) for k in names])
+    np.savez_compressed(os.path.join(HERE, "answer_table.npz"), **out)
+    with open(os.path.join(HERE, "answer_table.json"), "w") as f:
+        json.dump({"seed": seed, "table": [{"ans": a, "dsets": ds} for a, ds in ANS_TABLE], "labels": ANS_LABELS,
+                   "converted": converted, "gqa_only": gqa_only}, f, indent=0)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["all"]
+    which = _WHICH or ["all"]
     if "all" in which or "tok" in which:
         tokenizer_case()
+    if "all" in which or "ans" in which:
+        answer_table_case()
     torch.manual_seed(0)
     if "all" in which or "enc" in which:
         encoder_case("enc_tiny", TINY, 3, 1)

@@ -161,3 +161,62 @@ def test_tokenizer_and_features_match_reference_golden():
             assert hb.shape == (3, len(want), int(L))
             assert hb[0].tolist() == [w[0] for w in want] and hb[1].tolist() == [w[1] for w in want]
             assert hb[2].tolist() == [w[2] for w in want]
+
+
+def test_lxmert_snapshot_loading_matches_reference_golden(tmp_path, monkeypatch):
+    """AnswerTable / load_lxmert_qa (src/pretrain/qa_answer_table.py:8-198) against what the reference's own
+    function left in a model (tests/golden/make_golden.py answer_table_case): answer normalisation, rows
+    copied for known answers, rows zeroed for unknown ones, the rest of the head and the whole encoder
+    taken from the snapshot, ``module.`` prefixes and foreign keys ignored."""
+    import json
+    import numpy as np
+    from xggm_amd import param, synth
+    from xggm_amd.lxrt.modeling import BertConfig, VISUAL_CONFIG
+    from xggm_amd.vqa.vqacpv2_model import VQAModel
+    from xggm_amd.pretrain.qa_answer_table import AnswerTable, load_lxmert_qa
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    meta = json.load(open(os.path.join(here, "answer_table.json")))
+    g = np.load(os.path.join(here, "answer_table.npz"))
+    seed, labels = meta["seed"], meta["labels"]
+    cfg = shapes.TINY
+    VISUAL_CONFIG.set_visual_dims(cfg["feat_dim"], 4)
+    a = param.parse_args(["--llayers", str(cfg["l_layers"]), "--xlayers", str(cfg["x_layers"]), "--rlayers",
+                          str(cfg["r_layers"])])
+    bc = BertConfig(cfg["vocab"], hidden_size=cfg["hidden"], num_attention_heads=cfg["heads"],
+                    intermediate_size=cfg["inter"], max_position_embeddings=cfg["max_pos"])
+    model = VQAModel(len(labels), args=a, config=bc)
+    # the synthetic snapshot of the golden script, regenerated from its seed recipe
+    hid, n_pre = cfg["hidden"], len(meta["table"])
+    snap = {"module." + k: torch.from_numpy(synth.seeded_param("snap." + k, tuple(v.shape), seed + 1))
+            for k, v in model.lxrt_encoder.model.state_dict().items()}
+    for k, shp in {"0.weight": (2 * hid, hid), "0.bias": (2 * hid,), "2.weight": (2 * hid,), "2.bias": (2 * hid,),
+                   "3.weight": (n_pre, 2 * hid), "3.bias": (n_pre,)}.items():
+        snap["module.answer_head.logit_fc." + k] = torch.from_numpy(
+            synth.seeded_param("snap.answer_head." + k, shp, seed + 1))
+    snap["module.obj_predict_head.decoder.weight"] = torch.zeros(3, 3)
+    os.makedirs(tmp_path / "data" / "lxmert")
+    (tmp_path / "data" / "lxmert" / "all_ans.json").write_text(json.dumps(meta["table"]))
+    torch.save(snap, str(tmp_path / "snap_LXRT.pth"))
+    monkeypatch.chdir(tmp_path)  # the table path is relative to the working directory, as in the reference
+    table = AnswerTable()
+    assert [table.convert_ans(x) for x in labels] == meta["converted"]
+    assert AnswerTable(dsets=["gqa"]).all_answers() == meta["gqa_only"]
+    assert table.num_answers == n_pre and table.used("gray") and not table.used("grey")
+    load_lxmert_qa(str(tmp_path / "snap"), model, labels)
+    sd = model.state_dict()
+    for k in ("0.weight", "0.bias", "2.weight", "2.bias", "3.weight", "3.bias"):
+        assert np.array_equal(sd["logit_fc." + k].numpy(), g["head." + k]), k
+    zero_rows = [i for i, c in enumerate(meta["converted"]) if not table.used(c)]
+    assert zero_rows and all(not sd["logit_fc.3.weight"][i].any() for i in zero_rows)
+    enc = model.lxrt_encoder.model.state_dict()
+    assert sorted(enc) == list(g["enc_names"])
+    for k, n, d in zip(g["enc_names"], g["enc_norms"], g["enc_dots"]):
+        v = enc[str(k)].double()
+        probe = torch.from_numpy(synth._rng(seed, "probe:" + str(k)).standard_normal(tuple(v.shape), dtype=np.float32))
+        assert abs(float(v.norm()) - n) <= 1e-9 * max(1.0, n), k
+        assert abs(float((v * probe.double()).sum()) - d) <= 1e-9 * max(1.0, abs(d)), k
+    # a snapshot that lacks an encoder tensor is refused, as in the reference (:188-190)
+    del snap["module.bert.pooler.dense.bias"]
+    torch.save(snap, str(tmp_path / "short_LXRT.pth"))
+    with pytest.raises(AssertionError):
+        load_lxmert_qa(str(tmp_path / "short"), model, labels)

@@ -441,6 +441,106 @@ def test_lxrt_snapshot_save_load_round_trip(tmp_path):
     assert np.isfinite(float(loss))
 
 
+def test_lxmert_qa_snapshot_with_answer_surgery_on_device(tmp_path):
+    """load_lxmert_qa (src/pretrain/qa_answer_table.py:125-198) on a model that already lives on the GPU: the
+    encoder and the answer head come from the snapshot, the bf16 shadows follow, so the logit of every answer
+    the pre-training table knows equals the pre-training model's logit for that answer and every other logit
+    is exactly 0 (zeroed row and bias)."""
+    import json
+    from oracle import shapes
+    from xggm_amd.pretrain.qa_answer_table import AnswerTable, load_lxmert_qa
+    cfg, B = shapes.TINY, 4
+    table = [{"ans": a, "dsets": ["vqa"]} for a in ["man", "2", "cat", "gray", "yes", "no", "tree"]]
+    labels = ["yes", "the man", "two", "unicorn", "a cat.", "grey", ""]
+    (tmp_path / "all_ans.json").write_text(json.dumps(table))
+    tab = AnswerTable(path=str(tmp_path / "all_ans.json"))
+    bn = synth.vqa_batch(B, A=len(table), F=cfg["feat_dim"], vocab=cfg["vocab"], seed=4)
+    b = batch_tensors(bn, DEV)
+    sent = (b["input_ids"], b["input_mask"], b["segment_ids"])
+    pre = build_model(cfg, len(table), seed=31, dt=BF16).eval()  # stands for the pre-trained LXMERT-QA model
+    with torch.no_grad():
+        pre_logit = pre.logit_fc(pre(b["feats"], b["boxes"], sent)[2])
+    snap = {"module." + k[len("lxrt_encoder.model."):]: v.cpu() for k, v in pre.state_dict().items()
+            if k.startswith("lxrt_encoder.model.")}
+    snap.update({"module.answer_head." + k: v.cpu() for k, v in pre.state_dict().items() if k.startswith("logit_fc.")})
+    torch.save(snap, str(tmp_path / "pre_LXRT.pth"))
+    dst = build_model(cfg, len(labels), seed=32, dt=BF16).eval()
+    load_lxmert_qa(str(tmp_path / "pre"), dst, labels, answer_table=tab)
+    with torch.no_grad():
+        logit = dst.logit_fc(dst(b["feats"], b["boxes"], sent)[2])
+    for label, ans in enumerate(labels):
+        conv = tab.convert_ans(ans)
+        if tab.used(conv):
+            assert torch.equal(logit[:, label], pre_logit[:, tab.ans2id(conv)]), ans
+        else:
+            assert not logit[:, label].any(), ans
+    assert sum(tab.used(tab.convert_ans(x)) for x in labels) == 5
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+def test_predict_sweep_matches_oracle_answers(dt):
+    """``predict`` (src/vqa/vqacpv2.py:315-339): eval forward -> logit_fc -> arg-max -> answers, run eagerly and
+    through the captured predictor (batches of 4, 4 and a short last batch of 2), against the CPU oracle's logits:
+    the answer indices must be the oracle's wherever its top-2 margin is above the logit tolerance, and the eager
+    and the captured sweep must agree everywhere (same kernels, same rows)."""
+    from oracle import shapes, xggm_oracle as O
+    from helpers import seeded_params
+    from xggm_amd.engine import CapturedPredictor
+    from xggm_amd.vqa.vqacpv2 import predict, evaluate
+    cfg, A, seed, n = shapes.TINY, 23, 14, 10
+    m = build_model(cfg, A, seed=seed, dt=dt).train()  # predict must switch to eval itself and switch back
+    bn = synth.vqa_batch(n, A=A, F=cfg["feat_dim"], vocab=cfg["vocab"], seed=seed)
+    bc = batch_tensors(bn)
+    P = seeded_params(shapes.model_shapes(cfg, A), seed)
+    with torch.no_grad():
+        ref_logit = O.logit_fc(P, "logit_fc.", O.model_forward(P, bc, cfg)[2])
+    top2 = ref_logit.topk(2, dim=1).values
+    margin = (top2[:, 0] - top2[:, 1]).numpy()
+    ref_label = ref_logit.argmax(1).numpy()
+
+    class DSet:
+        label2ans = ["ans%d" % i for i in range(A)]
+
+    class Evaluator:
+        def evaluate(self, quesid2ans):
+            return sum(quesid2ans[q] == DSet.label2ans[ref_label[q]] for q in quesid2ans) / len(quesid2ans)
+
+        def dump_result(self, quesid2ans, path):
+            self.dumped = (dict(quesid2ans), path)
+
+    def loader():
+        for lo in range(0, n, 4):
+            hi = min(lo + 4, n)
+            sent = tuple(bc[k][lo:hi] for k in ("input_ids", "input_mask", "segment_ids"))
+            yield torch.arange(lo, hi), bc["feats"][lo:hi], bc["boxes"][lo:hi], sent, bc["target"][lo:hi]
+
+    ev = Evaluator()
+    eager = predict(m, (DSet, loader(), ev), dump="somewhere.json")
+    assert m.training and ev.dumped == (eager, "somewhere.json") and sorted(eager) == list(range(n))
+    pred = CapturedPredictor(m, 4)
+    assert m.training
+    captured = predict(m, (DSet, loader(), ev), predictor=pred)
+    assert captured == eager
+    # logits of the captured sweep against the oracle, then the answers
+    logits = []
+    for _, feats, boxes, sent, _ in loader():
+        logits.append(pred(feats.to(DEV), boxes.to(DEV), sent)[1].cpu().clone())
+    logits = torch.cat(logits)
+    abs_err = float((logits - ref_logit).abs().max())
+    tol = 2e-4 if dt == F32 else 3e-2
+    assert abs_err < tol * float(ref_logit.abs().max()), abs_err
+    sure = margin > 2 * abs_err  # the arg-max cannot flip where the oracle's top-2 margin exceeds twice the error
+    assert dt != F32 or sure.sum() >= n // 2
+    for q in range(n):
+        if sure[q]:
+            assert eager[q] == DSet.label2ans[ref_label[q]], q
+        assert eager[q] == DSet.label2ans[int(logits[q].argmax())]
+    assert evaluate(m, (DSet, loader(), ev), predictor=pred) >= sure.mean()
+    with pytest.raises(ValueError):
+        pred(bc["feats"][:5].to(DEV), bc["boxes"][:5].to(DEV), tuple(bc[k][:5] for k in
+                                                                     ("input_ids", "input_mask", "segment_ids")))
+
+
 def test_train_iteration_bf16_matches_oracle_trend():
     """bf16 execution of one full iteration (both passes) on the tiny model: losses within
     2 % of the fp32 oracle trajectory and the model keeps improving on the fixed batch."""

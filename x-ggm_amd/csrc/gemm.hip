@@ -688,15 +688,18 @@ struct GroupArgs {
 
 template <int BM, int BN> __global__ __launch_bounds__(NT, (min_waves<BM, BN>())) void gemm_grouped_kernel(GroupArgs ga) {
     extern __shared__ __attribute__((aligned(16))) bf16 fsm[];
-    // natural block order: an XCD-contiguous remap would hand whole problems (with different
-    // k-loop lengths) to different XCDs and unbalance them
+    // Which problem, and which tile of it.  Inside each problem the tiles get the XCD-aware order:
+    // blocks are dealt to XCDs by id % 8, so the problem's blocks of one residue class take one
+    // contiguous row-major run of its tiles (shared A row-panels stay in one L2), while every XCD
+    // still receives 1/8 of EVERY problem (a remap over the whole grid would hand whole problems,
+    // with different k-loop lengths, to different XCDs).  Same-box A/B: -0.04 ms per iteration.
     const int b = blockIdx.x;
-    int i = 0;
+    int i = 0, t0 = 0, t1 = ga.tile_start[1];
 #pragma unroll
     for (int k = 1; k < MAX_GROUP; ++k)
-        if (k < ga.nprob && b >= ga.tile_start[k]) i = k;
+        if (k < ga.nprob && b >= ga.tile_start[k]) { i = k; t0 = ga.tile_start[k]; t1 = ga.tile_start[k + 1]; }
     const GemmArgs g = ga.p[i];
-    const int local = b - ga.tile_start[i];
+    const int local = g.xcd_swizzle ? xcd_remap(b - t0, t1 - t0) : b - t0;
     const int gx = (g.N + BN - 1) / BN, gy = (g.M + BM - 1) / BM;
     const int tile_n = local % gx, tile_m = (local / gx) % gy, bz = local / (gx * gy);
     constexpr int DK = (BM * BN <= 64 * 64) ? 4 : 2;  // prefetch depth when an operand is k-major

@@ -203,3 +203,69 @@ class CapturedTrainer:
             b = self.run_pass(branch)
             a = self.run_pass("plain")
         return a, b
+
+
+class CapturedPredictor:
+    """The validation sweep of the reference (``VQA.predict``, src/vqa/vqacpv2.py:315-339; GQA twin
+    src/gqa/gqa_ood.py:379-403): eval mode, no autograd, encoder -> ``logit_fc`` -> arg-max; the generator is
+    not on this path.  The forward of one full batch is captured once and replayed; a short last batch is
+    padded (its padding rows are computed and dropped: samples are independent, so the kept rows do not change).
+    The logits are fp32 and the arg-max is torch's (first maximal index), as in ``logit.max(1)``."""
+
+    def __init__(self, model, batch_size, n_objects=36, feat_dim=None, max_seq_length=None, use_graph=True):
+        self.model = model
+        dev = next(model.parameters()).device
+        enc = model.lxrt_encoder
+        T = max_seq_length or enc.max_seq_length
+        F = feat_dim or enc.model.bert.encoder.visn_fc.visn_fc.in_features
+        self.B = batch_size
+        self.static = dict(feats=torch.zeros(batch_size, n_objects, F, device=dev),
+                           boxes=torch.zeros(batch_size, n_objects, 4, device=dev),
+                           ids=torch.zeros(3, batch_size, T, dtype=torch.long, device=dev))
+        self.static["ids"][1, :, 0] = 1  # a valid mask for the rows nobody has filled yet
+        self.graph, self.logit, self.label = None, None, None
+        self.use_graph = use_graph
+        if use_graph:
+            was_training = model.training
+            model.eval()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._forward()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.logit, self.label = self._forward()
+            model.train(was_training)
+
+    def _forward(self):
+        s = self.static
+        with torch.no_grad():
+            _, _, x = self.model(s["feats"], s["boxes"], (s["ids"][0], s["ids"][1], s["ids"][2]))
+            logit = self.model.logit_fc(x)
+            return logit, logit.max(1)[1]
+
+    def __call__(self, feats, boxes, sent):
+        """-> (labels [b] int64, logits [b, A] fp32) for b <= batch_size samples; ``sent``: list of strings or the
+        (input_ids, input_mask, segment_ids) tuple.  The returned tensors are views of static buffers: consume
+        them (``.cpu()``) before the next call."""
+        b = feats.shape[0]
+        if b > self.B:
+            raise ValueError("batch of %d exceeds the captured batch size %d" % (b, self.B))
+        s = self.static
+        if isinstance(sent, (tuple, list)) and len(sent) == 3 and torch.is_tensor(sent[0]):
+            for i in range(3):
+                s["ids"][i, :b].copy_(sent[i], non_blocking=True)
+        else:
+            s["ids"][:, :b].copy_(self.model.lxrt_encoder.batcher.host_batch(list(sent)), non_blocking=True)
+        s["feats"][:b].copy_(feats, non_blocking=True)
+        s["boxes"][:b].copy_(boxes, non_blocking=True)
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            was_training = self.model.training
+            self.model.eval()
+            self.logit, self.label = self._forward()
+            self.model.train(was_training)
+        return self.label[:b], self.logit[:b]

@@ -1,6 +1,6 @@
 """GQA-OOD iteration (src/gqa/gqa_ood.py:165-292): GGM pass first (KL weight 12), plain
 pass second.  Thin front-end over xggm_amd.vqa.vqacpv2."""
-from ..vqa.vqacpv2 import (loss_func, compute_kl_loss, BCEWithLogitsLoss, plain_pass, ggm_pass,  # noqa: F401
+from ..vqa.vqacpv2 import (loss_func, compute_kl_loss, BCEWithLogitsLoss, plain_pass, ggm_pass, predict, evaluate,  # noqa: F401
                            train_iteration as _train_iteration, make_optimizer)  # noqa: F401
 
 

@@ -106,23 +106,28 @@ class LXRTEncoderFeature(nn.Module):
 
     def multi_gpu(self):
         raise NotImplementedError("single-process nn.DataParallel is replaced by one process per GPU: "
-                                  "see xggm_amd.dist.DataParallelTrainer")
+                                  "see xggm_amd.vqa.vqacpv2.enable_data_parallel")
 
     @property
     def dim(self):
         return self._dim
+
+    @property
+    def batcher(self):
+        """the cached question -> token-id batcher of this encoder's tokenizer"""
+        if self.tokenizer is None:
+            raise RuntimeError("no tokenizer: pass vocab_path/tokenizer, or feed (input_ids, input_mask, "
+                               "segment_ids) tensors instead of strings")
+        if getattr(self, "_batcher", None) is None or self._batcher.tok is not self.tokenizer:
+            self._batcher = SentenceBatcher(self.tokenizer, self.max_seq_length)
+        return self._batcher
 
     def forward(self, sents, feats, visual_attention_mask=None):
         device = feats[0].device
         if isinstance(sents, (tuple, list)) and len(sents) == 3 and torch.is_tensor(sents[0]):
             input_ids, input_mask, segment_ids = (t.to(device) for t in sents)
         else:
-            if self.tokenizer is None:
-                raise RuntimeError("no tokenizer: pass vocab_path/tokenizer, or feed (input_ids, input_mask, "
-                                   "segment_ids) tensors instead of strings")
-            if getattr(self, "_batcher", None) is None or self._batcher.tok is not self.tokenizer:
-                self._batcher = SentenceBatcher(self.tokenizer, self.max_seq_length)
-            input_ids, input_mask, segment_ids = self._batcher(sents, device)
+            input_ids, input_mask, segment_ids = self.batcher(sents, device)
         feat_seq, output = self.model(input_ids, segment_ids, input_mask, visual_feats=feats,
                                       visual_attention_mask=visual_attention_mask)
         return feat_seq, input_mask, output

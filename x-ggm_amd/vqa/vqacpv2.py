@@ -178,3 +178,37 @@ def make_optimizer(model, lr, t_total, warmup=0.1):
     base_params = [p for p in model.parameters() if id(p) not in lxrt_ids]
     groups = [{"params": base_params, "lr": lr * 4}, {"params": list(model.lxrt_encoder.parameters())}]
     return BertAdam(groups, lr=lr, warmup=warmup, t_total=t_total)
+
+
+def predict(model, eval_tuple, dump=None, predictor=None):
+    """``VQA.predict`` (src/vqa/vqacpv2.py:315-339; GQA twin src/gqa/gqa_ood.py:379-403): eval mode, encoder ->
+    ``logit_fc`` -> arg-max -> ``{question_id: answer}``.  ``eval_tuple`` = (dset, loader, evaluator) as in the
+    reference; only the first four fields of a loader item are looked at (never the ground truth).  ``predictor``:
+    an ``engine.CapturedPredictor`` to replay one captured forward per batch instead of launching eagerly."""
+    dset, loader, evaluator = eval_tuple
+    dev = next(model.parameters()).device
+    was_training = model.training
+    model.eval()
+    quesid2ans = {}
+    try:
+        for datum_tuple in loader:
+            ques_id, feats, boxes, sent = datum_tuple[:4]
+            feats, boxes = feats.to(dev, non_blocking=True), boxes.to(dev, non_blocking=True)
+            if predictor is not None:
+                label, _ = predictor(feats, boxes, sent)
+            else:
+                with torch.no_grad():
+                    _, _, x = model(feats, boxes, sent)
+                    label = model.logit_fc(x).max(1)[1]
+            for qid, l in zip(ques_id, label.cpu().numpy()):
+                quesid2ans[qid.item() if hasattr(qid, "item") else qid] = dset.label2ans[l]
+    finally:
+        model.train(was_training)
+    if dump is not None:
+        evaluator.dump_result(quesid2ans, dump)
+    return quesid2ans
+
+
+def evaluate(model, eval_tuple, dump=None, predictor=None):
+    """``VQA.evaluate`` (src/vqa/vqacpv2.py:341-344)"""
+    return eval_tuple[2].evaluate(predict(model, eval_tuple, dump, predictor))
