@@ -93,6 +93,22 @@ typedef struct xggm_gemm_problem {
 } xggm_gemm_problem;
 int xggm_gemm_grouped_f32(const xggm_gemm_problem* probs, int n, xggm_stream_t stream);
 int xggm_gemm_grouped_bf16(const xggm_gemm_problem* probs, int n, xggm_stream_t stream);
+/* fp8 forward product of the mixed-precision configuration (BASELINE.json configs[4]: "fp8 MFMA path for LXMERT
+ * QKV/FFN GEMMs"; the Linear layers of src/lxrt/modeling.py:345-347 (query/key/value), :429 (intermediate),
+ * :442 (output) -- the reference itself is fp32 only, `--fp16` is unused):
+ *   C[m,n] = act(scale_a * scale_b * sum_k A(m,k) B(n,k) + bias[n]) (+ residual[m,n])
+ * A [M, K] and B [N, K] hold OCP e4m3fn bytes (k contiguous; row strides a_rs / b_ns in elements, multiples of
+ * 16, like K; 16-byte aligned bases); scale_a / scale_b: device scalars (null = 1), the reciprocals of the
+ * per-tensor quantisation scales; fp32 accumulation; bias fp32 or null; C / residual / preact bf16 with row
+ * stride ldc (c_f32 != 0: C fp32); act: XGGM_ACT_NONE .. XGGM_ACT_TANH as in xggm_gemm_bf16. */
+int xggm_gemm_fp8e4m3(const void* A, const void* B, void* C, int M, int N, int K, int64_t a_rs, int64_t b_ns, int64_t ldc,
+                      const float* scale_a, const float* scale_b, const float* bias, const void* residual, void* preact,
+                      int act, int c_f32, xggm_stream_t stream);
+/* y[i] = e4m3fn(clamp(x[i] * *qscale, -448, 448)), round-to-nearest-even; x fp32 / bf16, n % 8 == 0; qscale: device
+ * scalar or null (1); amax: device scalar or null, raised to max |x| (atomic; the caller zeroes it): the next
+ * step's scale without another pass over x. */
+int xggm_quantize_fp8e4m3_f32(const void* x, void* y, int64_t n, const float* qscale, float* amax, xggm_stream_t stream);
+int xggm_quantize_fp8e4m3_bf16(const void* x, void* y, int64_t n, const float* qscale, float* amax, xggm_stream_t stream);
 /* HOST: tile of grouped launches (0 heuristic, 1: 64x64, 2: 128x64, 3: 128x128) */
 int xggm_gemm_set_group_tile(int v);
 /* HOST: 1 = run bf16 GEMMs on the generic 64x64 kernel, 0 = tuned kernels (default); A/B tests */

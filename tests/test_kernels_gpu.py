@@ -675,3 +675,64 @@ def test_bad_arguments_fail_loudly(ops):
                      torch.zeros(130, 64, device=DEV), None, 2, 1, 65, 65, 0.0, None, 0)  # S > 64
     with pytest.raises(RuntimeError):
         ops.linear_fwd(torch.zeros(4, 8), torch.zeros(3, 8), None)  # CPU tensors: no fallback
+
+
+# ----------------------------------------------------------------------------- fp8 forward (BASELINE config C5)
+@pytest.mark.parametrize("dt", DTS)
+def test_quantize_fp8_is_torch_e4m3fn_rounding(ops, dt):
+    """xggm_quantize_fp8e4m3: bit-exact against torch's float8_e4m3fn cast (OCP e4m3fn, round-to-nearest-even,
+    subnormals, ties, signed zeros) of clamp(x * scale, +-448) computed in fp32; amax is max |x| exactly."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4096 * 8, generator=g) * torch.logspace(-6, 3, 4096 * 8)  # subnormal range up to saturation
+    x[:64] = torch.tensor([0.0, -0.0, 448.0, -448.0, 1e9, -1e9, 2 ** -9, 2 ** -10, 1.0625, 1.1875, 0.0009765625 * 1.5,
+                           17.0, 18.0, 19.0, 20.0, 21.0] * 4)
+    x = x.to(dt)
+    for qs in (None, 0.37, 64.0):
+        s = None if qs is None else torch.tensor([qs], device=DEV)
+        amax = torch.zeros(1, device=DEV)
+        y = ops.quantize_fp8(x.to(DEV), s, amax)
+        ref = (x.float() * (torch.tensor(qs) if qs else 1.0)).clamp(-448, 448).to(torch.float8_e4m3fn)
+        assert torch.equal(y.cpu().view(torch.uint8), ref.view(torch.uint8)), qs
+        assert float(amax) == float(x.float().abs().max())
+    with pytest.raises(RuntimeError, match="multiple of 8"):
+        ops.quantize_fp8(torch.zeros(12, device=DEV))
+
+
+@pytest.mark.parametrize("shape", [(640, 768, 768), (1152, 3072, 768), (1152, 768, 3072), (36, 2304, 768), (70, 200, 48)])
+@pytest.mark.parametrize("tile", [0, 1, 3, 5])
+def test_gemm_fp8_matches_dequantised_product(ops, shape, tile):
+    """xggm_gemm_fp8e4m3 against the fp32 product of the SAME e4m3 operands (what the matrix cores must compute:
+    exact products, fp32 accumulation) with scales, bias, GeLU and residual; every tile variant; ragged M / N.
+    Tolerance: bf16 rounding of the result plus fp32 accumulation-order noise."""
+    from xggm_amd import _lib
+    BF16 = torch.bfloat16
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.05
+    b = torch.randn(N, generator=g).to(DEV)
+    res = torch.randn(M, N, generator=g).to(BF16).to(DEV)
+    ax, aw = x.abs().max().reshape(1).to(DEV), w.abs().max().reshape(1).to(DEV)
+    qx, sx = ops.fp8_scale_for(ax)
+    qw, sw = ops.fp8_scale_for(aw)
+    x8, w8 = ops.quantize_fp8(x.to(BF16).to(DEV), qx), ops.quantize_fp8(w.to(DEV), qw)
+    _lib.lib.xggm_gemm_set_tile(tile)
+    try:
+        y, pre = ops.linear_fwd_fp8(x8, w8, sx, sw, bias=b, act=ops.ACT_GELU, want_preact=True, residual=res)
+        y32, _ = ops.linear_fwd_fp8(x8, w8, sx, sw, out_f32=True)
+    finally:
+        _lib.lib.xggm_gemm_set_tile(0)
+    prod = (x8.float().double() @ w8.float().double().t()) * float(sx) * float(sw)
+    assert rel_err(y32, prod) < 1e-4  # the fp8 MFMA sums each 32-term group before the fp32 accumulate
+    u = (prod + b.double()).float()
+    assert rel_err(pre, u) < 4e-3
+    ub = pre.float()  # the activation sees the stored pre-activation
+    want = torch.nn.functional.gelu(ub) + res.float()
+    assert rel_err(y, want) < 4e-3
+    # against the unquantised product: the e4m3 error itself (3 mantissa bits per operand, averaged over K)
+    full = x.to(BF16).double().to(DEV) @ w.double().to(DEV).t()
+    assert rel_err(y32, full) < 6e-2
+    for bad in (dict(K=K - 8),):
+        with pytest.raises(RuntimeError, match="multiples of 16"):
+            ops.call("xggm_gemm_fp8e4m3", ops.ptr(x8), ops.ptr(w8), ops.ptr(y), M, N, bad["K"], K, K, N, None, None, None,
+                     None, None, 0, 0, ops.stream())

@@ -107,3 +107,55 @@ extern "C" int xggm_zero_ranges_f32(float* base, const int64_t* offsets, const i
 
 EW_API(f32, float)
 EW_API(bf16, bf16)
+
+
+// ---- fp8 operands of the mixed-precision forward (BASELINE config C5): y = e4m3(clamp(x * qscale, +-448)),
+// OCP e4m3fn as gfx950's matrix cores read it, round-to-nearest-even (v_cvt_pk_fp8_f32).  Per-tensor scaling:
+// `qscale` is a device scalar (the GEMM multiplies by its reciprocal), `amax` (optional) collects max |x| for
+// the next step's scale ("delayed scaling": no extra pass over x).  8 elements per thread: one 16/32-byte load,
+// one 8-byte store.
+namespace {
+template <typename T>
+__global__ __launch_bounds__(NT) void quantize_fp8_kernel(const T* __restrict__ x, unsigned char* __restrict__ y, int64_t n,
+                                                          const float* __restrict__ qscale, float* amax) {
+    const float s = qscale ? *qscale : 1.0f;
+    float mx = 0.f;
+    const int64_t n8 = n >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n8; i += (int64_t)gridDim.x * NT) {
+        float lo[4], hi[4];
+        load4(x + 8 * i, lo);
+        load4(x + 8 * i + 4, hi);
+        const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        float q[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            mx = fmaxf(mx, fabsf(v[e]));
+            q[e] = fminf(fmaxf(v[e] * s, -448.f), 448.f);
+        }
+        int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], 0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w0, true);
+        int w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q[4], q[5], 0, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q[6], q[7], w1, true);
+        *reinterpret_cast<int2*>(y + 8 * i) = make_int2(w0, w1);
+    }
+    if (amax) {
+        mx = wave_max(mx);
+        // |x| >= 0: the IEEE bit pattern orders like the value
+        if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(reinterpret_cast<unsigned int*>(amax), __float_as_uint(mx));
+    }
+}
+}  // namespace
+
+#define QUANT_API(SUF, T)                                                                                               \
+    extern "C" int xggm_quantize_fp8e4m3_##SUF(const void* x, void* y, int64_t n, const float* qscale, float* amax,    \
+                                               hipStream_t st) {                                                        \
+        XGGM_REQUIRE(x && y && n > 0 && n % 8 == 0, "xggm_quantize_fp8e4m3: bad arguments (n = %lld must be a multiple of 8)", \
+                     (long long)n);                                                                                     \
+        XGGM_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 8 == 0,               \
+                     "xggm_quantize_fp8e4m3: misaligned pointers");                                                     \
+        hipLaunchKernelGGL((quantize_fp8_kernel<T>), dim3(grid1d(n / 8)), dim3(NT), 0, st, (const T*)x,                 \
+                           (unsigned char*)y, n, qscale, amax);                                                         \
+        return xggm_check_launch("xggm_quantize_fp8e4m3");                                                              \
+    }
+QUANT_API(f32, float)
+QUANT_API(bf16, bf16)

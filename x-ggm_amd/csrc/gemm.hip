@@ -291,15 +291,16 @@ __device__ __forceinline__ OpSrc make_src(const bf16* base, int64_t bytes, int64
     return s;
 }
 
-template <int R, bool KMAJ>
+template <int R, bool KMAJ, int ES = 2>  // ES: bytes per element (2 = bf16; 1 = fp8, k-major operands only)
 __device__ __forceinline__ void fast_load(short8_t (&reg)[R / 32], const OpSrc& src, int r0, int k0, int Rtot, int K, int tid) {
+    static_assert(ES == 2 || KMAJ, "fp8 operands are k-contiguous");
 #pragma unroll
     for (int i = 0; i < R / 32; ++i) {
         const int c = tid + NT * i;
         int off;
         if (KMAJ) {
-            const int row = min(r0 + (c >> 3), Rtot - 1), kc = k0 + (c & 7) * 8;
-            off = kc < K ? (row * src.rs + kc) * 2 : OOB_OFFSET;
+            const int row = min(r0 + (c >> 3), Rtot - 1), kc = k0 + (c & 7) * (16 / ES);
+            off = kc < K ? (row * src.rs + kc) * ES : OOB_OFFSET;
         } else {
             const int kl = k0 + c / (R / 8), rc = min(r0 + (c % (R / 8)) * 8, Rtot - 8);
             off = kl < K ? (kl * src.ks + rc) * 2 : OOB_OFFSET;
@@ -546,9 +547,15 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, const float4_
     }
 }
 
-template <int BM, int BN, bool AK, bool BKM, int D>
+// F8: both operands are OCP e4m3 bytes, k-contiguous.  A k-tile is then 128 elements -- the same 128 bytes per
+// row, so loads, LDS image, swizzle and fragment reads are the bf16 ones byte for byte; a lane's 16-byte fragment
+// feeds two v_mfma_f32_16x16x32_fp8_fp8 (8 bytes each).  Which 8 k-indices a lane supplies does not matter to a
+// reduction as long as A and B agree, and both go through the same mapping.
+template <int BM, int BN, bool AK, bool BKM, int D, bool F8 = false>
 __device__ __forceinline__ void gemm_kloop(const GemmArgs& g, int tile_m, int tile_n, int bz, bf16* fsm,
                                            float4_t (&acc)[BM / 32][BN / 32]) {
+    static_assert(!F8 || (AK && BKM), "fp8 operands are k-contiguous");
+    constexpr int ES = F8 ? 1 : 2, KT = 128 / ES;  // bytes per element, elements per k-tile
     // D = prefetch depth: D k-tiles of both operands are in flight in registers while one tile
     // is consumed from LDS.  These GEMMs are skinny (one k-chain per CU), so the k-loop would
     // otherwise run at one L2/HBM round trip per iteration.
@@ -563,12 +570,12 @@ __device__ __forceinline__ void gemm_kloop(const GemmArgs& g, int tile_m, int ti
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     STAMP(g, 0);
     STAMP_HW(g);
-    const bf16* A = reinterpret_cast<const bf16*>(g.A) + (int64_t)bz * g.a_bs;
-    const bf16* B = reinterpret_cast<const bf16*>(g.B) + (int64_t)bz * g.b_bs;
+    const bf16* A = reinterpret_cast<const bf16*>(reinterpret_cast<const char*>(g.A) + (int64_t)bz * g.a_bs * ES);
+    const bf16* B = reinterpret_cast<const bf16*>(reinterpret_cast<const char*>(g.B) + (int64_t)bz * g.b_bs * ES);
     // bytes from the (batch) base to the end of the operand: last row / k-row start + its valid length
-    const OpSrc sa = make_src(A, AK ? ((int64_t)(g.M - 1) * g.a_rs + (g.K + 7) / 8 * 8) * 2 : ((int64_t)(g.K - 1) * g.a_ks + g.a_rows) * 2,
+    const OpSrc sa = make_src(A, AK ? ((int64_t)(g.M - 1) * g.a_rs + (g.K + 7) / 8 * 8) * ES : ((int64_t)(g.K - 1) * g.a_ks + g.a_rows) * 2,
                               g.a_rs, g.a_ks);
-    const OpSrc sb = make_src(B, BKM ? ((int64_t)(g.N - 1) * g.b_ns + (g.K + 7) / 8 * 8) * 2 : ((int64_t)(g.K - 1) * g.b_ks + g.b_rows) * 2,
+    const OpSrc sb = make_src(B, BKM ? ((int64_t)(g.N - 1) * g.b_ns + (g.K + 7) / 8 * 8) * ES : ((int64_t)(g.K - 1) * g.b_ks + g.b_rows) * 2,
                               g.b_ns, g.b_ks);
 
 #pragma unroll
@@ -578,14 +585,14 @@ __device__ __forceinline__ void gemm_kloop(const GemmArgs& g, int tile_m, int ti
 
     short8_t ra[D][LA::NCH], rb[D][LB::NCH];
     // the k-loop runs a multiple of UNR tiles; tiles past K load zeros (see fast_load)
-    const int nk = ((g.K + 63) / 64 + UNR - 1) / UNR * UNR;
+    const int nk = ((g.K + KT - 1) / KT + UNR - 1) / UNR * UNR;
 #pragma unroll
     for (int s = 0; s < D; ++s) {
-        fast_load<BM, AK>(ra[s], sa, m0, s * 64, g.a_rows, g.K, tid);
-        fast_load<BN, BKM>(rb[s], sb, n0, s * 64, g.b_rows, g.K, tid);
+        fast_load<BM, AK, ES>(ra[s], sa, m0, s * KT, g.a_rows, g.K, tid);
+        fast_load<BN, BKM, ES>(rb[s], sb, n0, s * KT, g.b_rows, g.K, tid);
     }
-    fast_store<BM, AK>(fsm, ra[0], tid, 0, g.K, g.a_tail);
-    fast_store<BN, BKM>(fsm + LA::ELEMS, rb[0], tid, 0, g.K, g.b_tail);
+    fast_store<BM, AK>(fsm, ra[0], tid, 0, g.K, F8 ? 0 : g.a_tail);
+    fast_store<BN, BKM>(fsm + LA::ELEMS, rb[0], tid, 0, g.K, F8 ? 0 : g.b_tail);
     lds_barrier();
     STAMP(g, 1);
     for (int t0 = 0; t0 < nk; t0 += UNR) {
@@ -596,8 +603,8 @@ __device__ __forceinline__ void gemm_kloop(const GemmArgs& g, int tile_m, int ti
             const bf16* Bc = Ac + LA::ELEMS;
             bf16* An = fsm + ((u + 1) & 1) * STAGE;
             // stage (t % D) was copied to LDS one step ago: refill it with tile t + D
-            fast_load<BM, AK>(ra[u % D], sa, m0, (t + D) * 64, g.a_rows, g.K, tid);
-            fast_load<BN, BKM>(rb[u % D], sb, n0, (t + D) * 64, g.b_rows, g.K, tid);
+            fast_load<BM, AK, ES>(ra[u % D], sa, m0, (t + D) * KT, g.a_rows, g.K, tid);
+            fast_load<BN, BKM, ES>(rb[u % D], sb, n0, (t + D) * KT, g.b_rows, g.K, tid);
 #pragma unroll
             for (int ks = 0; ks < 64; ks += 32) {
                 bf16x8_t a[TM], b[TN];
@@ -611,10 +618,17 @@ __device__ __forceinline__ void gemm_kloop(const GemmArgs& g, int tile_m, int ti
                     for (int j = 0; j < TN; ++j)
                         // operands swapped: the 16x16 block comes out transposed, i.e. lane (fr, fq) holds
                         // row fr, columns 4 fq .. 4 fq + 3 -- four values that are contiguous in C
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+                        if constexpr (F8) {
+                            typedef long long2_t __attribute__((ext_vector_type(2)));
+                            const long2_t a8 = __builtin_bit_cast(long2_t, a[i]), b8 = __builtin_bit_cast(long2_t, b[j]);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(b8[0], a8[0], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(b8[1], a8[1], acc[i][j], 0, 0, 0);
+                        } else {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+                        }
             }
-            fast_store<BM, AK>(An, ra[(u + 1) % D], tid, (t + 1) * 64, g.K, g.a_tail);
-            fast_store<BN, BKM>(An + LA::ELEMS, rb[(u + 1) % D], tid, (t + 1) * 64, g.K, g.b_tail);
+            fast_store<BM, AK>(An, ra[(u + 1) % D], tid, (t + 1) * KT, g.K, F8 ? 0 : g.a_tail);
+            fast_store<BN, BKM>(An + LA::ELEMS, rb[(u + 1) % D], tid, (t + 1) * KT, g.K, F8 ? 0 : g.b_tail);
             lds_barrier();
         }
     }
@@ -673,6 +687,39 @@ __global__ __launch_bounds__(NT, (min_waves<BM, BN>())) void gemm_fast_kernel(Ge
         tile_n = nl % gridDim.x;
     }
     gemm_tile<BM, BN, AK, BKM, D>(g, tile_m, tile_n, blockIdx.z, fsm);
+}
+
+// ---- fp8 forward GEMM (BASELINE config C5: e4m3 operands for the QKV / FFN products, everything else bf16).
+// C = epilogue(sa * sb * sum_k A8(m,k) B8(n,k)): A8, B8 OCP e4m3 bytes, k-contiguous, quantised with per-tensor scales
+// whose reciprocals sa, sb are device scalars; accumulation in fp32 on the matrix cores, epilogue and output as
+// in the bf16 kernel.  Same tile pipeline with half the operand bytes per k (see gemm_kloop).
+template <int BM, int BN, int D>
+__global__ __launch_bounds__(NT, (min_waves<BM, BN>())) void gemm_fp8_kernel(GemmArgs g, const float* sa, const float* sb) {
+    extern __shared__ __attribute__((aligned(16))) bf16 fsm[];
+    const float s = (sa ? *sa : 1.f) * (sb ? *sb : 1.f);
+    int tile_m = blockIdx.y, tile_n = blockIdx.x;
+    if (g.xcd_swizzle) {
+        const int nl = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+        tile_m = nl / gridDim.x;
+        tile_n = nl % gridDim.x;
+    }
+    float4_t acc[BM / 32][BN / 32];
+    gemm_kloop<BM, BN, true, true, D, true>(g, tile_m, tile_n, 0, fsm, acc);
+    g.alpha *= s;
+    gemm_finish<BM, BN>(g, tile_m, tile_n, 0, fsm, acc);
+}
+
+template <int BM, int BN, int D> int launch_fp8_tile(const GemmArgs& g, const float* sa, const float* sb, hipStream_t stream) {
+    constexpr size_t lds = 2 * sizeof(bf16) * (OpLds<BM, true>::ELEMS + OpLds<BN, true>::ELEMS);
+    static bool attr_set = false;
+    if (lds > 48 * 1024 && !attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fp8_kernel<BM, BN, D>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_fp8_kernel<BM, BN, D>), dim3(ceil_div(g.N, BN), ceil_div(g.M, BM), 1), dim3(NT), lds, stream, g,
+                       sa, sb);
+    return xggm_check_launch("xggm_gemm_fp8e4m3");
 }
 
 // ---- grouped launch: up to 4 independent GEMMs (forward of both modalities, dgrad + wgrad of one
@@ -853,6 +900,36 @@ template <typename T> int launch(GemmArgs g, int batch, hipStream_t stream) {
 
 XGGM_GEMM_IMPL(xggm_gemm_f32, float)
 XGGM_GEMM_IMPL(xggm_gemm_bf16, bf16)
+
+extern "C" int xggm_gemm_fp8e4m3(const void* A, const void* B, void* C, int M, int N, int K, int64_t a_rs, int64_t b_ns,
+                                 int64_t ldc, const float* scale_a, const float* scale_b, const float* bias,
+                                 const void* residual, void* preact, int act, int c_f32, hipStream_t stream) {
+    XGGM_REQUIRE(M > 0 && N > 0 && K > 0, "xggm_gemm_fp8e4m3: empty problem M=%d N=%d K=%d", M, N, K);
+    XGGM_REQUIRE(A && B && C, "xggm_gemm_fp8e4m3: null operand");
+    XGGM_REQUIRE(K % 16 == 0 && a_rs % 16 == 0 && b_ns % 16 == 0 && a_rs >= K && b_ns >= K,
+                 "xggm_gemm_fp8e4m3: K and the row strides must be multiples of 16 (K=%d, strides %lld, %lld)", K,
+                 (long long)a_rs, (long long)b_ns);
+    XGGM_REQUIRE(reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(B) % 16 == 0,
+                 "xggm_gemm_fp8e4m3: operands must be 16-byte aligned");
+    XGGM_REQUIRE(act >= 0 && act < XGGM_ACT_GELU_GRAD, "xggm_gemm_fp8e4m3: bad activation %d", act);
+    XGGM_REQUIRE(ldc >= N, "xggm_gemm_fp8e4m3: ldc %lld < N %d", (long long)ldc, N);
+    XGGM_REQUIRE((int64_t)(M - 1) * a_rs + K < OOB_OFFSET && (int64_t)(N - 1) * b_ns + K < OOB_OFFSET,
+                 "xggm_gemm_fp8e4m3: operand larger than 2 GiB");
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K;
+    g.a_rs = a_rs; g.a_ks = 1; g.b_ns = b_ns; g.b_ks = 1; g.ldc = ldc;
+    g.a_bs = g.b_bs = g.c_bs = 0;
+    g.bias = bias; g.residual = residual; g.preact = preact; g.aux = nullptr; g.colsum = nullptr;
+    g.act = act; g.c_f32 = c_f32; g.accumulate = 0; g.alpha = 1.0f;
+    g.a_mode = g.b_mode = 1; g.a_tail = g.b_tail = 0; g.a_rows = M; g.b_rows = N;
+    g.xcd_swizzle = g_xcd_swizzle; g.batch = 1; SET_STAMP(g);
+    switch (g_tile_override) {  // same pins as the bf16 kernels (xggm_gemm_set_tile); default 64 x 64, depth 4
+        case 3: return launch_fp8_tile<128, 64, 2>(g, scale_a, scale_b, stream);
+        case 5: return launch_fp8_tile<128, 128, 2>(g, scale_a, scale_b, stream);
+        case 1: return launch_fp8_tile<64, 64, 2>(g, scale_a, scale_b, stream);
+        default: return launch_fp8_tile<64, 64, 4>(g, scale_a, scale_b, stream);
+    }
+}
 
 // test/diagnostic hook: route bf16 GEMMs through the generic kernel (1) or the tuned one (0)
 extern "C" int xggm_gemm_set_generic(int on) {

@@ -72,6 +72,45 @@ def linear_fwd(x, w, bias=None, act=ACT_NONE, want_preact=False, out_f32=False, 
     return y, pre
 
 
+# ----------------------------------------------------------------------------- fp8 forward (config C5)
+FP8 = torch.float8_e4m3fn
+FP8_MAX = 448.0
+
+
+def quantize_fp8(x, qscale=None, amax=None):
+    """x (fp32 / bf16, contiguous, numel % 8 == 0) -> e4m3fn(clamp(x * qscale, +-448)); ``qscale``: 1-element fp32
+    device tensor or None (1); ``amax``: 1-element fp32 device tensor raised to max |x|, or None."""
+    _c(x)
+    if x.dtype not in (F32, BF16):
+        raise RuntimeError("quantize_fp8: fp32 or bf16 input expected, got %s" % x.dtype)
+    y = torch.empty(x.shape, device=x.device, dtype=FP8)
+    call("xggm_quantize_fp8e4m3_" + sfx(x.dtype), ptr(x), ptr(y), x.numel(), ptr(qscale), ptr(amax), stream())
+    return y
+
+
+def fp8_scale_for(amax):
+    """(quantisation scale, its reciprocal) of a tensor whose max |x| is ``amax`` (1-element fp32 device tensor):
+    amax lands on the largest e4m3 value; an all-zero tensor gets scale 1."""
+    q = torch.where(amax > 0, FP8_MAX / amax, torch.ones_like(amax))
+    return q, 1.0 / q
+
+
+def linear_fwd_fp8(x8, w8, sx, sw, bias=None, act=ACT_NONE, want_preact=False, out_f32=False, residual=None):
+    """y[M,N] = act(sx * sw * (x8[M,K] @ w8[N,K]^T) + bias) (+ residual) with e4m3 operands; bf16 (or fp32) result.
+    ``sx`` / ``sw``: 1-element fp32 device tensors, the reciprocals of the operands' quantisation scales."""
+    M, K, a_rs = _rows(x8)
+    N, K2 = w8.shape
+    if x8.dtype != FP8 or w8.dtype != FP8 or K2 != K or w8.stride(1) != 1:
+        raise RuntimeError("linear_fwd_fp8: e4m3 operands [M,K] / [N,K] expected")
+    y = torch.empty((M, N), device=x8.device, dtype=F32 if out_f32 else BF16)
+    pre = torch.empty((M, N), device=x8.device, dtype=BF16) if want_preact else None
+    if residual is not None:
+        assert residual.shape == y.shape and residual.dtype == BF16 and residual.is_contiguous()
+    call("xggm_gemm_fp8e4m3", ptr(x8), ptr(w8), ptr(y), M, N, K, a_rs, w8.stride(0), N, ptr(sx), ptr(sw), ptr(bias),
+         ptr(residual), ptr(pre), act, int(out_f32), stream())
+    return y, pre
+
+
 def linear_dgrad(dy, w, residual=None, gelu_aux=None):
     """dx[M,K] = dy[M,N] @ w[N,K] (+ residual), optionally times gelu'(aux) (aux, dx same shape)."""
     M, N, a_rs = _rows(_chk(dy))
