@@ -597,3 +597,65 @@ def test_dropout_training_mode_runs_and_is_reproducible():
     assert np.allclose(runs[0][:2], runs[1][:2], rtol=1e-6)
     assert np.allclose(runs[0], runs[1], rtol=2e-3)
     assert not np.allclose(runs[0], runs[2], rtol=3e-3)
+
+
+def test_training_state_resume_continues_the_same_trajectory(tmp_path):
+    """save_training_state / load_training_state: three iterations with dropout on, against one iteration + snapshot
+    + a FRESH model and optimiser (other weights, other dropout seed) restored from it + two more iterations.
+    Weights, BertAdam moments (reference layout: step / next_m / next_v per parameter), step counters and the Philox
+    state all have to come back for the trajectories to coincide; a resume that drops the optimiser state (what the
+    reference's VQA.save/load does, src/vqa/vqacpv2.py:361-368) visibly does not.  Tolerances as in the dropout
+    reproducibility test (fp32 atomics in the bias gradients make the last bits run-dependent)."""
+    import random
+    from oracle import shapes
+    from xggm_amd.vqa.vqacpv2 import (train_iteration, BCEWithLogitsLoss, make_optimizer, save_training_state,
+                                      load_training_state)
+    cfg, A, B = shapes.TINY, 29, 4
+    bn = synth.vqa_batch(B, A=A, F=cfg["feat_dim"], vocab=cfg["vocab"], seed=3)
+    b = batch_tensors(bn, DEV)
+    b["sent"] = (b["input_ids"], b["input_mask"], b["segment_ids"])
+    branches = ["rel", "node", "rel"]
+
+    def fresh(seed_w, seed_rt):
+        m = build_model(cfg, A, seed=seed_w, dt=BF16)
+        m.seed = seed_rt
+        return m, make_optimizer(m, 2e-3, 12)
+
+    def run(m, opt, its):
+        out = []
+        for br in its:
+            o = train_iteration(m, opt, BCEWithLogitsLoss(), b, branch=br)
+            out += [float(o["loss_plain"]), float(o["loss_ggm"])]
+        return out
+
+    m, opt = fresh(5, 11)
+    straight = run(m, opt, branches)
+    want = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+
+    m1, opt1 = fresh(5, 11)
+    first = run(m1, opt1, branches[:1])
+    random.seed(1234)
+    token = random.random()
+    random.seed(1234)
+    path = str(tmp_path / "state.pth")
+    save_training_state(path, m1, opt1, epoch=2, iteration=1)
+    osd = opt1.state_dict()
+    n_params = sum(len(pg["params"]) for pg in osd["param_groups"])
+    assert len(osd["state"]) == n_params and set(osd["state"][0]) == {"step", "next_m", "next_v"}
+    assert osd["state"][0]["step"] == 2 and float(osd["state"][0]["next_v"].abs().sum()) > 0
+
+    m2, opt2 = fresh(77, 99)  # nothing in common with the run that was saved
+    extra = load_training_state(path, m2, opt2)
+    assert extra == {"epoch": 2, "iteration": 1} and random.random() == token
+    resumed = first + run(m2, opt2, branches[1:])
+    assert np.allclose(resumed[:4], straight[:4], rtol=1e-5) and np.allclose(resumed, straight, rtol=2e-3)
+    got = {k: v.detach().float().cpu() for k, v in m2.state_dict().items()}
+    worst = max(rel_err(got[k], want[k]) for k in want)
+    assert worst < 2e-3, worst
+    assert opt2.state_dict()["state"][0]["step"] == 6
+
+    # the reference's kind of resume: weights only, optimiser from scratch -> another trajectory
+    m3, opt3 = fresh(77, 99)
+    m3.load_state_dict(torch.load(path, map_location="cpu", weights_only=True)["model"])
+    cold = first + run(m3, opt3, branches[1:])
+    assert not np.allclose(cold, straight, rtol=2e-3)

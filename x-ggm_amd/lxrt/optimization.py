@@ -92,6 +92,65 @@ class BertAdam(Optimizer):
                         weight_decay=weight_decay, max_grad_norm=max_grad_norm)
         super().__init__(params, defaults)
 
+    # ---- checkpointing: the reference layout (src/lxrt/optimization.py:147-155 keeps per-parameter
+    # state['step'], state['next_m'], state['next_v']), read from / written into the flat arena
+    def _arena(self):
+        arena = _arena_of_params(p for pg in self.param_groups for p in pg['params'])
+        pending = getattr(self, "_pending_state", None)
+        if arena is not None and pending is not None:
+            self._pending_state = None
+            self._state_into_arena(arena, pending)
+        return arena
+
+    def state_dict(self):
+        sd = super().state_dict()
+        arena = self._arena()
+        if arena is None:
+            if getattr(self, "_pending_state", None) is not None:
+                sd['state'] = self._pending_state
+            return sd
+        steps = arena.steps.tolist()
+        state, idx = {}, 0
+        for pg in self.param_groups:
+            for p in pg['params']:
+                xg = getattr(p, "_xg", None)
+                if xg is not None and xg[0] is arena:
+                    _, o, k, gname = xg[:4]
+                    state[idx] = {'step': steps[arena.group_index[gname]],
+                                  'next_m': arena.m[o:o + k].view(p.shape).clone(),
+                                  'next_v': arena.v[o:o + k].view(p.shape).clone()}
+                idx += 1
+        sd['state'] = state
+        return sd
+
+    def load_state_dict(self, state_dict):
+        """hyper-parameters through torch's loader, moments and step counters IN PLACE into the arena (captured
+        graphs keep pointing at the same buffers).  Before the arena exists (no forward yet) the state is kept and
+        applied at the first use."""
+        super().load_state_dict({'state': {}, 'param_groups': state_dict['param_groups']})
+        self._pending_state = dict(state_dict.get('state', {}))
+        self._arena()
+
+    @torch.no_grad()
+    def _state_into_arena(self, arena, state):
+        step_of, idx = {}, 0
+        for pg in self.param_groups:
+            for p in pg['params']:
+                st = state.get(idx, state.get(str(idx)))
+                idx += 1
+                xg = getattr(p, "_xg", None)
+                if st is None or xg is None or xg[0] is not arena:
+                    continue
+                _, o, k, gname = xg[:4]
+                arena.m[o:o + k].view(p.shape).copy_(st['next_m'])
+                arena.v[o:o + k].view(p.shape).copy_(st['next_v'])
+                if step_of.setdefault(gname, int(st['step'])) != int(st['step']):
+                    raise ValueError("BertAdam.load_state_dict: parameters of arena group '%s' carry different step "
+                                     "counts (%d, %d); they always step together here" % (gname, step_of[gname],
+                                                                                          int(st['step'])))
+        for gname, s in step_of.items():
+            arena.steps[arena.group_index[gname]] = s
+
     def _hyper_of_group(self, arena, gname):
         """the optimiser param_group that holds (all) parameters of arena group ``gname``."""
         first = arena.groups[gname].params[0]
@@ -101,7 +160,7 @@ class BertAdam(Optimizer):
         return None
 
     def get_lr(self):
-        arena = _arena_of_params(p for pg in self.param_groups for p in pg['params'])
+        arena = self._arena()
         if arena is None:
             return [0]
         steps = arena.steps.tolist()
@@ -120,14 +179,14 @@ class BertAdam(Optimizer):
 
     def zero_grad(self, set_to_none=True):
         super().zero_grad(set_to_none=True)
-        arena = _arena_of_params(p for pg in self.param_groups for p in pg['params'])
+        arena = self._arena()
         if arena is not None:
             arena.begin_pass()
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
-        arena = _arena_of_params(p for pg in self.param_groups for p in pg['params'])
+        arena = self._arena()
         if arena is None:
             raise RuntimeError("BertAdam.step: parameters are not arena-managed; run a forward/backward first")
         sq = arena.sqnorm if arena.pending_clip is not None else None

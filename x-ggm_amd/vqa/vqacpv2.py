@@ -212,3 +212,24 @@ def predict(model, eval_tuple, dump=None, predictor=None):
 def evaluate(model, eval_tuple, dump=None, predictor=None):
     """``VQA.evaluate`` (src/vqa/vqacpv2.py:341-344)"""
     return eval_tuple[2].evaluate(predict(model, eval_tuple, dump, predictor))
+
+
+def save_training_state(path, model, optim, **extra):
+    """everything an exact resume needs, which ``VQA.save`` (src/vqa/vqacpv2.py:361-363, model weights only) leaves
+    out: BertAdam moments and step counters (reference state layout), the dropout / noise Philox state, the host
+    branch-choice generator, and whatever the caller adds (epoch, iteration, best score)."""
+    rt = runtime_of(model)
+    torch.save({"model": model.state_dict(), "optimizer": optim.state_dict(), "rng": rt.rng.cpu(),
+                "python_random": random.getstate(), "extra": extra}, path)
+
+
+def load_training_state(path, model, optim):
+    """restores what ``save_training_state`` wrote, in place (captured graphs stay valid); returns ``extra``"""
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    model.load_state_dict(ck["model"])
+    rt = runtime_of(model)  # creates the arena if this model has not run yet, refreshes the bf16 shadows
+    optim.load_state_dict(ck["optimizer"])
+    rt.rng.copy_(ck["rng"])
+    st = ck["python_random"]
+    random.setstate((st[0], tuple(st[1]), st[2]))
+    return ck["extra"]
