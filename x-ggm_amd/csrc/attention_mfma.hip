@@ -16,7 +16,7 @@ namespace {
 constexpr int NT = 512;  // 8 waves (measured: 256 threads 1.97 ms, 512 1.46 ms, 1024 1.77 ms for the backward launches of three passes): every phase (tile products, row softmax, gradient tiles) is spread over twice the waves
 constexpr int TILE_IT = NT >= 512 ? 1 : 512 / NT;  // 16-byte chunks per thread of a 64 x 64 bf16 tile
 constexpr int D = 64;
-constexpr int LDT = D + 16;  // tile row stride in elements (160 B): tr-reads conflict-free, b128 rows 16-B aligned
+constexpr int LDT = D + 16;  // tile row stride in elements (160 B): b128 rows 16-B aligned; tr-reads of k-rows 8 apart share banks (2-way; the GEMM swaps half-blocks against this, see gemm.hip fast_frag -- here the phases are barrier-latency-bound)
 
 typedef __attribute__((ext_vector_type(8))) short short8_t;
 typedef __attribute__((ext_vector_type(4))) short short4_t;
