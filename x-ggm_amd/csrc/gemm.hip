@@ -673,11 +673,44 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int tile_m, int til
 
 
 // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its own
-// 4 MiB L2.  Give every XCD a CONTIGUOUS run of tiles (row-major), so tiles sharing an A row-panel
-// run on one L2 instead of pulling every panel into all eight.  Placement changes speed only.
+// 4 MiB L2.  Give every XCD a CONTIGUOUS run of positions (xcd_remap) and read a position as a tile
+// of one rectangle of the grid (tile_of_position), so tiles sharing operand panels run on one L2
+// instead of pulling every panel into all eight.  Placement changes speed and traffic only.
 __device__ __forceinline__ int xcd_remap(int L, int nb) {
     const int q = nb >> 3, r = nb & 7, xcd = L & 7, idx = L >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// The same idea in two dimensions.  An XCD that owns a run of whole tile rows pulls every B panel into its L2
+// (8 copies of B across the chip); an xr x xc arrangement of the XCDs over the tile grid fetches A xc times and
+// B xr times instead.  Position p of the XCD-contiguous order (xcd_remap) is read rectangle-major: bands of rh
+// tile rows, inside a band column groups of rw tiles, inside a group row-major -- a run of ~n/8 positions is
+// (about) one rh x rw rectangle; ragged edges only make the last band / group smaller.  Everything here is
+// wave-uniform (scalar unit); band and group are found by comparison (at most 8 each), leaving one division.
+__device__ __forceinline__ void tile_of_position(int p, int gx, int gy, int M, int N, int& tile_m, int& tile_n) {
+    // minimise xc * |A| + xr * |B| ~ xc * M + xr * N over xr * xc = 8
+    int xr = 1;
+    long best = 8l * M + N;
+#pragma unroll
+    for (int r = 2; r <= 8; r *= 2) {
+        const long c = (long)(8 / r) * M + (long)r * N;
+        if (c < best) { best = c; xr = r; }
+    }
+    const int xc = 8 / xr;
+    const int rh = (gy + xr - 1) / xr, rw = (gx + xc - 1) / xc;  // divisions by 1, 2, 4, 8: shifts
+    int band = 0, q = p;
+#pragma unroll
+    for (int b = 1; b < 8; ++b)
+        if (b < xr && p >= b * rh * gx) { band = b; q = p - b * rh * gx; }
+    const int hb = min(rh, gy - band * rh);
+    int cg = 0, r = q;
+#pragma unroll
+    for (int c = 1; c < 8; ++c)
+        if (c < xc && q >= c * rw * hb) { cg = c; r = q - c * rw * hb; }
+    const int wb = min(rw, gx - cg * rw);
+    const int dr = r / wb;
+    tile_m = band * rh + dr;
+    tile_n = cg * rw + (r - dr * wb);
 }
 
 // waves per SIMD the register allocation must leave room for: a second (third, fourth) resident
@@ -688,11 +721,9 @@ template <int BM, int BN, bool AK, bool BKM, int D>
 __global__ __launch_bounds__(NT, (min_waves<BM, BN>())) void gemm_fast_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) bf16 fsm[];
     int tile_m = blockIdx.y, tile_n = blockIdx.x;
-    if (g.xcd_swizzle) {
-        const int nl = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-        tile_m = nl / gridDim.x;
-        tile_n = nl % gridDim.x;
-    }
+    if (g.xcd_swizzle)
+        tile_of_position(xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y), gridDim.x, gridDim.y, g.M,
+                         g.N, tile_m, tile_n);
     gemm_tile<BM, BN, AK, BKM, D>(g, tile_m, tile_n, blockIdx.z, fsm);
 }
 
@@ -705,11 +736,9 @@ __global__ __launch_bounds__(NT, (min_waves<BM, BN>())) void gemm_fp8_kernel(Gem
     extern __shared__ __attribute__((aligned(16))) bf16 fsm[];
     const float s = (sa ? *sa : 1.f) * (sb ? *sb : 1.f);
     int tile_m = blockIdx.y, tile_n = blockIdx.x;
-    if (g.xcd_swizzle) {
-        const int nl = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-        tile_m = nl / gridDim.x;
-        tile_n = nl % gridDim.x;
-    }
+    if (g.xcd_swizzle)
+        tile_of_position(xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y), gridDim.x, gridDim.y, g.M,
+                         g.N, tile_m, tile_n);
     float4_t acc[BM / 32][BN / 32];
     gemm_kloop<BM, BN, true, true, D, true>(g, tile_m, tile_n, 0, fsm, acc);
     g.alpha *= s;
@@ -744,9 +773,11 @@ template <int BM, int BN> __global__ __launch_bounds__(NT, (min_waves<BM, BN>())
     extern __shared__ __attribute__((aligned(16))) bf16 fsm[];
     // Which problem, and which tile of it.  Inside each problem the tiles get the XCD-aware order:
     // blocks are dealt to XCDs by id % 8, so the problem's blocks of one residue class take one
-    // contiguous row-major run of its tiles (shared A row-panels stay in one L2), while every XCD
-    // still receives 1/8 of EVERY problem (a remap over the whole grid would hand whole problems,
-    // with different k-loop lengths, to different XCDs).  Same-box A/B: -0.04 ms per iteration.
+    // contiguous run of positions = one rectangle of its tile grid (tile_of_position), while every
+    // XCD still receives 1/8 of EVERY problem (a remap over the whole grid would hand whole
+    // problems, with different k-loop lengths, to different XCDs).  L2-miss reads per launch
+    // (rocprofv3 FETCH_SIZE): natural order 76.6 MB, row-major runs 90.7 MB, rectangles 64.9 MB
+    // for the 128x64 kernel (43.8 / 45.5 / 33.3 MB for 64x64); step time equal within noise.
     const int b = blockIdx.x;
     int i = 0, t0 = 0, t1 = ga.tile_start[1];
 #pragma unroll
@@ -755,7 +786,15 @@ template <int BM, int BN> __global__ __launch_bounds__(NT, (min_waves<BM, BN>())
     const GemmArgs g = ga.p[i];
     const int local = g.xcd_swizzle ? xcd_remap(b - t0, t1 - t0) : b - t0;
     const int gx = (g.N + BN - 1) / BN, gy = (g.M + BM - 1) / BM;
-    const int tile_n = local % gx, tile_m = (local / gx) % gy, bz = local / (gx * gy);
+    const int bz = g.batch == 1 ? 0 : local / (gx * gy);
+    const int lt = local - bz * gx * gy;
+    int tile_m, tile_n;
+    if (g.xcd_swizzle) {
+        tile_of_position(lt, gx, gy, g.M, g.N, tile_m, tile_n);
+    } else {
+        tile_m = lt / gx;
+        tile_n = lt - tile_m * gx;
+    }
     constexpr int DK = (BM * BN <= 64 * 64) ? 4 : 2;  // prefetch depth when an operand is k-major
     float4_t acc[BM / 32][BN / 32];
     if (g.a_mode == 1) {
