@@ -388,6 +388,10 @@ int xggm_bertadam_f32(float* p, const float* g, float* m, float* v, void* shadow
                       xggm_stream_t stream);
 /* *lr_scale = warmup_linear(*step / t_total, warmup); *step += 1 (optimization.py:42-48) */
 int xggm_sched_step(int64_t* step, float* lr_scale, int64_t t_total, float warmup, xggm_stream_t stream);
+/* the same for n <= 16 distinct counters steps[index[i]] / lr_scale[index[i]] of one table in one launch (all
+ * parameter groups of one optimiser step); index, t_total, warmup: HOST arrays of n entries */
+int xggm_sched_step_multi(int64_t* steps, float* lr_scale, const int* index, const int64_t* t_total, const float* warmup,
+                          int n, xggm_stream_t stream);
 
 /* zero up to 16 element ranges [offset[i], offset[i] + length[i]) of one fp32 buffer in ONE launch: the
  * atomically accumulated gradient ranges of all parameter groups at the start of a backward pass.

@@ -285,6 +285,28 @@ __global__ void sched_kernel(int64_t* step, float* lr_scale, int64_t t_total, fl
     *step = s + 1;
 }
 
+// the same for several counters of one table in ONE launch (all parameter groups of an optimiser step)
+constexpr int MAX_SCHED = 16;
+struct SchedArgs {
+    int index[MAX_SCHED];
+    int64_t t_total[MAX_SCHED];
+    float warmup[MAX_SCHED];
+    int n;
+};
+__global__ void sched_multi_kernel(int64_t* steps, float* lr_scale, SchedArgs a) {
+    const int i = threadIdx.x;
+    if (blockIdx.x != 0 || i >= a.n) return;
+    const int k = a.index[i];
+    const int64_t s = steps[k];
+    float sc = 1.f;
+    if (a.t_total[i] > 0) {
+        const float x = (float)((double)s / (double)a.t_total[i]);
+        sc = x < a.warmup[i] ? x / a.warmup[i] : fmaxf((x - 1.f) / (a.warmup[i] - 1.f), 0.f);
+    }
+    lr_scale[k] = sc;
+    steps[k] = s + 1;
+}
+
 __global__ void rng_advance_kernel(uint64_t* rng, uint64_t by) {
     if (threadIdx.x == 0 && blockIdx.x == 0) rng[1] += by;
 }
@@ -390,6 +412,23 @@ extern "C" int xggm_sched_step(int64_t* step, float* lr_scale, int64_t t_total, 
     XGGM_REQUIRE(step && lr_scale, "xggm_sched_step: null pointer");
     hipLaunchKernelGGL(sched_kernel, dim3(1), dim3(64), 0, st, step, lr_scale, t_total, warmup);
     return xggm_check_launch("xggm_sched_step");
+}
+
+extern "C" int xggm_sched_step_multi(int64_t* steps, float* lr_scale, const int* index, const int64_t* t_total,
+                                     const float* warmup, int n, hipStream_t st) {
+    XGGM_REQUIRE(steps && lr_scale && index && t_total && warmup && n > 0 && n <= MAX_SCHED,
+                 "xggm_sched_step_multi: bad arguments (n = %d, at most %d counters per call)", n, MAX_SCHED);
+    SchedArgs a;
+    a.n = n;
+    for (int i = 0; i < n; ++i) {
+        XGGM_REQUIRE(index[i] >= 0, "xggm_sched_step_multi: negative index");
+        for (int j = 0; j < i; ++j) XGGM_REQUIRE(index[j] != index[i], "xggm_sched_step_multi: counter %d listed twice", index[i]);
+        a.index[i] = index[i];
+        a.t_total[i] = t_total[i];
+        a.warmup[i] = warmup[i];
+    }
+    hipLaunchKernelGGL(sched_multi_kernel, dim3(1), dim3(64), 0, st, steps, lr_scale, a);
+    return xggm_check_launch("xggm_sched_step_multi");
 }
 
 extern "C" int xggm_rng_advance(uint64_t* rng, uint64_t by, hipStream_t st) {

@@ -718,48 +718,48 @@ class DSMFn(Function):
     """loss_func (src/vqa/vqacpv2.py:48-51)."""
 
     @staticmethod
-    def forward(ctx, score, g, sigma):
+    def forward(ctx, score, g, sigma, scale=1.0):
         score = score.contiguous()
-        coef = 0.5 * sigma ** 2 / score.numel()  # 0.5 s^2 / (d1 d2) * mean over the batch
+        coef = scale * 0.5 * sigma ** 2 / score.numel()  # 0.5 s^2 / (d1 d2) * mean over the batch
         ctx.saved = (score, g, coef)
         return ops.dsm_fwd(score, g.contiguous(), coef)
 
     @staticmethod
     def backward(ctx, gout):
         score, g, coef = ctx.saved
-        return ops.dsm_bwd(score, g, gout.contiguous(), coef), None, None
+        return ops.dsm_bwd(score, g, gout.contiguous(), coef), None, None, None
 
 
 class SymKLFn(Function):
     """compute_kl_loss (src/vqa/vqacpv2.py:54-61)."""
 
     @staticmethod
-    def forward(ctx, x, y):
+    def forward(ctx, x, y, scale=1.0):
         x, y = x.contiguous(), y.contiguous()
-        coef = 1.0 / x.numel()
+        coef = scale / x.numel()
         ctx.saved = (x, y, coef)
         return ops.symkl_fwd(x, y, coef)
 
     @staticmethod
     def backward(ctx, gout):
         x, y, coef = ctx.saved
-        return ops.symkl_bwd(x, y, gout.contiguous(), coef, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return ops.symkl_bwd(x, y, gout.contiguous(), coef, ctx.needs_input_grad[0], ctx.needs_input_grad[1]) + (None,)
 
 
 class BCEFn(Function):
     """nn.BCEWithLogitsLoss()(logit, target) (mean).  fp32 logits."""
 
     @staticmethod
-    def forward(ctx, logit, target):
+    def forward(ctx, logit, target, scale=1.0):
         logit, target = logit.contiguous(), target.contiguous()
-        coef = 1.0 / logit.numel()
+        coef = scale / logit.numel()
         ctx.saved = (logit, target, coef)
         return ops.bce_fwd(logit, target, coef)
 
     @staticmethod
     def backward(ctx, gout):
         logit, target, coef = ctx.saved
-        return ops.bce_bwd(logit, target, gout.contiguous(), coef, F32), None
+        return ops.bce_bwd(logit, target, gout.contiguous(), coef, F32), None, None
 
 
 class GATFn(Function):

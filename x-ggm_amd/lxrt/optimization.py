@@ -191,6 +191,7 @@ class BertAdam(Optimizer):
             raise RuntimeError("BertAdam.step: parameters are not arena-managed; run a forward/backward first")
         sq = arena.sqnorm if arena.pending_clip is not None else None
         max_norm = arena.pending_clip if arena.pending_clip is not None else 0.0
+        todo = []
         for g in arena.active_groups():
             G = arena.groups[g]
             pg = self._hyper_of_group(arena, g)
@@ -198,9 +199,11 @@ class BertAdam(Optimizer):
                 continue  # parameters not handed to this optimiser
             if any(p.grad is None for p in G.params):
                 raise RuntimeError("arena group '%s' received gradients for only part of its parameters" % g)
-            gi = arena.group_index[g]
-            step_t, scale_t = arena.steps[gi:gi + 1], arena.lr_scale[gi:gi + 1]
-            ops.sched_step(step_t, scale_t, pg['t_total'], pg['warmup'])
+            todo.append((G, pg, arena.group_index[g]))
+        if todo:  # schedule values and step counters of all groups: one launch
+            ops.sched_step_multi(arena.steps, arena.lr_scale, [(gi, pg['t_total'], pg['warmup']) for _, pg, gi in todo])
+        for G, pg, gi in todo:
+            scale_t = arena.lr_scale[gi:gi + 1]
             sl = slice(G.start, G.end)
             ops.bertadam(arena.params[sl], arena.grads[sl], arena.m[sl], arena.v[sl],
                          None if arena.shadow is None else arena.shadow[sl], sq, max_norm, pg['lr'], scale_t,

@@ -746,6 +746,19 @@ def sched_step(step, lr_scale, t_total, warmup):
     call("xggm_sched_step", ptr(step), ptr(lr_scale), int(t_total), float(warmup), stream())
 
 
+def sched_step_multi(steps, lr_scale, entries):
+    """``entries``: [(index, t_total, warmup)] -- one launch for all of them (groups of 16)."""
+    _c(steps, torch.int64), _c(lr_scale, F32)
+    for i in range(0, len(entries), 16):
+        ch = entries[i:i + 16]
+        n = len(ch)
+        idx = (_ct.c_int * n)(*[int(e[0]) for e in ch])
+        tt = (_ct.c_int64 * n)(*[int(e[1]) for e in ch])
+        wu = (_ct.c_float * n)(*[float(e[2]) for e in ch])
+        call("xggm_sched_step_multi", ptr(steps), ptr(lr_scale), _ct.cast(idx, _ct.c_void_p), _ct.cast(tt, _ct.c_void_p),
+             _ct.cast(wu, _ct.c_void_p), n, stream())
+
+
 def rng_advance(rng, by=1):
     call("xggm_rng_advance", ptr(rng), int(by), stream())
 

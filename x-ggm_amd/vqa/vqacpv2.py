@@ -16,24 +16,41 @@ from ..lxrt.optimization import clip_grad_norm_
 from ..runtime import runtime_of
 
 
-def loss_func(score, grad_log_q_noise, sigma=0.2):
+# ``scale`` (not in the reference signatures, default 1): a constant factor folded into the loss kernel and its
+# backward.  The training passes use it for the loss weights (x num_answers, x 6 (8 KL + DSM), ...): every
+# ``scalar * loss`` written in torch is a kernel of its own in forward and another one in backward, ~5 us each for
+# one float.
+def loss_func(score, grad_log_q_noise, sigma=0.2, scale=1.0):
     """0.5 sigma^2 mean_b sum_ij (score - g)^2 / (d1 d2).  ref: src/vqa/vqacpv2.py:48-51"""
-    return XF.DSMFn.apply(score, grad_log_q_noise, sigma)
+    return XF.DSMFn.apply(score, grad_log_q_noise, sigma, scale)
 
 
-def compute_kl_loss(x, y):
+def compute_kl_loss(x, y, scale=1.0):
     """symmetric KL of the last-dim softmaxes, mean over all elements.
     ref: src/vqa/vqacpv2.py:54-61"""
     if x.dtype != y.dtype:
         x, y = x.float(), y.float()
-    return XF.SymKLFn.apply(x, y)
+    return XF.SymKLFn.apply(x, y, scale)
 
 
 class BCEWithLogitsLoss(nn.Module):
     """nn.BCEWithLogitsLoss() of src/vqa/vqacpv2.py:131 on fp32 logits."""
 
-    def forward(self, logit, target):
-        return XF.BCEFn.apply(logit.float(), target.float())
+    def forward(self, logit, target, scale=1.0):
+        return XF.BCEFn.apply(logit.float(), target.float(), scale)
+
+
+class _Scaled:
+    """a loss term that was computed with its weight folded in; ``float()`` gives the unweighted value"""
+
+    def __init__(self, t, c):
+        self.t, self.c = t.detach(), float(c)
+
+    def __float__(self):
+        return float(self.t) / self.c
+
+    def detach(self):
+        return self
 
 
 def remove_diagonal(adj_true):
@@ -71,7 +88,7 @@ def forward_backward_plain(model, bce_loss, feats, boxes, sent, target, between=
     model.zero_grad()
     _, _, x = model(feats, boxes, sent)
     logit = model.logit_fc(x)
-    loss = bce_loss(logit, target) * target.size(1)
+    loss = bce_loss(logit, target, scale=target.size(1))
     runtime_of(model).backward(loss, between)
     return loss.detach(), logit.detach()
 
@@ -91,27 +108,27 @@ def forward_backward_ggm(model, bce_loss, feats, boxes, sent, target, adj_true, 
         e = model.encoder_adj(x)
         adj_noise, grad_log_noise = XF.AdjInitFn.apply(e, N, sigma, randn, None if randn is not None else rt.rng, 9001)
         node_feats, adj_noise = model.generator(feat_seq[1], adj_noise)
-        loss_grad = loss_func(adj_noise, grad_log_noise, sigma=sigma)
-        d_loss = compute_kl_loss(adj_true, adj_noise) * A
-        loss_sm = kl_weight * d_loss + loss_grad
-        w_sm = 6
+        # loss = bce * A + 6 * (kl_weight * (kl * A) + dsm), the weights folded into the loss kernels
+        w_kl, w_dsm = 6.0 * kl_weight * A, 6.0
+        loss_grad = loss_func(adj_noise, grad_log_noise, sigma=sigma, scale=w_dsm)
+        d_loss = compute_kl_loss(adj_true, adj_noise, scale=w_kl)
     elif branch == "node":
         node_feats = XF.BcastRowsFn.apply(model.node_fc(x), N)  # == node_fc(x.unsqueeze(1).repeat(1, N, 1))
         node_feats, feat_grad = XF.FeatureNoiseFn.apply(node_feats, sigma, randn,
                                                         None if randn is not None else rt.rng, 9002)
         node_feats, _ = model.generator(node_feats, adj_true)
-        d_loss = compute_kl_loss(node_feats, feat_seq[1]) * A
-        loss_grad = loss_func(node_feats, feat_grad, sigma=sigma)
-        loss_sm = 0.15 * d_loss + 6 * loss_grad
-        w_sm = 1.1
+        # loss = bce * A + 1.1 * (0.15 * (kl * A) + 6 * dsm)
+        w_kl, w_dsm = 1.1 * 0.15 * A, 1.1 * 6.0
+        d_loss = compute_kl_loss(node_feats, feat_seq[1], scale=w_kl)
+        loss_grad = loss_func(node_feats, feat_grad, sigma=sigma, scale=w_dsm)
     else:
         raise ValueError(branch)
     x_gen = model.fusion_fc(XF.PoolConcatFn.apply(x, node_feats))
     logit = model.logit_fc(x_gen)
-    loss = bce_loss(logit, target) * A
-    loss = loss + w_sm * loss_sm
+    loss = bce_loss(logit, target, scale=A) + d_loss + loss_grad
     rt.backward(loss, between)
-    return loss.detach(), logit.detach(), dict(d_loss=d_loss.detach(), loss_grad=loss_grad.detach())
+    # reported as the reference logs them: d_loss = KL * A, loss_grad = the unweighted DSM term
+    return loss.detach(), logit.detach(), dict(d_loss=_Scaled(d_loss, w_kl / A), loss_grad=_Scaled(loss_grad, w_dsm))
 
 
 def clip_and_step(model, optim, clip=5.0):
