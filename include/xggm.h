@@ -216,6 +216,10 @@ typedef struct xggm_ln_fwd_problem {
     float* stats;
     int M;
     uint32_t sid_pre, sid_post;
+    /* in_slabs > 0: `in` is fp32 and holds in_slabs partial sums [in_slabs][M][H] (split-K products of a long-K
+     * GEMM, xggm_gemm_* with batch = in_slabs, c_f32 = 1): the row kernel adds them in order on the way in, so
+     * the GEMM gets in_slabs times the workgroups and no reduction pass exists.  0: `in` is T [M][H]. */
+    int in_slabs;
 } xggm_ln_fwd_problem;
 typedef struct xggm_ln_bwd_problem {
     const void* dy;

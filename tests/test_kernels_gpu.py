@@ -738,3 +738,35 @@ def test_gemm_fp8_matches_dequantised_product(ops, shape, tile):
         with pytest.raises(RuntimeError, match="multiples of 16"):
             ops.call("xggm_gemm_fp8e4m3", ops.ptr(x8), ops.ptr(w8), ops.ptr(y), M, N, bad["K"], K, K, N, None, None, None,
                      None, None, 0, 0, ops.stream())
+
+
+def test_layernorm_forward_sums_split_k_partials(ops):
+    """the FFN output product as S = 3 split-K slices (fp32 partial sums through the batch dimension of the grouped
+    GEMM) handed to the residual LayerNorm, which adds them on the way in: against fp64 torch of the same bf16
+    operands, and against the unsplit path (which rounds the product to bf16 before the LayerNorm)."""
+    BF = torch.bfloat16
+    M, K, H, S = 1152, 3072, 768, 3
+    x, x64 = rnd((M, K), BF, 1)
+    w, w64 = rnd((H, K), BF, 2, 0.03)
+    res, res64 = rnd((M, H), BF, 3)
+    b = torch.randn(H, generator=torch.Generator().manual_seed(4)).to(DEV)
+    gamma = (1 + 0.1 * torch.randn(H, generator=torch.Generator().manual_seed(5))).to(DEV)
+    beta = (0.1 * torch.randn(H, generator=torch.Generator().manual_seed(6))).to(DEV)
+    p, part = ops.p_fwd_splitk(x, w, S)
+    ops.gemm_group(BF, [p])
+    assert tuple(part.shape) == (S, M, H)
+    prod = x64.to(DEV) @ w64.to(DEV).t()
+    assert rel_err(part.sum(0), prod) < 1e-5
+    ln = ops.LnFwdReq(part, b, res, gamma, beta, 1e-12, dtype=BF)
+    ops.launch_row_requests([ln])
+    z = prod + b.double() + res64.to(DEV)
+    want = torch.nn.functional.layer_norm(z, (H,), gamma.double(), beta.double(), 1e-12)
+    assert rel_err(ln.z, z) < 4e-3 and rel_err(ln.out, want) < 6e-3
+    # the unsplit path
+    p1, h, _ = ops.p_fwd(x, w, None)
+    ops.gemm_group(BF, [p1])
+    ln1 = ops.LnFwdReq(h, b, res, gamma, beta, 1e-12)
+    ops.launch_row_requests([ln1])
+    assert rel_err(ln.out, ln1.out.double()) < 1e-2
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        ops.p_fwd_splitk(x, w, 5)

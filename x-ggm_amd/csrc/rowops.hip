@@ -187,7 +187,18 @@ __global__ __launch_bounds__(LN_FWD_W * 64) void ln_fwd_kernel(LnFwdGroup G, int
         for (int v = 0; v < NV; ++v) {
             const int c = (v * 64 + lane) * 4;
             if (c < H) {
-                load4(in + rb + c, z[v]);
+                if (sg.in_slabs > 0) {  // split-K partial sums (fp32), added in slab order
+                    const float* part = reinterpret_cast<const float*>(sg.in) + rb + c;
+                    load4(part, z[v]);
+                    for (int sl = 1; sl < sg.in_slabs; ++sl) {
+                        float t4[4];
+                        load4(part + (int64_t)sl * M * H, t4);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) z[v][i] += t4[i];
+                    }
+                } else {
+                    load4(in + rb + c, z[v]);
+                }
                 if (bias) {
                     float b4[4];
                     load4(bias + c, b4);
@@ -722,6 +733,8 @@ int ln_fwd_grouped(const xggm_ln_fwd_problem* probs, int n, int H, float eps, fl
             const xggm_ln_fwd_problem& q = probs[i0 + i];
             if (int e = check_row_shape("xggm_ln_fwd", q.M, H)) return e;
             XGGM_REQUIRE(q.in && q.gamma && q.beta && q.out, "xggm_ln_fwd: null pointer");
+            XGGM_REQUIRE(q.in_slabs >= 0 && q.in_slabs <= 8, "xggm_ln_fwd: in_slabs = %d (0..8)", q.in_slabs);
+            XGGM_REQUIRE(q.in_slabs == 0 || (q.z_out && q.z_out != q.in), "xggm_ln_fwd: split-K input needs its own z_out");
             G.s[i] = q;
             G.start[i] = total;
             total += std::min(ceil_div(q.M, LN_FWD_W), 4096);
@@ -738,7 +751,7 @@ template <typename T>
 int ln_fwd(const void* in, const float* bias, const void* residual, const float* gamma, const float* beta, void* out,
            void* z_out, float* stats, int M, int H, float eps, float p_pre, float p_post, const uint64_t* rng,
            uint32_t s_pre, uint32_t s_post, int accumulate, float out_scale, hipStream_t st) {
-    const xggm_ln_fwd_problem q{in, bias, residual, gamma, beta, out, z_out, stats, M, s_pre, s_post};
+    const xggm_ln_fwd_problem q{in, bias, residual, gamma, beta, out, z_out, stats, M, s_pre, s_post, 0};
     return ln_fwd_grouped<T>(&q, 1, H, eps, p_pre, p_post, rng, accumulate, out_scale, st);
 }
 

@@ -8,6 +8,8 @@ AccumulateGrad copies happen and the optimiser / all-reduce see contiguous memor
 Parameters are still passed as inputs (``*params``) so autograd schedules the backward of
 blocks whose data inputs need no gradient.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -299,17 +301,27 @@ def g_attn_bwd(rt, saved, dy, defer_wgrad=False, link=None):
     return dxq, dxkv
 
 
+# split-K of the FFN output product (XGGM_SPLIT_K = 0 / 1 turns it off; same-box A/B hook)
+_SPLIT_K = int(os.environ.get("XGGM_SPLIT_K", "3"))
+
+
 def g_ffn_fwd(rt, inter, outm, x):
     """BertIntermediate + BertOutput (src/lxrt/modeling.py:428-445):
     y = LN(dropout(W_2 gelu(W_1 x + b_1) + b_2) + x)."""
     a = rt.arena
     p1, act, u = ops.p_fwd(x, a.w(inter.dense.weight), inter.dense.bias.data, act=ops.ACT_GELU, want_preact=True)
     yield [p1]
-    p2, h, _ = ops.p_fwd(act, a.w(outm.dense.weight), None)
+    w2 = a.w(outm.dense.weight)
+    S = _SPLIT_K if (x.dtype == torch.bfloat16 and w2.shape[1] >= 2048 and w2.shape[1] % (64 * max(_SPLIT_K, 1)) == 0) else 0
+    if S > 1:
+        # K = 3072, N = 768: too few tiles for their long k-loop -> S slices of K, summed by the LayerNorm below
+        p2, h = ops.p_fwd_splitk(act, w2, S)
+    else:
+        p2, h, _ = ops.p_fwd(act, w2, None)
     yield [p2]
     p_hid = rt.p(rt.p_hidden)
     ln = ops.LnFwdReq(h, outm.dense.bias.data, x, outm.LayerNorm.weight.data, outm.LayerNorm.bias.data, 1e-12,
-                      p_pre=p_hid, rng=rt.rng, sid_pre=outm._sid)
+                      p_pre=p_hid, rng=rt.rng, sid_pre=outm._sid, dtype=x.dtype)
     yield ln
     return ln.out, (inter, outm, p_hid, (x, u, act, ln.z, ln.stats))
 

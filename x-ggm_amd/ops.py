@@ -180,6 +180,21 @@ def p_fwd(x, w, bias=None, act=ACT_NONE, want_preact=False, out_f32=False):
     return _problem(x, w, y, M, N, K, a_rs, 1, K, 1, N, bias=bias, preact=pre, act=act, c_f32=out_f32), y, pre
 
 
+def p_fwd_splitk(x, w, S):
+    """problem for the S partial products of y = x @ w^T over K / S wide slices of the reduction, fp32 [S, M, N]
+    (the batch dimension of the GEMM walks the slices); summed by the consumer (``LnFwdReq``).  For long-K
+    products with few tiles (FFN output: K = 3072, N = 768): S times the workgroups, 1 / S of the k-loop each."""
+    M, K, a_rs = _rows(_chk(x))
+    N = w.shape[0]
+    assert w.shape[1] == K and w.dtype == x.dtype and w.is_contiguous()
+    if K % (64 * S):
+        raise RuntimeError("p_fwd_splitk: K = %d is not a multiple of 64 * %d" % (K, S))
+    part = torch.empty((S, M, N), device=x.device, dtype=F32)
+    p = _problem(x, w, part, M, N, K // S, a_rs, 1, K, 1, N, c_f32=True)
+    p.batch, p.a_bs, p.b_bs, p.c_bs = S, K // S, K // S, M * N
+    return p, part
+
+
 def p_dgrad(dy, w, residual=None, gelu_aux=None, colsum=None, into=None):
     """problem for dx = dy @ w (+ residual) (* gelu'(aux)); ``colsum`` (fp32 [K]) += column sums of dx
     (the bias gradient of the Linear that produced the activation); ``into``: an existing gradient of the
@@ -353,7 +368,7 @@ class LnFwdProblem(_ct.Structure):
     """mirror of ``xggm_ln_fwd_problem`` (include/xggm.h)"""
     _fields_ = [("inp", _ct.c_void_p), ("bias", _ct.c_void_p), ("residual", _ct.c_void_p), ("gamma", _ct.c_void_p),
                 ("beta", _ct.c_void_p), ("out", _ct.c_void_p), ("z_out", _ct.c_void_p), ("stats", _ct.c_void_p),
-                ("M", _ct.c_int), ("sid_pre", _ct.c_uint32), ("sid_post", _ct.c_uint32)]
+                ("M", _ct.c_int), ("sid_pre", _ct.c_uint32), ("sid_post", _ct.c_uint32), ("in_slabs", _ct.c_int)]
 
 
 class LnBwdProblem(_ct.Structure):
@@ -368,25 +383,34 @@ class LnFwdReq:
     """a residual-LayerNorm forward a block generator hands to ``functional.drive``: requests of the
     same round (language + vision stream) are launched together.  Results: ``out``, ``z``, ``stats``."""
 
-    def __init__(self, x, bias, residual, gamma, beta, eps, p_pre=0.0, rng=None, sid_pre=0):
+    def __init__(self, x, bias, residual, gamma, beta, eps, p_pre=0.0, rng=None, sid_pre=0, dtype=None):
+        """``x``: [M, H] activations, or the fp32 split-K partial sums [S, M, H] of ``p_fwd_splitk`` (then
+        ``dtype`` = the activation type of out / z / residual)."""
         _c(x)
-        M, H = x.shape
+        slabs = 0
+        if x.dim() == 3:
+            slabs, M, H = x.shape
+            if x.dtype != F32 or dtype is None:
+                raise RuntimeError("LnFwdReq: split-K input is fp32 [S, M, H] and needs the activation dtype")
+        else:
+            M, H = x.shape
+            dtype = x.dtype
         _c(gamma, F32, "gamma"), _c(beta, F32, "beta")
         assert gamma.numel() == H and beta.numel() == H
         if bias is not None:
             _c(bias, F32, "bias")
             assert bias.numel() == H
         if residual is not None:
-            _c(residual, x.dtype, "residual")
-            assert residual.shape == x.shape
-        self.key = ("ln_fwd", x.dtype, H, float(eps), float(p_pre))
+            _c(residual, dtype, "residual")
+            assert tuple(residual.shape) == (M, H)
+        self.key = ("ln_fwd", dtype, H, float(eps), float(p_pre))
         self.rng = rng
-        self.out = torch.empty_like(x)
-        self.z = x
+        self.out = torch.empty((M, H), device=x.device, dtype=dtype)
+        self.z = torch.empty((M, H), device=x.device, dtype=dtype) if slabs else x  # pre-LN sum: in place when it can
         self.stats = torch.empty((M, 2), device=x.device, dtype=F32)
-        self.keep = (bias, residual, gamma, beta)
-        self.prob = LnFwdProblem(ptr(x), ptr(bias), ptr(residual), ptr(gamma), ptr(beta), ptr(self.out), ptr(x),
-                                 ptr(self.stats), M, sid_pre, 0)
+        self.keep = (x, bias, residual, gamma, beta)
+        self.prob = LnFwdProblem(ptr(x), ptr(bias), ptr(residual), ptr(gamma), ptr(beta), ptr(self.out), ptr(self.z),
+                                 ptr(self.stats), M, sid_pre, 0, slabs)
 
 
 class LnBwdReq:
