@@ -130,26 +130,38 @@ def test_stage_ranges_tile_the_full_size_arena():
     fake = G()
     fake.groups, fake.info = groups, info
     active = [(g.start, g.end) for g in groups.values()]
-    st = stage_ranges(fake, active, dict(pair_cut=2, x_mid=3), 4)
-    assert len(st) == 4 and all(st)
-    tiles = sorted(r for s_ in st for r in s_)
-    assert all(a[1] <= b[0] for a, b in zip(tiles, tiles[1:]))
-    assert sum(e - s_ for s_, e in tiles) == sum(e - s_ for s_, e in active)
-
-    def stage_of(name):
-        o = info[name][0]
-        return next(k for k, rs in enumerate(st) if any(a <= o < b for a, b in rs))
-
     pre = "lxrt_encoder.model.bert.encoder."
+
+    def check(st, n):
+        assert len(st) == n and all(st)
+        tiles = sorted(r for s_ in st for r in s_)
+        assert all(a[1] <= b[0] for a, b in zip(tiles, tiles[1:]))
+        assert sum(e - s_ for s_, e in tiles) == sum(e - s_ for s_, e in active)
+
+        def stage_of(name):
+            o = info[name][0]
+            return next(k for k, rs in enumerate(st) if any(a <= o < b for a, b in rs))
+
+        return stage_of, [sum(e - s_ for s_, e in rs) for rs in st]
+
+    # cuts above the embeddings, after two layer pairs, before the first and the second-to-last cross layer
+    stage_of, sizes = check(stage_ranges(fake, active, dict(pair_cut=2, x_mid=3, emb_cut=True), 5), 5)
     assert stage_of(pre + "x_layers.4.visual_attention.att.query.weight") == 0
     assert stage_of(pre + "x_layers.3.lang_inter.dense.weight") == 0
     assert stage_of(pre + "x_layers.2.lang_inter.dense.weight") == 1
     assert stage_of(pre + "x_layers.0.visual_attention.att.query.weight") == 1
     assert stage_of(pre + "layer.8.output.dense.weight") == 2 and stage_of(pre + "r_layers.2.output.dense.weight") == 2
     assert stage_of(pre + "layer.1.output.dense.weight") == 3 and stage_of(pre + "r_layers.0.output.dense.weight") == 3
-    assert stage_of(pre + "visn_fc.visn_fc.weight") == 3
+    assert stage_of(pre + "visn_fc.visn_fc.weight") == 4
     assert stage_of("logit_fc.3.weight") == 0 and stage_of("generator.gnn_layers.0.gnn_layers.0.ctx_layer.weight") == 0
-    assert stage_of(pre + "x_layers.4.visual_attention.output.LayerNorm.weight") == 3  # vectors: only after the last stage
-    assert stage_of("lxrt_encoder.model.bert.embeddings.word_embeddings.weight") == 3
-    sizes = [sum(e - s_ for s_, e in rs) for rs in st]
-    assert sum(sizes) > 2.2e8 and all(4e7 < z < 8e7 for z in sizes)  # 46 / 50 / 71 / 54 M parameters
+    assert stage_of(pre + "x_layers.4.visual_attention.output.LayerNorm.weight") == 4  # vectors: only after the last stage
+    assert stage_of("lxrt_encoder.model.bert.embeddings.word_embeddings.weight") == 4
+    # 46 / 50 / 71 / 28 / 26 M parameters: the exposed tail is the embedding tables + vectors + visn_fc
+    assert sum(sizes) > 2.2e8 and all(4e7 < z < 8e7 for z in sizes[:3]) and all(2e7 < z < 3.2e7 for z in sizes[3:])
+    # without the cut above the embeddings the two lowest regions are final together
+    stage_of, sizes4 = check(stage_ranges(fake, active, dict(pair_cut=2, x_mid=3), 4), 4)
+    assert stage_of(pre + "layer.1.output.dense.weight") == 3 and stage_of(pre + "visn_fc.visn_fc.weight") == 3
+    assert sizes4[:3] == sizes[:3] and sizes4[3] == sizes[3] + sizes[4]
+    # a forward that recorded another number of cuts than the layout predicts: everything after the last stage
+    st = stage_ranges(fake, active, dict(pair_cut=2, x_mid=3, emb_cut=True), 3)
+    assert [len(x) for x in st[:2]] == [0, 0] and sum(e - s_ for s_, e in st[2]) == sum(e - s_ for s_, e in active)

@@ -363,7 +363,7 @@ def test_two_stage_backward_gives_the_same_gradients(kind, layers):
                                  randn=b["randn_adj"] if kind == "rel" else b["randn_node"], between=between)
         torch.cuda.synchronize()
         if cut:
-            assert rt.n_stages == (2 if layers[1] < 4 else 4)
+            assert rt.n_stages == (3 if layers[1] < 4 else 5)  # cuts: above the embeddings, x0 (+ lower, xmid)
             assert seen["upper"] and sum(e - s for s, e, _ in seen["upper"]) > 0
             for s, e, g in seen["upper"]:
                 assert torch.equal(g, rt.arena.grads[s:e]), "a gradient above the cut changed after the cut"

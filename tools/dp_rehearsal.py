@@ -54,7 +54,7 @@ def main():
     torch.cuda.set_device(0)
     dist.init_process_group("gloo")
     report(run(False, rank, use_graph=False, iters=("rel",)), rank, "eager, 1 iteration")
-    for layers in ((2, 2, 1), (5, 4, 4)):  # one cut (two backward stages) / three cuts (four stages)
+    for layers in ((2, 2, 1), (5, 4, 4)):  # two cuts (three backward stages) / four cuts (five stages)
         check(rank, layers)
     dist.destroy_process_group()
 

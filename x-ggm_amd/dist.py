@@ -133,34 +133,38 @@ def stage_ranges(arena, ranges, layout, n_stages):
     """the active ``ranges`` of the flat gradient buffer split by backward stage: element k of the result holds
     the ranges whose gradients are FINAL once stage k of Runtime.backward has run (stage 0 = above the last cut).
     ``layout`` = Runtime.cut_layout (where LXRTEncoder.forward cuts), ``n_stages`` = cuts recorded + 1.
-    Forward regions of ``enc_main``: 0 = embeddings, visn_fc, layer pairs below ``pair_cut``; 1 = the other
-    single-modality layers; 2 = cross layers below ``x_mid``; 3 = the remaining cross layers and the pooler.
-    Every other arena group (enc_tail, heads, generator) is final after stage 0; the vector region of
-    ``enc_main`` (biases, LayerNorm parameters, embedding tables of ALL layers) only after the last stage."""
+    Forward regions of ``enc_main``: 0 = embeddings and visn_fc; 1 = layer pairs below ``pair_cut``; 2 = the other
+    single-modality layers; 3 = cross layers below ``x_mid``; 4 = the remaining cross layers and the pooler.  A cut
+    sits between regions 0|1 (``emb_cut``), 1|2 (``pair_cut``), 2|3 (always), 3|4 (``x_mid``); regions without a cut
+    between them are final together.  Every other arena group (enc_tail, heads, generator) is final after stage 0;
+    the vector region of ``enc_main`` (biases, LayerNorm parameters, embedding tables of ALL layers) only after
+    the last stage."""
     import re
     last = n_stages - 1
     main = arena.groups.get("enc_main")
-    pair_cut, x_mid = layout.get("pair_cut"), layout.get("x_mid")
-    # which cuts exist (in forward order) decides how regions map to stages
-    borders = []  # region index below which a cut sits
-    if pair_cut is not None:
+    pair_cut, x_mid, emb_cut = layout.get("pair_cut"), layout.get("x_mid"), layout.get("emb_cut", False)
+    # which cuts exist (in forward order) decides how regions map to stages: borders[i] = first region above cut i
+    borders = []
+    if emb_cut:
         borders.append(1)
-    borders.append(2)
+    if pair_cut is not None:
+        borders.append(2)
+    borders.append(3)
     if x_mid is not None:
-        borders.append(3)
+        borders.append(4)
     if len(borders) + 1 != n_stages:  # the forward recorded other cuts than the layout predicts: no split
         return [[] for _ in range(last)] + [list(ranges)]
 
     def region(name):
         m = re.search(r"\.x_layers\.(\d+)\.", name)
         if m:
-            return 3 if (x_mid is not None and int(m.group(1)) >= x_mid) else 2
+            return 4 if (x_mid is not None and int(m.group(1)) >= x_mid) else 3
         m = re.search(r"\.(?:layer|r_layers)\.(\d+)\.", name)
         if m:
-            return 1 if (pair_cut is not None and int(m.group(1)) >= pair_cut) else (0 if pair_cut is not None else 1)
+            return 2 if (pair_cut is None or int(m.group(1)) >= pair_cut) else 1
         if ".pooler." in name:
-            return 3
-        return 0 if pair_cut is not None else 1
+            return 4
+        return 0  # embeddings, visn_fc
 
     def stage_of_region(r):
         return sum(1 for b in borders if b > r)  # cuts after the region = stages that run before it is final

@@ -349,21 +349,26 @@ class LXRTEncoder(nn.Module):
         # language layers and relational (vision) layers are independent chains: the first
         # min(l, r) layers of both run pairwise in lockstep, the rest alone
         n_pair = min(self.num_l_layers, self.num_r_layers)
-        # data-parallel overlap: the autograd graph is cut at up to three places so the backward runs in stages
+        # data-parallel overlap: the autograd graph is cut at up to four places so the backward runs in stages
         # and the gradients above a cut go on the wire while the stage below it computes (Runtime.backward,
-        # dist.stage_ranges).  Positions: after the first two layer pairs, before the first and before the
-        # second-to-last cross-modality layer.
+        # dist.stage_ranges).  Positions: right above the embeddings / visual-feature encoder (their tables and
+        # the vector region are the only gradients that are final last: the exposed tail of the exchange), after
+        # the first two layer pairs, before the first and before the second-to-last cross-modality layer.
         rt = runtime_of(self)
         cutting = rt.cut_enabled and torch.is_grad_enabled()
         pair_cut = 2 if n_pair >= 4 else None
         x_mid = self.num_x_layers - 2 if self.num_x_layers >= 4 else None
-        rt.cut_layout = dict(pair_cut=pair_cut, x_mid=x_mid)
+        emb_cut = bool(cutting and lang_feats.requires_grad and visn_feats.requires_grad)
+        rt.cut_layout = dict(pair_cut=pair_cut, x_mid=x_mid, emb_cut=emb_cut)
         rt._cuts = []  # cuts of an earlier forward that never saw its backward are dropped
 
         def cut(tag, a, b):
             if cutting and a.requires_grad and b.requires_grad:
                 return rt.make_cut(tag, a, b)
             return a, b
+
+        if emb_cut:
+            lang_feats, visn_feats = cut("emb", lang_feats, visn_feats)
 
         for i in range(n_pair):
             if i == pair_cut:
