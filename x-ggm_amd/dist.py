@@ -112,7 +112,12 @@ class GradSync:
                 w.copy_(self.g[s:e])
                 wire.append(w)
                 o += e - s
-            works = [dist.all_reduce(w, op=op, group=self.group, async_op=True) for w in wire]
+            # the ranges of a stage are scattered over the gradient buffer (17 pieces per pass in the full model) but
+            # contiguous on the wire: ONE collective per stage buffer (split only above 4 x bucket_elems) instead
+            # of one per piece -- fewer, larger transfers for the point-to-point links
+            step = 4 * self.bucket_elems
+            works = [dist.all_reduce(buf[a:min(a + step, total)], op=op, group=self.group, async_op=True)
+                     for a in range(0, total, step)]
         else:
             works = [dist.all_reduce(self.g[s:e], op=op, group=self.group, async_op=True) for s, e in buckets]
         return (buckets, wire, works, use_avg)
@@ -121,8 +126,12 @@ class GradSync:
         if handle is None:
             return
         buckets, wire, works, use_avg = handle
+        if wire is not None:  # collectives cover the whole stage buffer, not single buckets
+            for w in works:
+                w.wait()
         for i, (s, e) in enumerate(buckets):
-            works[i].wait()
+            if wire is None:
+                works[i].wait()
             if wire is not None:
                 self.g[s:e].copy_(wire[i])
             if not use_avg:

@@ -182,14 +182,26 @@ class CapturedTrainer:
             if self._comm is None:
                 self._comm = torch.cuda.Stream()
             comm = self._comm
-            for k, g in enumerate(graphs):
-                g.replay()
-                comm.wait_stream(main)
+
+            def exchange(k, after):
+                comm.wait_event(after)
                 with torch.cuda.stream(comm):
                     if k < len(early):
                         sync.finish(sync.begin(early[k], slot=k))
                     else:
                         sync.sync(final)
+
+            # graph k + 1 is handed to the GPU BEFORE the host enqueues the (eager) exchange of stage k: those dozens
+            # of small launches take the host longer than the GPU needs to get to the end of graph k
+            prev = None
+            for k, g in enumerate(graphs):
+                g.replay()
+                ev = torch.cuda.Event()
+                ev.record(main)
+                if prev is not None:
+                    exchange(k - 1, prev)
+                prev = ev
+            exchange(len(graphs) - 1, prev)
             main.wait_stream(comm)
             gu.replay()
         return self.outputs[kind]
