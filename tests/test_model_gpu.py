@@ -411,6 +411,40 @@ def test_string_questions_equal_token_tensors():
     assert torch.equal(mask1, mask2) and torch.equal(l1, l2) and torch.equal(v1, v2) and torch.equal(x1, x2)
 
 
+def test_captured_predictor_takes_string_questions():
+    """the validation loader hands over question strings (src/vqa/vqacpv2.py:331): the captured predictor tokenises
+    them through the encoder's cached batcher and gives the labels of the eager ``model(feats, boxes, list_of_str)``
+    path, also for a short last batch and for a second sweep over cached sentences."""
+    import os
+    from oracle import shapes
+    from xggm_amd import param
+    from xggm_amd.engine import CapturedPredictor
+    from xggm_amd.lxrt.modeling import BertConfig, VISUAL_CONFIG
+    from xggm_amd.lxrt.tokenization import BertTokenizer
+    from xggm_amd.vqa.vqacpv2_model import VQAModel
+    cfg = dict(shapes.TINY, vocab=96)
+    tok = BertTokenizer(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vocab_small.txt"),
+                        do_lower_case=True)
+    VISUAL_CONFIG.set_visual_dims(cfg["feat_dim"], 4)
+    a = param.parse_args(["--llayers", "2", "--xlayers", "2", "--rlayers", "1"])
+    bc_ = BertConfig(cfg["vocab"], hidden_size=cfg["hidden"], num_attention_heads=cfg["heads"],
+                     intermediate_size=cfg["inter"], max_position_embeddings=cfg["max_pos"])
+    m = VQAModel(13, args=a, config=bc_, compute_dtype=BF16, tokenizer=tok)
+    m.load_state_dict({k: torch.from_numpy(synth.seeded_param(k, v.shape, 8)) for k, v in m.state_dict().items()})
+    m = m.to(DEV).eval()
+    sents = ["What is the man holding?", "how many people are there", "is it a dog-like cat?!", "", "what color is the cat",
+             "is the man holding a dog"]
+    bn = synth.vqa_batch(len(sents), A=13, F=cfg["feat_dim"], vocab=cfg["vocab"], seed=2)
+    b = batch_tensors(bn, DEV)
+    with torch.no_grad():
+        want = m.logit_fc(m(b["feats"], b["boxes"], sents)[2]).max(1)[1]
+    pred = CapturedPredictor(m, 4)
+    for _ in range(2):
+        got = torch.cat([pred(b["feats"][lo:lo + 4], b["boxes"][lo:lo + 4], sents[lo:lo + 4])[0].clone()
+                         for lo in (0, 4)])
+        assert torch.equal(got, want)
+
+
 def test_lxrt_snapshot_save_load_round_trip(tmp_path):
     """LXRTEncoderFeature.save / .load (src/lxrt/entry.py:208-238): a snapshot written by one model -- re-keyed with
     the ``module.`` prefix of a DataParallel-trained LXMERT file and carrying a pre-training head the VQA model
