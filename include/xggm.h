@@ -90,6 +90,11 @@ typedef struct xggm_gemm_problem {
     float* colsum;
     int act, c_f32, accumulate;
     float alpha;
+    /* or NULL.  fp32 outputs on the tuned bf16 kernels only: slot [batch][ceil(M/64)][ceil(N/64)] receives the sum of
+     * squares of the values this launch STORED in that 64 x 64 block of C (after `accumulate`); every slot is written
+     * by one workgroup, so a fixed-order sum of the slots is the squared norm of the weight gradient without another
+     * pass over it (nn.utils.clip_grad_norm_, src/vqa/vqacpv2.py:175). */
+    float* sqsum;
 } xggm_gemm_problem;
 int xggm_gemm_grouped_f32(const xggm_gemm_problem* probs, int n, xggm_stream_t stream);
 int xggm_gemm_grouped_bf16(const xggm_gemm_problem* probs, int n, xggm_stream_t stream);

@@ -693,3 +693,57 @@ def test_training_state_resume_continues_the_same_trajectory(tmp_path):
     m3.load_state_dict(torch.load(path, map_location="cpu", weights_only=True)["model"])
     cold = first + run(m3, opt3, branches[1:])
     assert not np.allclose(cold, straight, rtol=2e-3)
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("kind", ["plain", "rel", "node"])
+def test_clip_norm_from_gemm_slots_equals_norm_of_the_gradients(dt, kind):
+    """clip_grad_norm_: in bf16 mode the encoder's weight-gradient GEMMs leave per-block sums of squares in the
+    arena's slot table and the norm pass only reads what they do not cover; the total must be the norm of all
+    ``.grad`` tensors (fp64 on the host) -- also after a second backward without zero_grad (accumulated
+    gradients: the slots are overwritten with the sums of the accumulated values) and in fp32 mode (no slots)."""
+    from oracle import shapes
+    from xggm_amd.runtime import runtime_of
+    from xggm_amd.lxrt.optimization import clip_grad_norm_
+    from xggm_amd.vqa.vqacpv2 import BCEWithLogitsLoss
+    from xggm_amd import functional as XF
+    cfg, A, B, seed = dict(shapes.TINY, l_layers=3, x_layers=2, r_layers=2), 29, 4, 6
+    bn = synth.vqa_batch(B, A=A, F=cfg["feat_dim"], vocab=cfg["vocab"], seed=seed)
+    bn["randn_node"] = synth.randn_nodes(B, 36, cfg["hidden"], seed)
+    b = batch_tensors(bn, DEV)
+    sent = (b["input_ids"], b["input_mask"], b["segment_ids"])
+    m = build_model(cfg, A, seed=seed, dt=dt).eval()
+    bce = BCEWithLogitsLoss()
+
+    def fwd_bwd(zero):
+        if zero:
+            m.zero_grad()
+        rt = runtime_of(m)
+        feat_seq, _, x = m(b["feats"], b["boxes"], sent)
+        if kind == "plain":
+            loss = bce(m.logit_fc(x), b["target"], scale=A)
+        else:
+            from xggm_amd.vqa.vqacpv2 import compute_kl_loss, loss_func, remove_diagonal
+            adj_true = remove_diagonal(b["adj_true"].float())
+            if kind == "rel":
+                adj, g = XF.AdjInitFn.apply(m.encoder_adj(x), 36, 1.0, b["randn_adj"], None, 9001)
+                nodes, adj = m.generator(feat_seq[1], adj)
+                loss = loss_func(adj, g, sigma=1.0) + compute_kl_loss(adj_true, adj, scale=A)
+            else:
+                nodes = XF.BcastRowsFn.apply(m.node_fc(x), 36)
+                nodes, g = XF.FeatureNoiseFn.apply(nodes, 1.0, b["randn_node"], None, 9002)
+                nodes, _ = m.generator(nodes, adj_true)
+                loss = loss_func(nodes, g, sigma=1.0) + compute_kl_loss(nodes, feat_seq[1], scale=A)
+            loss = loss + bce(m.logit_fc(m.fusion_fc(XF.PoolConcatFn.apply(x, nodes))), b["target"], scale=A)
+        rt.backward(loss)
+
+    for zero in (True, False):  # second round: gradients accumulate on top of the first
+        fwd_bwd(zero)
+        total = float(clip_grad_norm_(m.parameters(), 5.0))
+        want = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters() if p.grad is not None)))
+        assert abs(total - want) < 2e-5 * want, (zero, total, want)
+        arena = runtime_of(m).arena
+        if dt == BF16:
+            assert len(arena.sq_covered) > 20 and float(arena.sq_slots.sum()) > 0  # the slot path was really taken
+        else:
+            assert not arena.sq_covered

@@ -33,6 +33,7 @@ struct GemmArgs {
     void* preact;          // T, layout of C, or null: alpha*acc + bias before the activation
     const void* aux;       // T, layout of C: pre-activation u for act == GELU_GRAD
     float* colsum;         // [N] or null: += column sums of the stored result (bias gradients)
+    float* sqsum;          // or null: [ceil(M/64)][ceil(N/64)] sums of squares of the STORED fp32 values per 64 x 64 block
     int act;
     int c_f32;         // store C as float regardless of T
     int accumulate;    // C += result
@@ -404,6 +405,11 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, const float4_
     float bias[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias[e] = (g.bias && col + e < g.N) ? g.bias[col + e] : 0.f;
+    // sum of squares of what this thread stores, per 64-row block of the tile (gradient-norm slots, see the end)
+    constexpr int RS = BM >= 64 ? BM / 64 : 1, CS = BN >= 64 ? BN / 64 : 1;
+    float sq_acc[RS];
+#pragma unroll
+    for (int r = 0; r < RS; ++r) sq_acc[r] = 0.f;
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {
         if ((wid >> 1) == h) {
@@ -492,6 +498,9 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, const float4_
                             o0.x += p0[b].x; o0.y += p0[b].y; o0.z += p0[b].z; o0.w += p0[b].w;
                             o1.x += p1[b].x; o1.y += p1[b].y; o1.z += p1[b].z; o1.w += p1[b].w;
                         }
+                        if (g.sqsum)
+                            sq_acc[RS == 1 ? 0 : h] += (o0.x * o0.x + o0.y * o0.y) + (o0.z * o0.z + o0.w * o0.w) +
+                                                       (o1.x * o1.x + o1.y * o1.y) + (o1.z * o1.z + o1.w * o1.w);
                         // fp32 outputs are weight gradients (860 MB per pass, next read by the norm / update
                         // passes from HBM anyway): non-temporal, so they do not evict activations and weights
                         // (same-box A/B against plain stores, tools/ab.sh: 12.26 vs 12.39 ms per iteration)
@@ -531,7 +540,9 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, const float4_
                     if (g.colsum) stage[lr * LDS_LD + lc + e] = x;
                     if (g.c_f32) {
                         float* c = reinterpret_cast<float*>(g.C) + idx + e;
-                        *c = g.accumulate ? (*c + x) : x;
+                        const float o = g.accumulate ? (*c + x) : x;
+                        *c = o;
+                        if (g.sqsum) sq_acc[RS == 1 ? 0 : h] += o * o;
                     } else {
                         bf16* c = reinterpret_cast<bf16*>(g.C) + idx + e;
                         *c = __float2bfloat16(g.accumulate ? (__bfloat162float(*c) + x) : x);
@@ -550,6 +561,28 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, const float4_
                 atomicAdd(g.colsum + n0 + tid, sacc);
             }
             lds_barrier();
+        }
+    }
+    if (g.sqsum && g.c_f32) {
+        // one slot per 64 x 64 block of the output, written by exactly one workgroup, summed in a fixed order: the
+        // clip norm of the weight gradients without another pass over them (lxrt/optimization.py clip_grad_norm_).
+        // The loop above ended with a barrier: the staging LDS is free.
+        const int cs = lc / 64;  // a thread's chunks all sit in one 64-column block
+#pragma unroll
+        for (int r = 0; r < RS; ++r)
+#pragma unroll
+            for (int c = 0; c < CS; ++c) {
+                const float v = wave_sum(cs == c ? sq_acc[r] : 0.f);
+                if (lane == 0) stage[(r * CS + c) * 4 + wid] = v;
+            }
+        lds_barrier();
+        if (tid < RS * CS) {
+            const int r = tid / CS, c = tid % CS;
+            const int row = m0 + r * 64, cl = n0 + c * 64;
+            const int64_t sc = (g.N + 63) / 64, sr = (g.M + 63) / 64;
+            if (row < g.M && cl < g.N)
+                g.sqsum[(int64_t)bz * sr * sc + (int64_t)(row / 64) * sc + cl / 64] =
+                    (stage[tid * 4] + stage[tid * 4 + 1]) + (stage[tid * 4 + 2] + stage[tid * 4 + 3]);
         }
     }
 }
@@ -913,6 +946,7 @@ template <typename T> int launch(GemmArgs g, int batch, hipStream_t stream) {
     XGGM_REQUIRE(g.act >= 0 && g.act <= XGGM_ACT_GELU_GRAD, "xggm_gemm: bad activation %d", g.act);
     XGGM_REQUIRE(g.act != XGGM_ACT_GELU_GRAD || g.aux, "xggm_gemm: GELU_GRAD needs aux");
     XGGM_REQUIRE(g.ldc >= g.N, "xggm_gemm: ldc %lld < N %d", (long long)g.ldc, g.N);
+    XGGM_REQUIRE(!g.sqsum || g.c_f32, "xggm_gemm: sqsum is defined for fp32 outputs");
     g.a_mode = pick_mode<T>(g.A, g.a_rs, g.a_ks, g.a_bs, g.M, g.K, &g.a_tail, &g.a_rows);
     g.b_mode = pick_mode<T>(g.B, g.b_ns, g.b_ks, g.b_bs, g.N, g.K, &g.b_tail, &g.b_rows);
     dim3 grid(ceil_div(g.N, BN), ceil_div(g.M, BM), batch);
@@ -920,6 +954,8 @@ template <typename T> int launch(GemmArgs g, int batch, hipStream_t stream) {
     if constexpr (sizeof(T) == 2) {
         if (g.a_mode != 0 && g.b_mode != 0 && !g_force_generic) return launch_fast(g, batch, stream);
     }
+    XGGM_REQUIRE(!g.sqsum, "xggm_gemm: sqsum needs the tuned bf16 kernels (8-aligned operands); this problem runs on the "
+                           "generic kernel");
     // the generic kernel's vector loads assume exact multiples: padded-edge operands load element-wise there
     if (g.a_tail || g.a_rows != g.M) g.a_mode = 0;
     if (g.b_tail || g.b_rows != g.N) g.b_mode = 0;
@@ -938,7 +974,7 @@ template <typename T> int launch(GemmArgs g, int batch, hipStream_t stream) {
         g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K;                                                          \
         g.a_rs = a_rs; g.a_ks = a_ks; g.b_ns = b_ns; g.b_ks = b_ks; g.ldc = ldc;                                       \
         g.a_bs = a_bs; g.b_bs = b_bs; g.c_bs = c_bs;                                                                   \
-        g.bias = bias; g.residual = residual; g.preact = preact; g.aux = aux; g.colsum = colsum;                      \
+        g.bias = bias; g.residual = residual; g.preact = preact; g.aux = aux; g.colsum = colsum; g.sqsum = nullptr;   \
         g.act = act; g.c_f32 = c_f32; g.accumulate = accumulate; g.alpha = alpha;                                     \
         g.a_mode = g.b_mode = 0; g.xcd_swizzle = g_xcd_swizzle; g.batch = batch; SET_STAMP(g); \
         return launch<T>(g, batch, stream);                                                                            \
@@ -965,7 +1001,7 @@ extern "C" int xggm_gemm_fp8e4m3(const void* A, const void* B, void* C, int M, i
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K;
     g.a_rs = a_rs; g.a_ks = 1; g.b_ns = b_ns; g.b_ks = 1; g.ldc = ldc;
     g.a_bs = g.b_bs = g.c_bs = 0;
-    g.bias = bias; g.residual = residual; g.preact = preact; g.aux = nullptr; g.colsum = nullptr;
+    g.bias = bias; g.residual = residual; g.preact = preact; g.aux = nullptr; g.colsum = nullptr; g.sqsum = nullptr;
     g.act = act; g.c_f32 = c_f32; g.accumulate = 0; g.alpha = 1.0f;
     g.a_mode = g.b_mode = 1; g.a_tail = g.b_tail = 0; g.a_rows = M; g.b_rows = N;
     g.xcd_swizzle = g_xcd_swizzle; g.batch = 1; SET_STAMP(g);
@@ -996,7 +1032,7 @@ GemmArgs from_problem(const xggm_gemm_problem& p) {
     g.A = p.A; g.B = p.B; g.C = p.C; g.M = p.M; g.N = p.N; g.K = p.K;
     g.a_rs = p.a_rs; g.a_ks = p.a_ks; g.b_ns = p.b_ns; g.b_ks = p.b_ks; g.ldc = p.ldc;
     g.a_bs = p.a_bs; g.b_bs = p.b_bs; g.c_bs = p.c_bs;
-    g.bias = p.bias; g.residual = p.residual; g.preact = p.preact; g.aux = p.aux; g.colsum = p.colsum;
+    g.bias = p.bias; g.residual = p.residual; g.preact = p.preact; g.aux = p.aux; g.colsum = p.colsum; g.sqsum = p.sqsum;
     g.act = p.act; g.c_f32 = p.c_f32; g.accumulate = p.accumulate; g.alpha = p.alpha;
     g.a_mode = g.b_mode = 0; g.xcd_swizzle = g_xcd_swizzle; g.batch = p.batch; SET_STAMP(g);
     return g;

@@ -201,7 +201,7 @@ def drive(dt, gens):
 
 def _p_wgrad(rt, dy, x, ps):
     gw, acc = rt.arena.target(ps)
-    return ops.p_wgrad(dy, x, gw, acc)
+    return ops.p_wgrad(dy, x, gw, acc, rt.arena.sq_target(ps, dy))
 
 
 def g_attn_fwd(rt, att, outm, xq, xkv, mask, B, Sq, Sk, salt):

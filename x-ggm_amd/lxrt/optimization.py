@@ -54,16 +54,34 @@ def clip_grad_norm_(parameters, max_norm):
     if arena is None:
         raise RuntimeError("clip_grad_norm_: parameters are not arena-managed; run a forward first")
     arena.sqnorm.zero_()
-    # adjacent active groups are one contiguous range of the flat gradient buffer: one launch
-    spans = []
-    for g in arena.active_groups():
+    # ranges of the flat gradient buffer the norm pass has to READ: everything of the active groups except the
+    # matrices whose weight-gradient GEMM already left its sum of squares in the slot table (arena.sq_target);
+    # adjacent ranges are one launch
+    spans, slot_spans = [], []
+
+    def add(a, b):
+        if b > a:
+            if spans and spans[-1][1] == a:
+                spans[-1][1] = b
+            else:
+                spans.append([a, b])
+
+    for g in sorted(arena.active_groups(), key=lambda n: arena.groups[n].start):
         G = arena.groups[g]
-        if spans and spans[-1][1] == G.start:
-            spans[-1][1] = G.end
-        else:
-            spans.append([G.start, G.end])
-    for a, b in sorted(spans):
+        covered = arena.sq_covered if (arena.sq_enabled and g in arena.sq_range) else ()
+        if not covered:
+            add(G.start, G.end)
+            continue
+        pos = G.start
+        for o, k, n in sorted((o, k, n) for n, (o, k, g_, _) in arena.info.items() if g_ == g and n in covered):
+            add(pos, o)
+            pos = o + k  # alignment gaps hold zeros
+        add(pos, G.end)
+        slot_spans.append(arena.sq_range[g])
+    for a, b in spans:
         ops.sqnorm(arena.grads[a:b], arena.sqnorm)
+    for a, b in slot_spans:  # torch's sum is a fixed reduction tree: deterministic
+        arena.sqnorm.add_(arena.sq_slots[a:b].sum())
     arena.pending_clip = float(max_norm)
     return arena.sqnorm.sqrt()
 

@@ -157,7 +157,8 @@ class GemmProblem(_ct.Structure):
                 ("ldc", _ct.c_int64), ("batch", _ct.c_int),
                 ("a_bs", _ct.c_int64), ("b_bs", _ct.c_int64), ("c_bs", _ct.c_int64),
                 ("bias", _ct.c_void_p), ("residual", _ct.c_void_p), ("preact", _ct.c_void_p), ("aux", _ct.c_void_p),
-                ("colsum", _ct.c_void_p), ("act", _ct.c_int), ("c_f32", _ct.c_int), ("accumulate", _ct.c_int), ("alpha", _ct.c_float)]
+                ("colsum", _ct.c_void_p), ("act", _ct.c_int), ("c_f32", _ct.c_int), ("accumulate", _ct.c_int), ("alpha", _ct.c_float),
+                ("sqsum", _ct.c_void_p)]
 
 
 def _problem(A, B, C, M, N, K, a_rs, a_ks, b_ns, b_ks, ldc, bias=None, residual=None, preact=None, aux=None,
@@ -214,12 +215,19 @@ def p_dgrad(dy, w, residual=None, gelu_aux=None, colsum=None, into=None):
                     act=ACT_GELU_GRAD if gelu_aux is not None else ACT_NONE, colsum=colsum), dx
 
 
-def p_wgrad(dy, x, gw, accumulate):
-    """problem for gw (+)= dy^T @ x (fp32)."""
+def p_wgrad(dy, x, gw, accumulate, sqsum=None):
+    """problem for gw (+)= dy^T @ x (fp32).  ``sqsum``: fp32 [ceil(N/64) * ceil(K/64)] slots that receive the sums of
+    squares of the stored gradient per 64 x 64 block (tuned bf16 kernels only), or None."""
     M, N, dy_rs = _rows(_chk(dy))
     M2, K, x_rs = _rows(_chk(x))
     assert M2 == M and x.dtype == dy.dtype and tuple(gw.shape) == (N, K) and gw.dtype == F32 and gw.is_contiguous()
-    return _problem(dy, x, gw, N, K, M, 1, dy_rs, 1, x_rs, K, c_f32=True, accumulate=accumulate)
+    p = _problem(dy, x, gw, N, K, M, 1, dy_rs, 1, x_rs, K, c_f32=True, accumulate=accumulate)
+    if sqsum is not None:
+        _c(sqsum, F32, "sqsum slots")
+        assert sqsum.numel() == ((N + 63) // 64) * ((K + 63) // 64)
+        p.sqsum = ptr(sqsum)
+        p.keep = p.keep + (sqsum,)
+    return p
 
 
 def gemm_group(dt, problems):

@@ -69,6 +69,7 @@ def enable_data_parallel(model, group=None, wire_dtype=None, overlap=None):
     rt = runtime_of(model)
     broadcast_params(rt.arena, group)
     object.__setattr__(model, "_grad_sync", GradSync(rt.arena.grads, group, wire_dtype))
+    rt.arena.sq_enabled = False  # the clip norm is that of the AVERAGED gradients: read them after the exchange
     if overlap is None:
         overlap = os.environ.get("XGGM_DP_OVERLAP", "1") != "0"
     rt.cut_enabled = bool(overlap)
