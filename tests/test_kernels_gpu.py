@@ -770,3 +770,63 @@ def test_layernorm_forward_sums_split_k_partials(ops):
     assert rel_err(ln.out, ln1.out.double()) < 1e-2
     with pytest.raises(RuntimeError, match="multiple of 64"):
         ops.p_fwd_splitk(x, w, 5)
+
+
+@pytest.mark.parametrize("group_tile", [0, 1, 2, 3])
+def test_wgrad_norm_slots(ops, group_tile):
+    """xggm_gemm_problem.sqsum: every 64 x 64 block of the stored fp32 weight gradient leaves its sum of squares in
+    its slot -- for every tile size of the grouped kernels (a 128-wide tile writes 2 or 4 slots), with ``accumulate``
+    (the slot holds the sum of the ACCUMULATED values), for ragged edges (2274 rows: the last block is partial), in a
+    group with a problem that has no slots; the fixed-order total is the squared norm of the gradients."""
+    from xggm_amd import _lib
+    BF = torch.bfloat16
+    shapes_ = [(1152, 768, 3072), (640, 2274, 1536), (1152, 768, 768)]  # (M tokens, N out, K in)
+    _lib.lib.xggm_gemm_set_group_tile(group_tile)
+    try:
+        for accumulate in (False, True):
+            probs, checks = [], []
+            for i, (M, N, K) in enumerate(shapes_):
+                Np = (N + 7) // 8 * 8  # odd widths: rows padded to a multiple of 8 elements, as the heads do
+                dy = rnd((M, Np), BF, 10 + i, 0.5)[0][:, :N]
+                x, _ = rnd((M, K), BF, 20 + i)
+                gw = torch.randn(N, K, device=DEV) if accumulate else torch.empty(N, K, device=DEV)
+                prev = gw.clone()
+                nr, nc = (N + 63) // 64, (K + 63) // 64
+                slots = torch.full((nr * nc,), float("nan"), device=DEV) if i != 2 else None
+                probs.append(ops.p_wgrad(dy, x, gw, accumulate, slots))
+                checks.append((dy, x, gw, prev, slots, nr, nc, N, K))
+            ops.gemm_group(BF, probs)
+            for dy, x, gw, prev, slots, nr, nc, N, K in checks:
+                want = dy.double().t() @ x.double() + (prev.double() if accumulate else 0)
+                assert rel_err(gw, want) < 1e-5
+                if slots is None:
+                    continue
+                pad = torch.zeros(nr * 64, nc * 64, device=DEV, dtype=torch.float64)
+                pad[:N, :K] = gw.double() ** 2
+                blocks = pad.view(nr, 64, nc, 64).sum(dim=(1, 3)).reshape(-1)
+                assert torch.isfinite(slots).all()
+                assert float((slots.double() - blocks).abs().max()) < 1e-5 * float(blocks.max())
+                assert abs(float(slots.double().sum()) - float((gw.double() ** 2).sum())) < 1e-6 * float(blocks.sum())
+    finally:
+        _lib.lib.xggm_gemm_set_group_tile(0)
+    # fp32 storage runs on the generic kernel, which has no such epilogue: refused, not silently skipped
+    dy, _ = rnd((64, 64), torch.float32, 1)
+    p = ops.p_wgrad(dy, dy, torch.empty(64, 64, device=DEV), False, torch.zeros(1, device=DEV))
+    with pytest.raises(RuntimeError, match="sqsum"):
+        ops.gemm_group(torch.float32, [p])
+
+
+def test_sched_step_multi_matches_reference_schedule(ops):
+    """xggm_sched_step_multi: warmup_linear(step / t_total, warmup) (src/lxrt/optimization.py:42-48) and step += 1 for
+    several counters of one table in one launch, untouched counters stay; against the host schedule."""
+    from oracle import xggm_oracle as O
+    steps = torch.tensor([0, 3, 7, 19, 40, 5], dtype=torch.int64, device=DEV)
+    scale = torch.full((6,), -1.0, device=DEV)
+    entries = [(0, 20, 0.1), (2, 20, 0.1), (3, 20, 0.1), (4, 20, 0.1), (5, -1, 0.1)]
+    ops.sched_step_multi(steps, scale, entries)
+    assert steps.tolist() == [1, 3, 8, 20, 41, 6]
+    want = [O.warmup_linear(0 / 20, 0.1), -1.0, O.warmup_linear(7 / 20, 0.1), O.warmup_linear(19 / 20, 0.1),
+            O.warmup_linear(40 / 20, 0.1), 1.0]
+    assert np.allclose(scale.cpu().numpy(), want, rtol=1e-6, atol=1e-7)
+    with pytest.raises(RuntimeError, match="listed twice"):
+        ops.sched_step_multi(steps, scale, [(1, 20, 0.1), (1, 20, 0.1)])
