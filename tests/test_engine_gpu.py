@@ -1,0 +1,123 @@
+"""The captured engine (what bench.py times): hipGraph replays of the three pass kinds against the same passes launched
+eagerly, and size-independent properties of the full-size iteration (BASELINE configs[1]: 9/5/5 LXMERT + GCN x 2, 32
+samples) that the oracle is too slow to check element by element."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from xggm_amd import synth  # noqa: E402
+from helpers import batch_tensors, rel_err  # noqa: E402
+
+DEV = "cuda"
+BF16 = torch.bfloat16
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def _tiny(seed_w, seed_rt, layers=(3, 2, 2)):
+    from oracle import shapes
+    from test_model_gpu import build_model
+    from xggm_amd.vqa.vqacpv2 import make_optimizer
+    cfg = dict(shapes.TINY, l_layers=layers[0], x_layers=layers[1], r_layers=layers[2])
+    m = build_model(cfg, 29, seed=seed_w, dt=BF16)
+    m.seed = seed_rt
+    return cfg, m, make_optimizer(m, 2e-3, 40)
+
+
+@pytest.mark.parametrize("order", ["vqa", "gqa"])
+def test_captured_replay_equals_eager_passes(order):
+    """CapturedTrainer: each pass kind is captured once and replayed; the replays must train the model exactly as the
+    same sequence of eagerly launched passes does (same Philox stream: dropout on), including the warm-up passes the
+    constructor runs before capturing, batches swapped in through ``load_batch``, and both iteration orders."""
+    from xggm_amd.engine import CapturedTrainer
+    from xggm_amd.runtime import runtime_of
+    from xggm_amd.vqa.vqacpv2 import plain_pass, ggm_pass, BCEWithLogitsLoss
+    B, A = 4, 29
+    cfg, m1, o1 = _tiny(5, 11)
+    _, m2, o2 = _tiny(5, 11)
+    batches = [batch_tensors(synth.vqa_batch(B, A=A, F=cfg["feat_dim"], vocab=cfg["vocab"], seed=s), DEV) for s in (3, 4)]
+    branches = ["rel", "node", "rel"]
+    klw = 8.0 if order == "vqa" else 12.0
+
+    tr = CapturedTrainer(m1, o1, batches[0], sigma=1.0, order=order, warmup_iters=1)
+    cap = []
+    for i, br in enumerate(branches):
+        tr.load_batch(batches[i % 2])
+        (lp, _, _), (lg, _, _) = tr.iteration(br)
+        cap += [float(lp), float(lg)]
+
+    # the same schedule, launched eagerly on the twin
+    bce = BCEWithLogitsLoss()
+    rt2 = runtime_of(m2)
+    m2.train()
+
+    def run(kind, b):
+        sent = (b["input_ids"], b["input_mask"], b["segment_ids"])
+        if kind == "plain":
+            out = plain_pass(m2, o2, bce, b["feats"], b["boxes"], sent, b["target"])
+        else:
+            out = ggm_pass(m2, o2, bce, b["feats"], b["boxes"], sent, b["target"], b["adj_true"], kind, 1.0, klw)
+        rt2.advance()
+        return float(out[0])
+
+    for kind in ("plain", "rel", "node"):  # the constructor's warm-up iteration
+        run(kind, batches[0])
+    eager = []
+    for i, br in enumerate(branches):
+        b = batches[i % 2]
+        if order == "vqa":
+            eager += [run("plain", b), run(br, b)]
+        else:
+            g = run(br, b)
+            eager += [run("plain", b), g]
+    # fp32 atomics (bias gradients) make the last bits run-dependent: tolerances of the dropout reproducibility test
+    assert np.allclose(cap[:2], eager[:2], rtol=1e-5), (cap, eager)
+    assert np.allclose(cap, eager, rtol=3e-3), (cap, eager)
+    sd1, sd2 = m1.state_dict(), m2.state_dict()
+    worst = max(rel_err(sd1[k].float(), sd2[k].float()) for k in sd1)
+    assert worst < 3e-3, worst
+    assert rt2.arena.steps.tolist() == runtime_of(m1).arena.steps.tolist()
+    assert runtime_of(m1).rng.tolist() == rt2.rng.tolist()
+
+
+def test_full_size_iteration_properties():
+    """BASELINE configs[1] on the captured engine (full 9/5/5 model, 32 samples, bf16, dropout on): losses and
+    parameters stay finite; the clip norm the pass reports (GEMM slot table + norm pass) equals the fp64 norm of the
+    gradient buffer; the first pass only changes what the warm-up schedule lets it change (lr factor 0 at step 0);
+    an engine built the same way reproduces the loss trajectory."""
+    import types
+    import bench
+    from xggm_amd.engine import CapturedTrainer
+    from xggm_amd.runtime import runtime_of
+    args = types.SimpleNamespace(batch=32, answers=2274, steps=4, warmup=0, dtype="bf16", seed=9595)
+    traj = []
+    for rep in range(2):
+        model, optim, batch = bench.build(args, torch.device("cuda", 0))
+        rt = runtime_of(model)
+        tr = CapturedTrainer(model, optim, batch, sigma=1.0, order="vqa", warmup_iters=1)
+        arena = rt.arena
+        losses = []
+        for br in ("rel", "node"):
+            (lp, _, tp), (lg, _, tg) = tr.iteration(br)
+            losses += [float(lp), float(lg)]
+            # after a replay the gradient buffer holds the last (GGM) pass's gradients: every group but the head of
+            # the other branch (a replay leaves no ``.grad`` attributes behind to ask)
+            act = [G for g, G in arena.groups.items() if g != ("node_fc" if br == "rel" else "encoder_adj")]
+            want = float(torch.sqrt(sum(float((arena.grads[G.start:G.end].double() ** 2).sum()) for G in act)
+                                    * torch.ones((), dtype=torch.float64)))
+            assert abs(float(tg) - want) < 1e-4 * want, (br, float(tg), want)
+            assert float(tp) > 0
+        assert all(np.isfinite(losses)) and all(x > 0 for x in losses)
+        assert bool(torch.isfinite(arena.params).all()) and bool(torch.isfinite(arena.m).all())
+        assert float(arena.sq_slots.sum()) > 0  # the encoder's weight gradients went through the slot table
+        assert min(arena.steps.tolist()) >= 2
+        traj.append(losses)
+        del tr, model, optim
+        torch.cuda.empty_cache()
+    assert np.allclose(traj[0][:1], traj[1][:1], rtol=1e-6) and np.allclose(traj[0], traj[1], rtol=2e-3), traj

@@ -99,8 +99,11 @@ class CapturedTrainer:
             import torch.distributed as dist
             dist.barrier()
             torch.cuda.synchronize()
-        pool = None
         for kind in ("plain", "rel", "node"):
+            # one memory pool per pass kind (shared by the graphs of that kind only): with a pool shared across kinds
+            # the outputs of one kind (loss, logits, norm) can land where an earlier-captured kind keeps its
+            # intermediates, and replaying that kind then overwrites them before the caller has read them
+            pool = None
             if not self.split:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool, capture_error_mode=self.capture_mode):
