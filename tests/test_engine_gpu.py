@@ -165,3 +165,32 @@ def test_bench_on_a_one_rank_rccl_group():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["steps"] == 2 and line["value"] > 0 and line["config"]["hip_graph"] is True
     assert set(line["ms_per_pass"]) == {"plain", "rel", "node"} and all(v > 0 for v in line["ms_per_pass"].values())
+
+
+def test_training_state_restored_under_live_graphs(tmp_path):
+    """load_training_state writes weights, moments, step counters and the Philox state IN PLACE, so an engine whose
+    graphs were captured before the restore continues exactly where the saved run stood: trainer A runs two
+    iterations, saves, runs a third; trainer B (other weights, other dropout seed, graphs already captured and
+    replayed) loads the snapshot and runs one iteration -- same losses, same parameters."""
+    from xggm_amd.engine import CapturedTrainer
+    from xggm_amd.vqa.vqacpv2 import save_training_state, load_training_state
+    B, A = 4, 29
+    cfg, ma, oa = _tiny(5, 11)
+    _, mb, ob = _tiny(77, 99)
+    batch = batch_tensors(synth.vqa_batch(B, A=A, F=cfg["feat_dim"], vocab=cfg["vocab"], seed=3), DEV)
+    ta = CapturedTrainer(ma, oa, batch, warmup_iters=1)
+    tb = CapturedTrainer(mb, ob, batch, warmup_iters=1)
+    tb.iteration("rel")  # B has a history of its own
+    for br in ("rel", "node"):
+        ta.iteration(br)
+    path = str(tmp_path / "state.pth")
+    save_training_state(path, ma, oa, iteration=2)
+    (lp_a, _, _), (lg_a, _, _) = ta.iteration("rel")
+    want = [float(lp_a), float(lg_a)]
+    assert load_training_state(path, mb, ob) == {"iteration": 2}
+    (lp_b, _, _), (lg_b, _, _) = tb.iteration("rel")
+    got = [float(lp_b), float(lg_b)]
+    assert np.allclose(got, want, rtol=1e-5), (got, want)
+    sa, sb = ma.state_dict(), mb.state_dict()
+    assert max(rel_err(sb[k].float(), sa[k].float()) for k in sa) < 2e-3
+    assert oa.state_dict()["state"][0]["step"] == ob.state_dict()["state"][0]["step"]
