@@ -687,6 +687,14 @@ def test_training_state_resume_continues_the_same_trajectory(tmp_path):
     worst = max(rel_err(got[k], want[k]) for k in want)
     assert worst < 2e-3, worst
     assert opt2.state_dict()["state"][0]["step"] == 6
+    # get_lr (src/lxrt/optimization.py:100-114): one scheduled rate per parameter in param_groups order -- heads at
+    # 4 * lr first (logit_fc has taken all six steps), then the encoder; [0] while a parameter has never been stepped
+    from xggm_amd.lxrt.optimization import warmup_linear
+    lrs = opt2.get_lr()
+    assert len(lrs) == n_params
+    assert abs(lrs[-1] - 2e-3 * warmup_linear(6 / 12, 0.1)) < 1e-12 and abs(lrs[0] - 4 * lrs[-1]) < 1e-12
+    fresh_model, fresh_opt = fresh(1, 1)
+    assert fresh_opt.get_lr() == [0]
 
     # the reference's kind of resume: weights only, optimiser from scratch -> another trajectory
     m3, opt3 = fresh(77, 99)

@@ -178,21 +178,25 @@ class BertAdam(Optimizer):
         return None
 
     def get_lr(self):
+        """ref :100-114: the scheduled learning rate of every parameter, in param_groups order; ``[0]`` while some
+        parameter has never been stepped (the reference's empty ``state[p]``)."""
         arena = self._arena()
         if arena is None:
             return [0]
         steps = arena.steps.tolist()
         lr = []
-        for g, G in arena.groups.items():
-            pg = self._hyper_of_group(arena, g)
-            if pg is None:
-                continue
-            s = steps[arena.group_index[g]]
-            if pg['t_total'] != -1:
-                sc = SCHEDULES[pg['schedule']](s / pg['t_total'], pg['warmup'])
-            else:
-                sc = 1.0
-            lr.extend([pg['lr'] * sc] * len(G.params))
+        for pg in self.param_groups:
+            for p in pg['params']:
+                xg = getattr(p, "_xg", None)
+                if xg is None or xg[0] is not arena:
+                    return [0]
+                s = steps[arena.group_index[xg[3]]]
+                if s == 0:
+                    return [0]
+                if pg['t_total'] != -1:
+                    lr.append(pg['lr'] * SCHEDULES[pg['schedule']](s / pg['t_total'], pg['warmup']))
+                else:
+                    lr.append(pg['lr'])
         return lr
 
     def zero_grad(self, set_to_none=True):
