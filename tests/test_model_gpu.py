@@ -755,3 +755,63 @@ def test_clip_norm_from_gemm_slots_equals_norm_of_the_gradients(dt, kind):
             assert len(arena.sq_covered) > 20 and float(arena.sq_slots.sum()) > 0  # the slot path was really taken
         else:
             assert not arena.sq_covered
+
+
+@pytest.mark.parametrize("branch", ["rel", "node"])
+def test_trainer_written_with_plain_torch_statements_equals_the_fused_pass(branch):
+    """INTEGRATION.md's claim: a training loop that keeps its own torch statements around the drop-in modules -- boolean
+    mask scatter of the edge logits into the upper triangle plus transpose-add (what src/vqa/vqacpv2.py:195-199 does),
+    the noise helpers of module.graph_utils, torch.cat / tanh / mean for the fused question vector, python-float loss
+    weights, plain ``loss.backward()``, torch's own ``nn.utils.clip_grad_norm_`` on the arena-backed ``.grad`` views and
+    ``optim.step()`` -- trains exactly like ``ggm_pass`` (custom index kernel, PoolConcat / BcastRows functions,
+    weights folded into the loss kernels, staged backward, fused clip)."""
+    from oracle import shapes
+    from xggm_amd.module.graph_utils import add_edge_noise_v2, add_feature_noise_v2
+    from xggm_amd.vqa.vqacpv2 import (ggm_pass, BCEWithLogitsLoss, make_optimizer, loss_func, compute_kl_loss)
+    cfg, A, B, N, seed = shapes.TINY, 29, 4, 36, 15
+    bn = synth.vqa_batch(B, A=A, F=cfg["feat_dim"], vocab=cfg["vocab"], seed=seed)
+    bn["randn_node"] = synth.randn_nodes(B, N, cfg["hidden"], seed)
+    b = batch_tensors(bn, DEV)
+    sent = (b["input_ids"], b["input_mask"], b["segment_ids"])
+    bce = BCEWithLogitsLoss()
+    randn = b["randn_adj"] if branch == "rel" else b["randn_node"]
+
+    fused = build_model(cfg, A, seed=seed, dt=F32).eval()
+    opt_f = make_optimizer(fused, 1e-3, 8)
+    for _ in range(2):  # the warm-up schedule makes the first update a no-op
+        lf, _, _ = ggm_pass(fused, opt_f, bce, b["feats"], b["boxes"], sent, b["target"], b["adj_true"], branch, sigma=1.0,
+                            kl_weight=8.0, randn=randn)
+
+    m = build_model(cfg, A, seed=seed, dt=F32).eval()
+    opt = make_optimizer(m, 1e-3, 8)
+    for _ in range(2):
+        m.zero_grad()
+        feat_seq, _, x = m(b["feats"], b["boxes"], sent)
+        adj_true = b["adj_true"].float()
+        adj_true = adj_true.triu(1) + adj_true.tril(-1)
+        if branch == "rel":
+            v = m.encoder_adj(x)
+            ones = torch.ones(B, N, N, device=DEV)
+            adj = torch.zeros(B, N, N, device=DEV)
+            adj[ones.triu(1) == 1] = v.float().view(-1)
+            adj = adj + adj.transpose(1, 2)
+            adj_noise, grad_log_noise = add_edge_noise_v2(adj, 1.0, randn=randn)  # (the same Gaussian draw as the twin)
+            nodes, adj_noise = m.generator(feat_seq[1], adj_noise)
+            loss_sm = 8.0 * (compute_kl_loss(adj_true, adj_noise) * A) + loss_func(adj_noise, grad_log_noise, sigma=1.0)
+            w_sm = 6
+        else:
+            nodes = m.node_fc(x.unsqueeze(1).repeat(1, N, 1))
+            nodes, feat_grad = add_feature_noise_v2(nodes, 1.0, randn=randn)
+            nodes, _ = m.generator(nodes, adj_true)
+            loss_sm = 0.15 * (compute_kl_loss(nodes, feat_seq[1]) * A) + 6 * loss_func(nodes, feat_grad, sigma=1.0)
+            w_sm = 1.1
+        x_gen = m.fusion_fc(torch.cat([x, torch.tanh(nodes.mean(dim=1))], dim=-1))
+        loss = bce(m.logit_fc(x_gen), b["target"]) * A + w_sm * loss_sm
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 5.0)
+        opt.step()
+    assert abs(float(loss.detach()) - float(lf)) < 1e-4 * abs(float(lf)), (float(loss.detach()), float(lf))
+    sf, sm = fused.state_dict(), m.state_dict()
+    for k in sf:
+        d = float((sm[k].double() - sf[k].double()).norm())
+        assert d < 2e-5 * float(sf[k].double().norm()) + 1e-9, (k, d)
