@@ -757,8 +757,9 @@ def test_clip_norm_from_gemm_slots_equals_norm_of_the_gradients(dt, kind):
             assert not arena.sq_covered
 
 
+@pytest.mark.parametrize("dt", [F32, BF16])
 @pytest.mark.parametrize("branch", ["rel", "node"])
-def test_trainer_written_with_plain_torch_statements_equals_the_fused_pass(branch):
+def test_trainer_written_with_plain_torch_statements_equals_the_fused_pass(branch, dt):
     """INTEGRATION.md's claim: a training loop that keeps its own torch statements around the drop-in modules -- boolean
     mask scatter of the edge logits into the upper triangle plus transpose-add (what src/vqa/vqacpv2.py:195-199 does),
     the noise helpers of module.graph_utils, torch.cat / tanh / mean for the fused question vector, python-float loss
@@ -776,13 +777,13 @@ def test_trainer_written_with_plain_torch_statements_equals_the_fused_pass(branc
     bce = BCEWithLogitsLoss()
     randn = b["randn_adj"] if branch == "rel" else b["randn_node"]
 
-    fused = build_model(cfg, A, seed=seed, dt=F32).eval()
+    fused = build_model(cfg, A, seed=seed, dt=dt).eval()
     opt_f = make_optimizer(fused, 1e-3, 8)
     for _ in range(2):  # the warm-up schedule makes the first update a no-op
         lf, _, _ = ggm_pass(fused, opt_f, bce, b["feats"], b["boxes"], sent, b["target"], b["adj_true"], branch, sigma=1.0,
                             kl_weight=8.0, randn=randn)
 
-    m = build_model(cfg, A, seed=seed, dt=F32).eval()
+    m = build_model(cfg, A, seed=seed, dt=dt).eval()
     opt = make_optimizer(m, 1e-3, 8)
     for _ in range(2):
         m.zero_grad()
@@ -810,8 +811,20 @@ def test_trainer_written_with_plain_torch_statements_equals_the_fused_pass(branc
         loss.backward()
         torch.nn.utils.clip_grad_norm_(m.parameters(), 5.0)
         opt.step()
-    assert abs(float(loss.detach()) - float(lf)) < 1e-4 * abs(float(lf)), (float(loss.detach()), float(lf))
+    # fp32 storage: the two formulations are the same arithmetic; bf16 storage: torch rounds its intermediates (mean,
+    # tanh, cat) to bf16 where the fused functions keep fp32, so the update agrees to bf16 accuracy only
+    ltol = 1e-4 if dt == F32 else 2e-2
+    assert abs(float(loss.detach()) - float(lf)) < ltol * abs(float(lf)), (float(loss.detach()), float(lf))
     sf, sm = fused.state_dict(), m.state_dict()
-    for k in sf:
-        d = float((sm[k].double() - sf[k].double()).norm())
-        assert d < 2e-5 * float(sf[k].double().norm()) + 1e-9, (k, d)
+    if dt == F32:
+        for k in sf:
+            d = float((sm[k].double() - sf[k].double()).norm())
+            assert d < 2e-5 * float(sf[k].double().norm()) + 1e-9, (k, d)
+    else:
+        # BertAdam's first real step is sign-like (m / sqrt(v) = +-3.16 whatever |g|), so elements whose gradient is
+        # bf16 noise flip freely; what must agree is the direction of the update as a whole
+        w0 = {k: torch.from_numpy(synth.seeded_param(k, tuple(v.shape), seed)).double() for k, v in sf.items()}
+        da = torch.cat([(sf[k].double().cpu() - w0[k]).flatten() for k in sf])
+        db = torch.cat([(sm[k].double().cpu() - w0[k]).flatten() for k in sf])
+        cos = float((da * db).sum() / (da.norm() * db.norm()))
+        assert cos > 0.9 and bool(torch.isfinite(db).all()), cos
