@@ -828,3 +828,30 @@ def test_trainer_written_with_plain_torch_statements_equals_the_fused_pass(branc
         db = torch.cat([(sm[k].double().cpu() - w0[k]).flatten() for k in sf])
         cos = float((da * db).sum() / (da.norm() * db.norm()))
         assert cos > 0.9 and bool(torch.isfinite(db).all()), cos
+
+
+def test_switching_the_compute_dtype_rebuilds_the_arena():
+    """runtime.set_compute_dtype: one model object, bf16 execution, then exact-fp32 execution, then bf16 again; every
+    switch rebuilds the arena around the SAME parameters (the optimiser keeps working on them), and each mode gives
+    what a model built in that mode gives."""
+    from oracle import shapes
+    from xggm_amd.runtime import set_compute_dtype, runtime_of
+    from xggm_amd.vqa.vqacpv2 import plain_pass, BCEWithLogitsLoss, make_optimizer
+    cfg, A, B = shapes.TINY, 17, 4
+    b = batch_tensors(synth.vqa_batch(B, A=A, F=cfg["feat_dim"], vocab=cfg["vocab"], seed=2), DEV)
+    sent = (b["input_ids"], b["input_mask"], b["segment_ids"])
+    ref = {dt: build_model(cfg, A, seed=4, dt=dt).eval() for dt in (F32, BF16)}
+    want = {dt: ref[dt](b["feats"], b["boxes"], sent)[2] for dt in (F32, BF16)}
+    m = build_model(cfg, A, seed=4, dt=BF16).eval()
+    opt = make_optimizer(m, 1e-3, 8)
+    params = [p for p in m.parameters()]
+    for dt in (BF16, F32, BF16):
+        set_compute_dtype(m, dt)
+        x = m(b["feats"], b["boxes"], sent)[2]
+        assert x.dtype == dt and torch.equal(x, want[dt])
+        assert runtime_of(m).arena.compute_dtype == dt
+    assert all(p is q for p, q in zip(params, m.parameters()))
+    before = m.state_dict()["logit_fc.3.weight"].clone()
+    for _ in range(2):
+        plain_pass(m, opt, BCEWithLogitsLoss(), b["feats"], b["boxes"], sent, b["target"])
+    assert not torch.equal(before, m.state_dict()["logit_fc.3.weight"])
