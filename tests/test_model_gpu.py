@@ -855,3 +855,25 @@ def test_switching_the_compute_dtype_rebuilds_the_arena():
     for _ in range(2):
         plain_pass(m, opt, BCEWithLogitsLoss(), b["feats"], b["boxes"], sent, b["target"])
     assert not torch.equal(before, m.state_dict()["logit_fc.3.weight"])
+
+
+def test_batch_size_may_change_between_calls():
+    """the last batch of an epoch is smaller (drop_last=False in the validation loaders, src/vqa/vqacpv2_data.py): one
+    model object runs batches of 4, 1, 3 and 4 samples, forward and training passes; every forward equals what a
+    freshly built model gives on that batch (no workspace, arena or cached shape is tied to the first batch size)."""
+    from oracle import shapes
+    from xggm_amd.vqa.vqacpv2 import plain_pass, ggm_pass, BCEWithLogitsLoss, make_optimizer
+    cfg, A = shapes.TINY, 17
+    m = build_model(cfg, A, seed=4, dt=BF16).eval()
+    opt = make_optimizer(m, 0.0, 8)  # lr 0: the weights stay comparable to the fresh twin's
+    twin = build_model(cfg, A, seed=4, dt=BF16).eval()
+    for i, B in enumerate((4, 1, 3, 4)):
+        b = batch_tensors(synth.vqa_batch(B, A=A, F=cfg["feat_dim"], vocab=cfg["vocab"], seed=20 + i), DEV)
+        sent = (b["input_ids"], b["input_mask"], b["segment_ids"])
+        (l1, v1), _, x1 = m(b["feats"], b["boxes"], sent)
+        (l2, v2), _, x2 = twin(b["feats"], b["boxes"], sent)
+        assert torch.equal(l1, l2) and torch.equal(v1, v2) and torch.equal(x1, x2), B
+        lp, _ = plain_pass(m, opt, BCEWithLogitsLoss(), b["feats"], b["boxes"], sent, b["target"])
+        lg, _, _ = ggm_pass(m, opt, BCEWithLogitsLoss(), b["feats"], b["boxes"], sent, b["target"], b["adj_true"],
+                            "rel" if i % 2 else "node")
+        assert np.isfinite(float(lp)) and np.isfinite(float(lg))
