@@ -2,7 +2,9 @@
 """Benchmark of the X-GGM training iteration on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1 without a launcher: this process spawns the N ranks itself, BEFORE any GPU call;
+     under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` the ranks
+     are already there and RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment)
 
 One "step" = one training iteration of the reference loop (src/vqa/vqacpv2.py:164-254): a
 plain-VQA pass and a graph-generative pass, EACH a full forward + backward + grad-norm clip +
@@ -11,16 +13,23 @@ synthetic VQA-CP-v2-shaped batch of 32 samples per GPU (36 objects x 2048-d, 20 
 A = 2274), bf16 storage / fp32 accumulate, dropout on.  Weak scaling: 32 samples per rank,
 gradients averaged over RCCL.  Prints ONE JSON line (rank 0).
 
+    --order gqa        the GQA-OOD loop (src/gqa/gqa_ood.py:165-292): GGM pass first, KL weight 12, A = 1842
+    --dtype fp8        e4m3 operands for the forward QKV / FFN products (BASELINE configs[4]); bf16 GNN + backward
+    --workload c4      BASELINE configs[3]: generator only, 64 objects x 64 adjacency, batch 64, forward + backward
+
 Extra objects on the line:
-  roofline     the dominant kernel family of the step, timed live with HIP events on the
-               launch stream in an instrumented (un-captured) iteration
-  cpu_baseline the CPU oracle (oracle/xggm_oracle.py, torch fp32) timed on this box's host cores
-               on one iteration of the same workload (N = 1 only)
+  roofline           the dominant kernel family of the step (c4: the LDS-tiled aggregate kernel), timed live with
+                     HIP events on the launch stream in an instrumented (un-captured) iteration
+  cpu_baseline       the CPU oracle (oracle/xggm_oracle.py, torch fp32) timed on this box's host cores on a bounded
+                     sample of the same workload (N = 1 only)
+  value_with_loader  the same steps with the loader boundary inside the timed region: a fresh host batch every
+                     step (tokenised strings + pinned feature buffers), H2D on a copy stream, double-buffered
 """
 import argparse
 import json
 import os
 import random
+import subprocess
 import sys
 import time
 
@@ -33,47 +42,186 @@ PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARC
 PEAK_HBM_GBS = 8000.0
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=5)
-    p.add_argument("--batch", type=int, default=32, help="samples per GPU")
-    p.add_argument("--answers", type=int, default=2274)
+    p.add_argument("--batch", type=int, default=None, help="samples per GPU (32; c4: 64)")
+    p.add_argument("--answers", type=int, default=None, help="answer vocabulary (2274 VQA-CP v2; 1842 with --order gqa)")
+    p.add_argument("--order", default="vqa", choices=["vqa", "gqa"],
+                   help="vqa: plain pass then GGM pass, KL x 8; gqa: GGM first, KL x 12 (src/gqa/gqa_ood.py:165-292)")
+    p.add_argument("--workload", default="train", choices=["train", "c4"])
     p.add_argument("--delta", type=int, default=5, help="relation-branch probability delta/10")
-    p.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"])
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-timing", action="store_true")
+    p.add_argument("--no-loader", action="store_true", help="skip the loader-inclusive leg")
     p.add_argument("--wire", default="bf16", choices=["bf16", "f32"], help="gradient all-reduce dtype")
+    p.add_argument("--zero1", type=int, default=None, help="1: shard the update over the ranks (reduce-scatter -> "
+                   "BertAdam on the shard -> all-gather of the weights); default: on for N > 1")
     p.add_argument("--seed", type=int, default=9595)
-    return p.parse_args()
+    a = p.parse_args(argv)
+    if a.answers is None:
+        a.answers = 1842 if a.order == "gqa" else 2274
+    if a.batch is None:
+        a.batch = 64 if a.workload == "c4" else 32
+    return a
 
 
+# ------------------------------------------------------------------------------------------ rank spawn
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N copies of this script, one per GPU, from a parent
+    that has made no GPU call (a process that initialised the GPU must never exec another program on this pool);
+    rank 0 prints the JSON line on the stdout it inherits."""
+    import socket
+    n = args.gpus
+    if not os.environ.get("XGGM_SHARE_GPU"):
+        have = torch.cuda.device_count()  # counting devices does not initialise the GPU
+        if have < n:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (XGGM_SHARE_GPU=1 + XGGM_DIST_BACKEND=gloo "
+                             "rehearses the multi-rank path on one GPU)" % (n, have))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                r = p.poll()
+                if r is None:
+                    continue
+                procs.remove(p)
+                if r != 0 and rc == 0:
+                    rc = r
+                    for q in procs:  # one rank died: the others would wait in a collective forever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            p.kill()
+    raise SystemExit(rc)
+
+
+# ------------------------------------------------------------------------------------------ model / data
 def build(args, device):
     from xggm_amd import param, synth
     from xggm_amd.lxrt.modeling import BertConfig, VISUAL_CONFIG
     from xggm_amd.vqa.vqacpv2_model import VQAModel
+    from xggm_amd.gqa.gqa_ood_model import GQAModel
     from xggm_amd.vqa.vqacpv2 import make_optimizer
     VISUAL_CONFIG.set_visual_dims(2048, 4)
     a = param.parse_args(["--llayers", "9", "--xlayers", "5", "--rlayers", "5"])
     torch.manual_seed(args.seed)
-    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    model = VQAModel(args.answers, gnn="GCN", n_layers=2, args=a, config=BertConfig(30522), compute_dtype=dt)
+    dt = torch.float32 if args.dtype == "f32" else torch.bfloat16
+    cls = GQAModel if args.order == "gqa" else VQAModel
+    model = cls(args.answers, gnn="GCN", n_layers=2, args=a, config=BertConfig(30522), compute_dtype=dt,
+                tokenizer=synthetic_tokenizer())
     model.seed = args.seed
     model = model.to(device)
+    if args.dtype == "fp8":
+        from xggm_amd.fp8 import enable_fp8
+        enable_fp8(model)
     rank = int(os.environ.get("RANK", 0))
     b = synth.vqa_batch(args.batch, A=args.answers, seed=1000 + rank)
     batch = {k: torch.from_numpy(v).to(device) for k, v in b.items() if k != "randn_adj"}
-    n_iters = args.steps + args.warmup + 16
-    optim = make_optimizer(model, 1e-6, 2 * n_iters)  # lr of script/vqacpv2.sh:26, t_total = 2 * iterations
+    n_iters = args.steps + args.warmup + 64
+    lr = 5e-6 if args.order == "gqa" else 1e-6  # script/gqa_ood.sh:27, script/vqacpv2.sh:26; t_total = 2 * iterations
+    optim = make_optimizer(model, lr, 2 * n_iters)
     return model, optim, batch
 
 
-def kernel_timing(trainer, branches):
-    """time every C-ABI launch of one un-captured iteration per branch with HIP events recorded
-    on the launch stream; a long sleep kernel is queued first so the host runs ahead and the
-    events bracket back-to-back GPU execution, not Python latency."""
+_WORDS = None
+
+
+def synthetic_tokenizer():
+    """a WordPiece tokenizer over a synthetic 30522-entry vocabulary (there is no bert-base-uncased vocab.txt
+    offline): the loader-inclusive leg feeds question STRINGS through the same host path the reference uses
+    (src/lxrt/entry.py:37-72)."""
+    import tempfile
+    from xggm_amd.lxrt.tokenization import BertTokenizer
+    global _WORDS
+    special = ["[PAD]"] + ["[unused%d]" % i for i in range(99)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"]
+    _WORDS = ["w%d" % i for i in range(30522 - len(special))]
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+        f.write("\n".join(special + _WORDS) + "\n")
+        path = f.name
+    try:
+        return BertTokenizer(path, do_lower_case=True)
+    finally:
+        os.unlink(path)
+
+
+class HostLoader:
+    """what the reference's DataLoaderX hands the loop (src/tools/data_loader.py:8-10, src/vqa/vqacpv2.py:164-171):
+    host batches (feats, boxes, sent strings, target, adj) -- here a ring of seeded synthetic batches in PINNED
+    memory, a different one every step.  ``stage(i)`` tokenises batch i and queues its H2D copies on a copy
+    stream into one of two device staging sets; ``commit()`` makes the trainer's static input buffers take the
+    staged batch (device-to-device, on the compute stream, behind the copy's event).  Staging batch i + 1 while
+    step i runs hides PCIe behind the step."""
+
+    def __init__(self, trainer, model, args, device, n_batches=8):
+        from xggm_amd import synth
+        rank = int(os.environ.get("RANK", 0))
+        rng = random.Random(args.seed + 77 * rank)
+        self.trainer, self.batcher = trainer, model.lxrt_encoder.batcher
+        self.host = []
+        for i in range(n_batches):
+            b = synth.vqa_batch(args.batch, A=args.answers, seed=5000 + 100 * rank + i)
+            hb = {k: torch.from_numpy(b[k]).pin_memory() for k in ("feats", "boxes", "target", "adj_true")}
+            hb["sent"] = [" ".join(rng.choice(_WORDS) for _ in range(rng.randint(3, 17))) for _ in range(args.batch)]
+            self.host.append(hb)
+        self.copy = torch.cuda.Stream()
+        keys = ("feats", "boxes", "target", "adj_true")
+        self.stage_bufs = [{k: torch.empty_like(trainer.static[k]) for k in keys} for _ in range(2)]
+        for s in self.stage_bufs:
+            s["ids"] = torch.empty((3,) + tuple(trainer.static["input_ids"].shape), dtype=torch.long, device=device)
+        self.events = [torch.cuda.Event(), torch.cuda.Event()]
+        self.free = [torch.cuda.Event(), torch.cuda.Event()]  # staging set consumed by the compute stream
+        self.slot = 0
+        self.staged = None
+        self.bytes = sum(v.numel() * v.element_size() for k, v in self.host[0].items() if k != "sent") + \
+            3 * 8 * trainer.static["input_ids"].numel()
+
+    def stage(self, i):
+        hb = self.host[i % len(self.host)]
+        s = self.slot
+        ids = self.batcher.host_batch(hb["sent"])  # cached WordPiece ids -> pinned [3, B, T]
+        self.copy.wait_event(self.free[s])
+        with torch.cuda.stream(self.copy):
+            for k in ("feats", "boxes", "target", "adj_true"):
+                self.stage_bufs[s][k].copy_(hb[k], non_blocking=True)
+            self.stage_bufs[s]["ids"].copy_(ids, non_blocking=True)
+            self.batcher.record_copy()
+            self.events[s].record(self.copy)
+        self.staged = s
+        self.slot ^= 1
+
+    def commit(self):
+        s = self.staged
+        main = torch.cuda.current_stream()
+        main.wait_event(self.events[s])
+        st, sb = self.trainer.static, self.stage_bufs[s]
+        for k in ("feats", "boxes", "target", "adj_true"):
+            st[k].copy_(sb[k], non_blocking=True)
+        st["input_ids"].copy_(sb["ids"][0], non_blocking=True)
+        st["input_mask"].copy_(sb["ids"][1], non_blocking=True)
+        st["segment_ids"].copy_(sb["ids"][2], non_blocking=True)
+        self.free[s].record(main)
+
+
+# ------------------------------------------------------------------------------------------ kernel timing
+def kernel_timing(run_passes):
+    """time every C-ABI launch of un-captured passes with HIP events recorded on the launch stream; a long sleep
+    kernel is queued first so the host runs ahead and the events bracket back-to-back GPU execution, not Python
+    latency.  ``run_passes``: list of callables, each one pass."""
     from xggm_amd import _lib
     import xggm_amd.ops as ops_mod
     rec = []
@@ -82,30 +230,33 @@ def kernel_timing(trainer, branches):
     def timed(name, *a):
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
-        work = 0.0
+        work, probs = 0.0, None
+        fam = name
         if name.startswith("xggm_gemm_grouped_"):
             probs = (ops_mod.GemmProblem * a[1]).from_address(a[0].value)
             work = sum(2.0 * p.M * p.N * p.K * p.batch for p in probs)
-            name = "xggm_gemm_" + name.rsplit("_", 1)[1]  # same kernel family as the single launches
+            fam = "xggm_gemm_" + name.rsplit("_", 1)[1]  # same kernel family as the single launches
+        elif name.startswith("xggm_gemm_fp8"):
+            work = 2.0 * a[3] * a[4] * a[5]
         elif name.startswith("xggm_gemm_"):
             work = 2.0 * a[3] * a[4] * a[5] * a[11]
         e0.record()
-        orig(name if not name.startswith("xggm_gemm_") or len(a) > 3 else "xggm_gemm_grouped_" + name.rsplit("_", 1)[1], *a)
+        orig(name, *a)
         e1.record()
         desc = ""
-        if os.environ.get("XGGM_DUMP_GEMMS") and name.startswith("xggm_gemm_"):
-            if len(a) == 3:
+        if os.environ.get("XGGM_DUMP_GEMMS") and fam.startswith("xggm_gemm_"):
+            if probs is not None:
                 desc = " + ".join("%dx%dx%d%s" % (p.M, p.N, p.K, "f" if p.c_f32 else "") for p in probs)
             else:
                 desc = "%dx%dx%d" % (a[3], a[4], a[5])
-        rec.append((name, a, e0, e1, work, desc))
+        rec.append((fam, a, e0, e1, work, desc))
 
-    for kind in ["plain"] + list(branches):
+    for run in run_passes:
         torch.cuda.synchronize()
         torch.cuda._sleep(int(5e7))  # head start for the host: launches queue up behind it
         ops_mod.call = timed
         try:
-            trainer._eager_pass(kind)
+            run()
         finally:
             ops_mod.call = orig
         torch.cuda.synchronize()
@@ -129,12 +280,19 @@ def kernel_timing(trainer, branches):
             f["bytes"] += a[5] * (16 + 12 + (2 if a[4] else 0))
         elif name == "xggm_sqnorm_f32":
             f["bytes"] += a[1] * 4
+        elif name.startswith("xggm_aggregate_"):
+            # x read once + out written once (T) + the fp32 adjacency read once
+            B, N, H = a[3], a[4], a[5]
+            es = 4 if name.endswith("f32") else 2
+            f["bytes"] += B * N * H * es * (3 if a[10] else 2) + B * N * N * 4
     return fam
 
 
 def cpu_baseline(args):
-    """the CPU oracle on ONE iteration (plain + relation pass, each fwd+bwd+clip+BertAdam) of the
-    same workload; weights are random (values do not affect the timing)."""
+    """the CPU oracle on a bounded sample of the same workload, per BASELINE.md section 3: configuration C2 (this
+    bench's batch) with the relation and the node branch timed separately (each iteration = plain pass + GGM
+    pass, each fwd + bwd + clip + BertAdam), and C1 (4 samples).  Weights are random (values do not affect the
+    timing).  ``value`` = the delta = 5 mix (mean of the two branch times)."""
     from oracle import shapes, xggm_oracle as O
     from xggm_amd import synth
     # the GPU box gives one GPU a 16-core CPU share; more threads than that only thrash
@@ -151,36 +309,64 @@ def cpu_baseline(args):
     M = {k: torch.zeros_like(v) for k, v in P.items()}
     V = {k: torch.zeros_like(v) for k, v in P.items()}
     step = {k: 0 for k in P}
-    b = synth.vqa_batch(args.batch, A=args.answers, seed=1000)
-    b["randn_node"] = synth.randn_nodes(args.batch, 36, 768, 0)
-    b = {k: torch.from_numpy(v) for k, v in b.items()}
-    t0 = time.perf_counter()
-    iters = 0
-    while iters < 8 and time.perf_counter() - t0 < 12.0:  # bounded sample: about 10-20 s of CPU work
-        O.train_pass(P, M, V, step, b, cfg, "plain", 1e-6, 100)
-        O.train_pass(P, M, V, step, b, cfg, "rel", 1e-6, 100, sigma=1.0, kl_weight=8.0, gnn="GCN")
-        iters += 1
-    dt = time.perf_counter() - t0
-    return {"value": round(iters * args.batch / dt, 3), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": "%d iterations (plain pass + relation-generation pass, each fwd+bwd+clip+BertAdam) at %d "
-                      "samples, fp32, full 9/5/5 model, torch CPU oracle, %.1f s" % (iters, args.batch, dt)}
+    kl = 12.0 if args.order == "gqa" else 8.0
+
+    def batch_of(B):
+        b = synth.vqa_batch(B, A=args.answers, seed=1000)
+        b["randn_node"] = synth.randn_nodes(B, 36, 768, 0)
+        return {k: torch.from_numpy(v) for k, v in b.items()}
+
+    def iteration(b, branch):
+        passes = [("plain", {}), (branch, dict(sigma=1.0, kl_weight=kl, gnn="GCN"))]
+        if args.order == "gqa":
+            passes.reverse()
+        for kind, kw in passes:
+            O.train_pass(P, M, V, step, b, cfg, kind, 1e-6, 100, **kw)
+
+    def timed(b, branch, budget, max_iters):
+        t0 = time.perf_counter()
+        n = 0
+        while n < max_iters and (n == 0 or time.perf_counter() - t0 < budget):
+            iteration(b, branch)
+            n += 1
+        return (time.perf_counter() - t0) / n, n
+
+    t_all = time.perf_counter()
+    b2, b1 = batch_of(args.batch), batch_of(4)
+    iteration(b1, "rel")  # warm-up: thread pool, allocator
+    s_rel, n_rel = timed(b2, "rel", 6.0, 3)
+    s_node, n_node = timed(b2, "node", 6.0, 3)
+    s_c1, n_c1 = timed(b1, "node", 3.0, 3)
+    mix = 0.5 * (s_rel + s_node)
+    return {"value": round(args.batch / mix, 3), "unit": "samples/s", "cores": cores, "kind": "port",
+            "by_branch": {"rel": {"s_per_iteration": round(s_rel, 3), "samples_per_s": round(args.batch / s_rel, 3)},
+                          "node": {"s_per_iteration": round(s_node, 3), "samples_per_s": round(args.batch / s_node, 3)}},
+            "c1_batch4": {"s_per_iteration": round(s_c1, 3), "samples_per_s": round(4 / s_c1, 3)},
+            "sample": "torch CPU oracle, fp32, full 9/5/5 model, A=%d, %s order: %d + %d iterations (plain pass + "
+                      "relation / node generation pass, each fwd+bwd+clip+BertAdam) at %d samples, %d at 4 samples "
+                      "(config C1); value = mean of the two branches; %.1f s in all"
+                      % (args.answers, args.order, n_rel, n_node, args.batch, n_c1, time.perf_counter() - t_all)}
 
 
 def pmc_traffic(family):
-    """HBM-side bytes per C-ABI launch of a kernel family, from the committed PMC passes
-    (profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this bench in separate eager
-    runs, gfx950 correction applied by tools/pmc_summary.py); None when no profile covers the family."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    """HBM-side bytes per C-ABI launch of a kernel family, from the committed PMC passes (profiles/*pmc_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this bench in separate eager runs, gfx950 correction applied by
+    tools/pmc_summary.py); the newest round's file that covers the family wins; None when none does."""
+    import glob
     key = {"xggm_gemm_bf16": "gemm_", "xggm_bertadam_f32": "bertadam_kernel", "xggm_ln_bwd_bf16": "ln_bwd_kernel",
-           "xggm_ln_fwd_bf16": "ln_fwd_kernel", "xggm_attn_bwd_bf16": "attn_bwd", "xggm_attn_fwd_bf16": "attn_fwd"}.get(family)
-    if key is None or not os.path.exists(path):
+           "xggm_ln_fwd_bf16": "ln_fwd_kernel", "xggm_attn_bwd_bf16": "attn_bwd", "xggm_attn_fwd_bf16": "attn_fwd",
+           "xggm_aggregate_bf16": "aggregate_kernel"}.get(family)
+    if key is None:
         return None
-    tot = n = 0.0
-    for name, r in json.load(open(path)).items():
-        if key in name:
-            tot += (r["read_bytes_per_launch"] + r["write_bytes_per_launch"]) * r["launches"]
-            n += r["launches"]
-    return round(tot / n) if n else None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
+        tot = n = 0.0
+        for name, r in json.load(open(path)).items():
+            if key in name:
+                tot += (r["read_bytes_per_launch"] + r["write_bytes_per_launch"]) * r["launches"]
+                n += r["launches"]
+        if n:
+            return round(tot / n)
+    return None
 
 
 def log(msg):
@@ -191,9 +377,134 @@ def log(msg):
 T_START = time.perf_counter()
 
 
+def roofline_of(fam, prefer=None):
+    tot = sum(f["ms"] for f in fam.values())
+    kernels = {k: {"ms": round(f["ms"], 3), "launches": f["n"], "share": round(f["ms"] / tot, 4)}
+               for k, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])[:8]}
+    dom = prefer if prefer in fam else max(fam, key=lambda k: fam[k]["ms"])
+    f = fam[dom]
+    if dom.startswith("xggm_gemm_"):
+        ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
+        roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(dom),
+                    "launches": f["n"], "avg_us": round(1000 * f["ms"] / f["n"], 2)}
+    else:
+        ach = f["bytes"] / (f["ms"] * 1e-3) / 1e9 if f["bytes"] else 0.0
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
+                    "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": pmc_traffic(dom),
+                    "launches": f["n"], "avg_us": round(1000 * f["ms"] / f["n"], 2)}
+    for k in ("xggm_bertadam_f32", "xggm_aggregate_bf16"):  # the HBM-bound families: always with their rate
+        if k in fam and fam[k]["ms"] > 0 and fam[k]["bytes"]:
+            kernels.setdefault(k, {"ms": round(fam[k]["ms"], 3), "launches": fam[k]["n"],
+                                   "share": round(fam[k]["ms"] / tot, 4)})
+            kernels[k]["GB/s"] = round(fam[k]["bytes"] / (fam[k]["ms"] * 1e-3) / 1e9, 1)
+    return roofline, kernels
+
+
+# ------------------------------------------------------------------------------------------ C4: generator stress
+def main_c4(args, device):
+    """BASELINE configs[3]: the graph generator alone on 64 objects x 64 x 64 adjacency, batch 64: forward +
+    backward of GCNGenerator(768, 2) (src/module/graph_generative_modeling.py:199-233) per step, captured into a
+    hipGraph; roofline = the LDS-tiled aggregate kernel (out = adj @ x per sample) against HBM."""
+    from xggm_amd import synth
+    from xggm_amd.module.graph_generative_modeling import GCNGenerator
+    from xggm_amd.runtime import bind_root, runtime_of
+    B, N, H = args.batch, 64, 768
+    torch.manual_seed(args.seed)
+    gen = GCNGenerator(hidden_dim=H, n_layers=2)
+    bind_root(gen, torch.float32 if args.dtype == "f32" else torch.bfloat16)
+    gen = gen.to(device).train()
+    x_np, adj_np = synth.generator_inputs("c4", "GCN", B, N, H, 0)
+    dt = torch.float32 if args.dtype == "f32" else torch.bfloat16
+    x = torch.from_numpy(x_np).to(device=device, dtype=dt).requires_grad_(True)
+    adj = torch.from_numpy(adj_np).to(device).requires_grad_(True)
+    rt = runtime_of(gen)
+    gx = torch.randn(B, N, H, device=device, dtype=dt) / (N * H) ** 0.5
+    ga = torch.randn(B, N, N, device=device) / N
+
+    def step():
+        gen.zero_grad()
+        rt.arena.begin_pass()
+        x.grad = adj.grad = None
+        xo, ao = gen(x, adj)
+        torch.autograd.backward([xo, ao], [gx, ga])
+        rt.advance()
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = None
+    if not args.no_graph:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+    run = graph.replay if graph is not None else step
+    for _ in range(args.warmup):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    dtm = time.perf_counter() - t0
+    ms_step = 1000.0 * dtm / args.steps
+    value = B * args.steps / dtm
+    log("c4 timed region: %.3f ms/step, %.1f samples/s" % (ms_step, value))
+    roofline = kernels = None
+    if not args.no_kernel_timing:
+        fam = kernel_timing([step])
+        roofline, kernels = roofline_of(fam, prefer="xggm_aggregate_" + ("f32" if args.dtype == "f32" else "bf16"))
+    cpu = None
+    if not args.no_cpu_baseline:
+        cpu = cpu_baseline_c4(args, B, N, H)
+    print(json.dumps({
+        "metric": "generator fwd+bwd samples/sec (64-obj x 64 adjacency stress, BASELINE configs[3])",
+        "value": round(value, 2), "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "C4 stress: GCNGenerator(768, 2 layers) forward + backward, batch=%d, 64 objects x 64 x 64 "
+                               "adjacency, 1 GPU, dropout on" % B, "global_batch": B, "parallelism": "dp1",
+                   "hip_graph": graph is not None},
+        "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu}))
+
+
+def cpu_baseline_c4(args, B, N, H):
+    from oracle import shapes, xggm_oracle as O
+    from xggm_amd import synth
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
+    torch.set_num_threads(cores)
+    P = {k: torch.from_numpy(synth.seeded_param(k, s, 0)).requires_grad_(True)
+         for k, s in shapes.generator_shapes("GCN", H, 2).items()}
+    x_np, adj_np = synth.generator_inputs("c4", "GCN", B, N, H, 0)
+    x = torch.from_numpy(x_np).requires_grad_(True)
+    adj = torch.from_numpy(adj_np).requires_grad_(True)
+    t0 = time.perf_counter()
+    n = 0
+    while n < 20 and (n < 2 or time.perf_counter() - t0 < 10.0):
+        xo, ao = O.gcn_generator(P, "generator.", x, adj, 2)
+        torch.autograd.grad([xo.sum() + ao.sum()], [x, adj] + list(P.values()))
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(B * n / dt, 2), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "torch CPU oracle gcn_generator forward + backward, fp32, batch %d, N=%d: %d steps, %.1f s"
+                      % (B, N, n, dt)}
+
+
+# ------------------------------------------------------------------------------------------ the training step
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", 1))
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        spawn_ranks(args)  # does not return
+    world = int(env_world or 1)
+    if world != args.gpus and not os.environ.get("XGGM_DP_FORCE"):
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d; launch with `python bench.py --gpus N` (spawns the "
+                         "ranks) or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`"
+                         % (args.gpus, world))
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     if os.environ.get("XGGM_SHARE_GPU"):  # several ranks on one GPU (logic rehearsal only)
@@ -202,11 +513,16 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    if args.workload == "c4":
+        if world > 1:
+            raise SystemExit("bench.py --workload c4 is a one-GPU configuration")
+        return main_c4(args, device)
     force_dp = world == 1 and bool(os.environ.get("XGGM_DP_FORCE"))  # one-rank RCCL rehearsal of the N > 1 path
     if force_dp:
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+    backend = None
     if world > 1 or force_dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -215,6 +531,7 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == world
     from xggm_amd.engine import CapturedTrainer
     from xggm_amd.runtime import runtime_of
     if os.environ.get("XGGM_GROUP_TILE"):  # A/B hook: pin the tile of grouped GEMM launches (1: 64x64, 2: 128x64, 3: 128x128)
@@ -226,10 +543,12 @@ def main():
     log("model on %s" % device)
     # first forward creates the arena; data parallel hooks need it
     rt = runtime_of(model)
+    zero1 = False
     if world > 1 or force_dp:
         from xggm_amd.vqa.vqacpv2 import enable_data_parallel
-        enable_data_parallel(model, wire_dtype=torch.bfloat16 if args.wire == "bf16" else None)
-    trainer = CapturedTrainer(model, optim, batch, sigma=1.0, order="vqa", use_graph=not args.no_graph)
+        zero1 = bool(args.zero1) if args.zero1 is not None else False
+        enable_data_parallel(model, wire_dtype=torch.bfloat16 if args.wire == "bf16" else None, zero1=zero1)
+    trainer = CapturedTrainer(model, optim, batch, sigma=1.0, order=args.order, use_graph=not args.no_graph)
     log("trainer ready (hip_graph=%s)" % (not args.no_graph))
     pyrng = random.Random(args.seed)  # identical draws on every rank (src/vqa/vqacpv2.py:192)
 
@@ -242,6 +561,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(dt):
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return dt
+
     for _ in range(args.warmup):
         trainer.iteration(branch())
     barrier()
@@ -250,26 +577,44 @@ def main():
     for _ in range(args.steps):
         trainer.iteration(branch())
     barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(time.perf_counter() - t0)
     ms_step = 1000.0 * dt / args.steps
     value = args.batch * world * args.steps / dt
     log("timed region: %.3f ms/step, %.1f samples/s" % (ms_step, value))
 
+    # the same steps with the loader boundary inside the timed region (never `value`)
+    with_loader = None
+    if not args.no_loader:
+        loader = HostLoader(trainer, model, args, device)
+        for i in range(3):
+            loader.stage(i)
+            loader.commit()
+            trainer.iteration(branch())
+        loader.stage(0)
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            loader.commit()             # batch i: staged while step i - 1 ran
+            trainer.iteration(branch())
+            loader.stage(i + 1)         # batch i + 1: tokenise + H2D on the copy stream, under step i
+        barrier()
+        dtl = max_over_ranks(time.perf_counter() - t1)
+        with_loader = {"value": round(args.batch * world * args.steps / dtl, 2),
+                       "ms_per_step": round(1000.0 * dtl / args.steps, 3), "host_bytes_per_step": loader.bytes,
+                       "what": "fresh pinned host batch every step: cached WordPiece tokenisation of %d question "
+                               "strings, H2D on a copy stream into double-buffered staging, device-side hand-over "
+                               "to the captured graphs' input buffers" % args.batch}
+        log("with loader: %.3f ms/step" % with_loader["ms_per_step"])
+
     # per-branch step time (diagnostic; not part of the timed region)
     per_branch = {}
-    if rank == 0 or world > 1:
-        for br in ("rel", "node"):
-            barrier()
-            t1 = time.perf_counter()
-            for _ in range(5):
-                trainer.iteration(br)
-            barrier()
-            per_branch[br] = round(1000.0 * (time.perf_counter() - t1) / 5, 3)
+    for br in ("rel", "node"):
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            trainer.iteration(br)
+        barrier()
+        per_branch[br] = round(1000.0 * (time.perf_counter() - t1) / 5, 3)
 
     # per-pass time: forward + backward + clip + BertAdam of ONE pass (SURVEY section 8d asks for both views)
     per_pass = {}
@@ -286,31 +631,13 @@ def main():
         # EVERY rank runs the instrumented passes (they contain the gradient exchange: a rank that skipped them
         # would leave the others waiting in a collective); rank 0 reports
         log("kernel timing pass")
-        fam = kernel_timing(trainer, ["rel", "node"])
-    if rank == 0 and not args.no_kernel_timing:
-        tot = sum(f["ms"] for f in fam.values())
-        kernels = {k: {"ms": round(f["ms"], 3), "launches": f["n"], "share": round(f["ms"] / tot, 4)}
-                   for k, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])[:8]}
-        dom = max(fam, key=lambda k: fam[k]["ms"])
-        f = fam[dom]
-        if dom.startswith("xggm_gemm_"):
-            ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
-            roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(dom),
-                        "launches": f["n"], "avg_us": round(1000 * f["ms"] / f["n"], 2)}
-        else:
-            ach = f["bytes"] / (f["ms"] * 1e-3) / 1e9 if f["bytes"] else 0.0
-            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
-                        "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": pmc_traffic(dom),
-                        "launches": f["n"], "avg_us": round(1000 * f["ms"] / f["n"], 2)}
-        # the optimiser is the HBM-bound half of the step: always report it too
-        if "xggm_bertadam_f32" in fam and fam["xggm_bertadam_f32"]["ms"] > 0:
-            fo = fam["xggm_bertadam_f32"]
-            kernels["xggm_bertadam_f32"]["GB/s"] = round(fo["bytes"] / (fo["ms"] * 1e-3) / 1e9, 1)
+        fam = kernel_timing([lambda k=k: trainer._eager_pass(k) for k in ("plain", "rel", "node")])
+        if rank == 0:
+            roofline, kernels = roofline_of(fam)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        log("cpu baseline (oracle, one iteration)")
+        log("cpu baseline (oracle)")
         cpu = cpu_baseline(args)
         log("cpu baseline done: %s" % cpu["value"])
 
@@ -320,16 +647,19 @@ def main():
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "%dxMI355X %s: VQA-CP-v2-shaped synthetic batch=%d/GPU, 36 objects x 2048, "
-                                   "20 tokens, A=%d, LXMERT 9/5/5 + GCNx2, full fwd+bwd+clip+BertAdam x2 passes, "
-                                   "dropout on, delta=%d branch mix" % (world, args.dtype, args.batch, args.answers,
-                                                                        args.delta),
-                       "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                       "hip_graph": not args.no_graph, "grad_wire": args.wire if world > 1 else None},
-            "ms_per_step_by_branch": per_branch, "ms_per_pass": per_pass,
+            "config": {"workload": "%dxMI355X %s: %s-shaped synthetic batch=%d/GPU, 36 objects x 2048, "
+                                   "20 tokens, A=%d, LXMERT 9/5/5 + GCNx2, full fwd+bwd+clip+BertAdam x2 passes "
+                                   "(%s), dropout on, delta=%d branch mix"
+                                   % (world, args.dtype, "GQA-OOD" if args.order == "gqa" else "VQA-CP-v2", args.batch,
+                                      args.answers, "GGM pass first, KL x 12" if args.order == "gqa" else
+                                      "plain pass first, KL x 8", args.delta),
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "order": args.order,
+                       "world_size": world, "backend": backend, "zero1": zero1,
+                       "hip_graph": not args.no_graph, "grad_wire": args.wire if (world > 1 or force_dp) else None},
+            "ms_per_step_by_branch": per_branch, "ms_per_pass": per_pass, "value_with_loader": with_loader,
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
         }
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1 or force_dp:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -95,7 +95,8 @@ def test_full_size_iteration_properties():
     import bench
     from xggm_amd.engine import CapturedTrainer
     from xggm_amd.runtime import runtime_of
-    args = types.SimpleNamespace(batch=32, answers=2274, steps=4, warmup=0, dtype="bf16", seed=9595)
+    args = bench.parse(["--steps", "4", "--warmup", "0"])  # the defaults ARE configs[1]: 32 samples, A = 2274, bf16
+    assert (args.batch, args.answers, args.dtype, args.order, args.seed) == (32, 2274, "bf16", "vqa", 9595)
     traj = []
     for rep in range(2):
         model, optim, batch = bench.build(args, torch.device("cuda", 0))
@@ -165,6 +166,65 @@ def test_bench_on_a_one_rank_rccl_group():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["steps"] == 2 and line["value"] > 0 and line["config"]["hip_graph"] is True
     assert set(line["ms_per_pass"]) == {"plain", "rel", "node"} and all(v > 0 for v in line["ms_per_pass"].values())
+
+
+def _run_bench(args, env_extra=None, timeout=1200):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **(env_extra or {}))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):  # a launcher's variables must not leak into the child
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True,
+                       timeout=timeout, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_spawns_two_ranks():
+    """`python bench.py --gpus 2` with no launcher: the parent spawns the two ranks itself (before any GPU call) and
+    rank 0 prints the line.  Here both ranks share the one GPU of the box and exchange over gloo (XGGM_SHARE_GPU,
+    XGGM_DIST_BACKEND): the process group, the staged exchange, the max-over-ranks timing and the JSON are those
+    of the real N = 2 run, only the transport differs."""
+    line = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8", "--no-cpu-baseline",
+                       "--no-kernel-timing"], {"XGGM_DIST_BACKEND": "gloo", "XGGM_SHARE_GPU": "1"})
+    assert line["n_gpus"] == 2 and line["config"]["world_size"] == 2 and line["config"]["backend"] == "gloo"
+    assert line["config"]["global_batch"] == 16 and line["config"]["parallelism"] == "dp2"
+    assert line["value"] > 0 and line["scaling"] == "weak" and line["steps"] == 2
+    assert line["value_with_loader"]["value"] > 0
+
+
+def test_bench_rejects_a_world_size_that_contradicts_gpus():
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       timeout=300, env=env, cwd=root)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_bench_gqa_order_line():
+    """BASELINE configs[2] per GPU: GQA-OOD-shaped workload (GGM pass first, KL x 12, A = 1842; src/gqa/gqa_ood.py:165-292)"""
+    line = _run_bench(["--gpus", "1", "--order", "gqa", "--answers", "1842", "--steps", "3", "--warmup", "1",
+                       "--no-cpu-baseline"])
+    assert line["n_gpus"] == 1 and line["config"]["order"] == "gqa" and "A=1842" in line["config"]["workload"]
+    assert "GGM pass first" in line["config"]["workload"] and line["value"] > 0
+    assert line["roofline"]["frac"] > 0 and line["value_with_loader"]["value"] > 0
+
+
+def test_bench_c4_stress_line():
+    """BASELINE configs[3]: 64 objects x 64 adjacency, batch 64, aggregate kernel against the HBM roofline"""
+    line = _run_bench(["--workload", "c4", "--steps", "10", "--warmup", "2"])
+    assert line["config"]["global_batch"] == 64 and "64 objects" in line["config"]["workload"]
+    rf = line["roofline"]
+    assert rf["kernel"] == "xggm_aggregate_bf16" and rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["achieved"] > 0
+    assert line["cpu_baseline"]["value"] > 0 and line["value"] > line["cpu_baseline"]["value"]
 
 
 def test_training_state_restored_under_live_graphs(tmp_path):

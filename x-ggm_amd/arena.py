@@ -92,6 +92,7 @@ class ParamArena:
         self.sqnorm = torch.zeros(1, device=dev, dtype=torch.float32)
         self.group_index = {g: i for i, g in enumerate(order)}
         self.pending_clip = None  # max_norm registered by clip_grad_norm_, consumed by BertAdam.step
+        self.zero1 = None         # dist.ShardedUpdate when the update is sharded over data-parallel ranks
         self.touched = set()
         self.vec_zeroed = False
         self.all_dirty = True

@@ -273,7 +273,9 @@ class CapturedPredictor:
             for i in range(3):
                 s["ids"][i, :b].copy_(sent[i], non_blocking=True)
         else:
-            s["ids"][:, :b].copy_(self.model.lxrt_encoder.batcher.host_batch(list(sent)), non_blocking=True)
+            batcher = self.model.lxrt_encoder.batcher
+            s["ids"][:, :b].copy_(batcher.host_batch(list(sent)), non_blocking=True)
+            batcher.record_copy()  # the pinned buffer is not rewritten before this copy has read it
         s["feats"][:b].copy_(feats, non_blocking=True)
         s["boxes"][:b].copy_(boxes, non_blocking=True)
         if self.graph is not None:

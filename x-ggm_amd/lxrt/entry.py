@@ -39,12 +39,19 @@ class SentenceBatcher:
     questions repeat (every epoch, and many VQA questions are shared between images), so token ids are cached
     per sentence; the batch is assembled in ONE int64 [3, B, T] pinned host buffer and crosses PCIe as one
     asynchronous copy instead of three ``torch.tensor(list, device=...)`` calls.  Results are identical to
-    ``convert_sents_to_features`` (tests/test_abi_cpu.py)."""
+    ``convert_sents_to_features`` (tests/test_abi_cpu.py).
 
-    def __init__(self, tokenizer, max_seq_length, max_cached=1 << 20):
+    The pinned buffers form a ring (``depth`` of them), each guarded by an event recorded behind the H2D copy
+    that read it last: a buffer is rewritten only after that copy has completed, however far the host runs
+    ahead of the GPU (every iteration tokenises at least twice: plain pass and GGM pass)."""
+
+    def __init__(self, tokenizer, max_seq_length, max_cached=1 << 20, depth=4):
         self.tok, self.T, self.max_cached = tokenizer, max_seq_length, max_cached
         self.cache = {}
-        self._pinned = None
+        self.depth = depth
+        self._ring = []     # [pinned tensor, numpy view, event of the last copy out of it | None]
+        self._next = 0
+        self._last = None   # ring entry handed out by the latest host_batch
 
     def ids_of(self, sent):
         ids = self.cache.get(sent)
@@ -55,26 +62,51 @@ class SentenceBatcher:
                 self.cache[sent] = ids
         return ids
 
-    def host_batch(self, sents):
-        """int64 [3, B, T] host tensor: ids, mask, segment ids (pinned when a GPU is present)."""
-        B = len(sents)
-        buf = self._pinned
-        if buf is None or buf.shape[1] < B:
+    def _entry(self, B):
+        if self._ring and self._ring[0][0].shape[1] < B:
+            for e in self._ring:  # a larger batch than the ring was built for: drain, then rebuild
+                if e[2] is not None:
+                    e[2].synchronize()
+            self._ring, self._next = [], 0
+        if len(self._ring) < self.depth:
             buf = torch.zeros((3, max(B, 32), self.T), dtype=torch.long)
             if torch.cuda.is_available():
                 buf = buf.pin_memory()
-            self._pinned, self._np = buf, buf.numpy()  # numpy view: row fills without per-row tensor objects
-        arr = self._np
+            self._ring.append([buf, buf.numpy(), None])  # numpy view: row fills without per-row tensor objects
+            return self._ring[-1]
+        e = self._ring[self._next]
+        self._next = (self._next + 1) % self.depth
+        if e[2] is not None:
+            e[2].synchronize()  # the copy that read this buffer last has finished
+            e[2] = None
+        return e
+
+    def host_batch(self, sents):
+        """int64 [3, B, T] host tensor: ids, mask, segment ids (pinned when a GPU is present).  A caller that ships
+        it with its own asynchronous copy calls ``record_copy()`` right behind that copy."""
+        B = len(sents)
+        e = self._entry(B)
+        buf, arr = e[0], e[1]
         arr[:2, :B] = 0
         for b, s in enumerate(sents):
             ids = self.ids_of(s)
             n = len(ids)
             arr[0, b, :n] = ids
             arr[1, b, :n] = 1
+        self._last = e
         return buf[:, :B]
+
+    def record_copy(self, stream=None):
+        """mark the buffer of the latest ``host_batch`` as in flight on ``stream`` (default: the current one)"""
+        if self._last is not None and torch.cuda.is_available():
+            ev = torch.cuda.Event()
+            ev.record(stream if stream is not None else torch.cuda.current_stream())
+            self._last[2] = ev
 
     def __call__(self, sents, device):
         dev = self.host_batch(sents).to(device, non_blocking=True)
+        if dev.is_cuda:
+            self.record_copy()
         return dev[0], dev[1], dev[2]
 
 

@@ -58,21 +58,35 @@ def remove_diagonal(adj_true):
     return adj_true.triu(1) + adj_true.tril(-1)
 
 
-def enable_data_parallel(model, group=None, wire_dtype=None, overlap=None):
+def enable_data_parallel(model, group=None, wire_dtype=None, overlap=None, zero1=False):
     """one process per GPU: average the flat gradient arena over ``group`` between backward and
     the fused clip + BertAdam of every pass (xggm_amd.dist.GradSync); replicas start equal.
     ``overlap`` (default on; XGGM_DP_OVERLAP=0 turns it off): cut the backward between the single-modality
     and the cross-modality layers so the all-reduce of the upper 60 % of the gradients runs under the
-    backward of the lower layers (engine.CapturedTrainer)."""
+    backward of the lower layers (engine.CapturedTrainer).  ``zero1``: shard the update (dist.ShardedUpdate:
+    reduce-scatter of the matrix gradients, BertAdam on this rank's 1/world of every matrix range, all-gather
+    of the bf16 weights the GEMMs read).
+    Every rank draws its OWN dropout masks and denoising noise (the Philox seed is folded with the rank): the
+    averaged gradient is then that of one batch of world x B samples with independent noise; only the host-side
+    branch decision is shared (``pick_branch``)."""
     import os
+    import torch.distributed as dist
     from ..dist import GradSync, broadcast_params
     rt = runtime_of(model)
     broadcast_params(rt.arena, group)
-    object.__setattr__(model, "_grad_sync", GradSync(rt.arena.grads, group, wire_dtype))
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if rank:
+        # seed word of the device-resident {seed, offset} pair; saved / restored with the training state
+        rt.rng[0] = (int(rt.rng[0].item()) + rank * 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF
+    gs = GradSync(rt.arena.grads, group, wire_dtype)
+    object.__setattr__(model, "_grad_sync", gs)
     rt.arena.sq_enabled = False  # the clip norm is that of the AVERAGED gradients: read them after the exchange
     if overlap is None:
         overlap = os.environ.get("XGGM_DP_OVERLAP", "1") != "0"
     rt.cut_enabled = bool(overlap)
+    if zero1 and (gs.world > 1 or gs.force):
+        from ..dist import ShardedUpdate
+        rt.arena.zero1 = ShardedUpdate(rt.arena, group)
     return model
 
 
@@ -156,9 +170,16 @@ def ggm_pass(model, optim, bce_loss, feats, boxes, sent, target, adj_true, branc
     return out
 
 
-def pick_branch(delta, rng=random):
-    """random.randint(1, 10) <= args.delta -> relation generation (src/vqa/vqacpv2.py:192-193)"""
-    return "rel" if rng.randint(1, 10) <= delta else "node"
+def pick_branch(delta, rng=random, model=None):
+    """random.randint(1, 10) <= args.delta -> relation generation (src/vqa/vqacpv2.py:192-193).  With data
+    parallelism (``model`` carries a gradient exchange) every rank takes RANK 0's draw: ranks on different
+    branches would exchange different parameter ranges (encoder_adj vs node_fc) and hang or mix gradients."""
+    rel = rng.randint(1, 10) <= delta
+    gs = getattr(model, "_grad_sync", None) if model is not None else None
+    if gs is not None and gs.world > 1:
+        from ..dist import sync_branch
+        rel = sync_branch(rel, gs.g.device, gs.group)
+    return "rel" if rel else "node"
 
 
 def train_iteration(model, optim, bce_loss, batch, delta=5, sigma=1.0, order="vqa", branch=None, clip=5.0):
@@ -168,7 +189,7 @@ def train_iteration(model, optim, bce_loss, batch, delta=5, sigma=1.0, order="vq
     rt = runtime_of(model)
     model.train()
     if branch is None:
-        branch = pick_branch(delta)
+        branch = pick_branch(delta, model=model)
     args = (batch["feats"], batch["boxes"], batch["sent"], batch["target"])
     out = {}
     if order == "vqa":
