@@ -95,6 +95,17 @@ typedef struct xggm_gemm_problem {
      * by one workgroup, so a fixed-order sum of the slots is the squared norm of the weight gradient without another
      * pass over it (nn.utils.clip_grad_norm_, src/vqa/vqacpv2.py:175). */
     float* sqsum;
+    /* e4m3 side of the mixed-precision forward (xggm_gemm_grouped_fp8e4m3 reads scale_a / scale_b; every bf16-output
+     * kernel honours c8): scale_a, scale_b: device scalars, the reciprocals of the per-tensor quantisation scales of
+     * A and B (NULL = 1).  c8 (or NULL): a second copy of the stored result as OCP e4m3 bytes, layout of C, each
+     * value multiplied by *c8_qscale (NULL = 1) and saturated to +-448 -- the operand of the NEXT forward product,
+     * written by its producer instead of by a quantisation pass; *c8_amax (or NULL) is raised to max |value| (one
+     * atomic per workgroup; feeds the delayed scale update, xggm_fp8_scale_update). */
+    const float* scale_a;
+    const float* scale_b;
+    void* c8;
+    const float* c8_qscale;
+    float* c8_amax;
 } xggm_gemm_problem;
 int xggm_gemm_grouped_f32(const xggm_gemm_problem* probs, int n, xggm_stream_t stream);
 int xggm_gemm_grouped_bf16(const xggm_gemm_problem* probs, int n, xggm_stream_t stream);
@@ -109,6 +120,28 @@ int xggm_gemm_grouped_bf16(const xggm_gemm_problem* probs, int n, xggm_stream_t 
 int xggm_gemm_fp8e4m3(const void* A, const void* B, void* C, int M, int N, int K, int64_t a_rs, int64_t b_ns, int64_t ldc,
                       const float* scale_a, const float* scale_b, const float* bias, const void* residual, void* preact,
                       int act, int c_f32, xggm_stream_t stream);
+/* The same product for up to 4 problems in one launch (the language and the vision stream of a layer, the two
+ * directions of a cross-attention layer): every problem has e4m3 operands A [M, K] / B [N, K], k contiguous (a_ks =
+ * b_ks = 1, strides in elements = bytes, multiples of 16 like K), its own scale_a / scale_b, and the bf16 epilogue of
+ * xggm_gemm_grouped_bf16 (bias, GELU + pre-activation, residual, fp32 split-K slabs through batch / c_f32, c8).  Not
+ * for the backward: dgrad / wgrad stay bf16. */
+int xggm_gemm_grouped_fp8e4m3(const xggm_gemm_problem* probs, int n, xggm_stream_t stream);
+/* Delayed per-tensor scaling of the e4m3 operands: one table (amax, history, qscale, dscale = 1 / qscale) whose
+ * entries are weight operands and activation sites.  Protocol of the producers (LayerNorm / GELU epilogue /
+ * attention output / BertAdam): an entry with qscale <= 0 is uncalibrated -- they quantise with 1 and record every
+ * maximum; otherwise they quantise with qscale and record the maximum of the step in amax only when it exceeds half
+ * (BertAdam: three quarters) of the representable range 448 / qscale: e4m3 is a floating-point format, so a stale
+ * SMALLER maximum costs no precision and only a larger one saturates, and the same-address atomics stay rare.
+ * This call, for the n entries the pointers address (amax, qscale, dscale: n floats; hist: n x hist_len):
+ *   hist[i][*pos % hist_len] = amax[i]; amax[i] = 0; m = max_j hist[i][j];
+ *   m > 0: qscale[i] = 448 / (margin * m)          (range = margin x the largest recent maximum)
+ *   m == 0, shrink != 0, history just wrapped: qscale[i] *= 2   (nothing near the range for hist_len calls)
+ *   dscale[i] = 1 / qscale[i];   bump != 0: *pos += 1.
+ * Activation sites: once per pass, margin 1.25, shrink, bump.  Weight operands: for the parameter groups a pass
+ * updates, BEFORE xggm_bertadam_ex writes their e4m3 copies with the new scale (margin 4/3, no shrink, no bump).
+ * Everything is device-resident (graph replay); n <= 1024. */
+int xggm_fp8_scale_update(float* amax, float* hist, float* qscale, float* dscale, int64_t* pos, int n, int hist_len,
+                          float margin, int shrink, int bump, xggm_stream_t stream);
 /* y[i] = e4m3fn(clamp(x[i] * *qscale, -448, 448)), round-to-nearest-even; x fp32 / bf16, n % 8 == 0; qscale: device
  * scalar or null (1); amax: device scalar or null, raised to max |x| (atomic; the caller zeroes it): the next
  * step's scale without another pass over x. */
@@ -172,6 +205,11 @@ typedef struct xggm_attn_problem {
     float* dbq;
     float* dbk;
     float* dbv;
+    /* forward, bf16 storage only: out8 (or NULL) = e4m3 copy of `out` scaled by *qscale (NULL = 1), rows of o_rs
+     * bytes -- the A operand of the fp8 output projection; *amax (or NULL) raised to max |out| */
+    void* out8;
+    const float* qscale;
+    float* amax;
 } xggm_attn_problem;
 int xggm_attn_fwd_grouped_f32(const xggm_attn_problem* probs, int n, int head_dim, const uint64_t* rng, xggm_stream_t stream);
 int xggm_attn_fwd_grouped_bf16(const xggm_attn_problem* probs, int n, int head_dim, const uint64_t* rng, xggm_stream_t stream);
@@ -225,6 +263,11 @@ typedef struct xggm_ln_fwd_problem {
      * GEMM, xggm_gemm_* with batch = in_slabs, c_f32 = 1): the row kernel adds them in order on the way in, so
      * the GEMM gets in_slabs times the workgroups and no reduction pass exists.  0: `in` is T [M][H]. */
     int in_slabs;
+    /* out8 (or NULL; bf16 storage only): e4m3 copy of `out` scaled by *qscale (NULL = 1), [M][H] bytes -- the A operand
+     * of the following fp8 product (QKV / FFN input); *amax (or NULL) is raised to max |out| (one atomic per workgroup). */
+    void* out8;
+    const float* qscale;
+    float* amax;
 } xggm_ln_fwd_problem;
 typedef struct xggm_ln_bwd_problem {
     const void* dy;
@@ -395,6 +438,38 @@ int xggm_sqnorm_f32(const float* g, int64_t n, float* out, float* ws, xggm_strea
 int xggm_bertadam_f32(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, const float* sqnorm,
                       float max_norm, float lr, const float* lr_scale, float b1, float b2, float eps, float weight_decay,
                       xggm_stream_t stream);
+/* The same update with everything a deployment variant needs, as one argument block (HOST struct, copied):
+ *  - g_bf16 != 0: `g` holds bf16 gradients (the data-parallel wire arena the weight-gradient GEMMs write and
+ *    RCCL reduces in place: no fp32 copy of the matrix gradients exists);
+ *  - lr_dev (or NULL): device scalar that replaces `lr` (edits of param_groups[i]['lr'] reach replayed graphs);
+ *  - shadow8 (or NULL): e4m3 copy of the updated weights for the fp8 forward products, written in the same pass.
+ *    Per-tensor scales: w8_id[(elem0 + i) >> 8] (uint16 per 256-element chunk of the arena, 0 = this chunk has no
+ *    e4m3 copy) selects the entry of w8_qscale the value is multiplied by, and w8_amax[id] is raised to max |p_new|
+ *    for the next scale update (xggm_fp8_scale_update).  `elem0`: arena offset of p[0], a multiple of 256 when
+ *    shadow8 is given. */
+typedef struct xggm_adam_args {
+    float* p;
+    const void* g;
+    float* m;
+    float* v;
+    void* shadow_bf16;
+    int64_t n;
+    const float* sqnorm;
+    float max_norm;
+    float lr;
+    const float* lr_dev;
+    const float* lr_scale;
+    float b1, b2, eps, weight_decay;
+    int g_bf16;
+    void* shadow8;
+    const uint16_t* w8_id;
+    const float* w8_qscale;
+    float* w8_amax;
+    int64_t elem0;
+} xggm_adam_args;
+int xggm_bertadam_ex(const xggm_adam_args* args, xggm_stream_t stream);
+/* *out += sum g^2 of a flat bf16 range (the wire arena), same fixed summation order as xggm_sqnorm_f32 */
+int xggm_sqnorm_bf16(const void* g, int64_t n, float* out, float* ws, xggm_stream_t stream);
 /* *lr_scale = warmup_linear(*step / t_total, warmup); *step += 1 (optimization.py:42-48) */
 int xggm_sched_step(int64_t* step, float* lr_scale, int64_t t_total, float warmup, xggm_stream_t stream);
 /* the same for n <= 16 distinct counters steps[index[i]] / lr_scale[index[i]] of one table in one launch (all

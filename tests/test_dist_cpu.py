@@ -109,24 +109,7 @@ def test_stage_ranges_tile_the_full_size_arena():
             return n
 
     named = [(k, FakeParam(v)) for k, v in shapes.model_shapes(shapes.FULL, 2274).items()]
-    order, groups, info, off = [], {}, {}, 0
-    for n, p in named:
-        g = A.default_group_of(n, FakeModel)
-        if g not in order:
-            order.append(g)
-    for gname in order:
-        grp = G()
-        grp.start = off = A._align(off)
-        members = [(n, p) for n, p in named if A.default_group_of(n, FakeModel) == gname]
-        for atomic in (False, True):
-            if atomic:
-                grp.vec_start = off
-            for n, p in members:
-                if A.is_atomic(n, p) == atomic:
-                    info[n] = (off, p.numel(), gname, atomic)
-                    off = A._align(off + p.numel())
-        grp.end = off
-        groups[gname] = grp
+    _, groups, info, _ = A.layout(named, A.default_group_of, FakeModel)
     fake = G()
     fake.groups, fake.info = groups, info
     active = [(g.start, g.end) for g in groups.values()]

@@ -830,3 +830,218 @@ def test_sched_step_multi_matches_reference_schedule(ops):
     assert np.allclose(scale.cpu().numpy(), want, rtol=1e-6, atol=1e-7)
     with pytest.raises(RuntimeError, match="listed twice"):
         ops.sched_step_multi(steps, scale, [(1, 20, 0.1), (1, 20, 0.1)])
+
+
+# ------------------------------------------------------------------------------------------------ fp8 forward (C5)
+def _e4m3(x, q):
+    """reference quantisation: torch's float8_e4m3fn cast of clamp(x * q, +-448), as uint8 bits"""
+    return (x.float() * q).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+
+
+def _deq(x8):
+    return x8.view(torch.float8_e4m3fn).float()
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+def test_gemm_grouped_fp8_matches_dequantised_products(ops, tile):
+    """xggm_gemm_grouped_fp8e4m3: the four forward products of one cross-attention round (two Q, two fused KV) and an
+    FFN pair incl. GELU + pre-activation + e4m3 copy of the result and the split-K fp32 slabs, against the fp64
+    product of the SAME e4m3 operands; every tile of the grouped kernel."""
+    from xggm_amd import _lib
+    BF = torch.bfloat16
+    g = torch.Generator().manual_seed(11)
+
+    def operand(M, K, scale):
+        x = torch.randn(M, K, generator=g) * scale
+        a = x.abs().max().reshape(1).to(DEV)
+        q, s = ops.fp8_scale_for(a)
+        return ops.quantize_fp8(x.to(BF).to(DEV), q).view(torch.uint8), s
+
+    _lib.lib.xggm_gemm_set_group_tile(tile)
+    try:
+        # cross-attention round: lang queries, vision keys/values, vision queries, lang keys/values
+        xl, sl = operand(640, 768, 1.0)
+        xv, sv = operand(1152, 768, 1.5)
+        wq, sq = operand(768, 768, 0.03)
+        wkv, skv = operand(1536, 768, 0.03)
+        bq = torch.randn(768, generator=g).to(DEV)
+        bkv = torch.randn(1536, generator=g).to(DEV)
+        probs, outs = [], []
+        for x8, sx, w8, sw, b in ((xl, sl, wq, sq, bq), (xv, sv, wkv, skv, bkv), (xv, sv, wq, sq, bq), (xl, sl, wkv, skv, bkv)):
+            p, y, _ = ops.p_fwd8(x8, w8, sx, sw, b)
+            probs.append(p)
+            outs.append((y, x8, sx, w8, sw, b))
+        ops.gemm_group8(probs)
+        for y, x8, sx, w8, sw, b in outs:
+            ref = _deq(x8).double() @ _deq(w8).double().t() * float(sx) * float(sw) + b.double()
+            assert rel_err(y, ref) < 4e-3
+        # FFN pair: intermediate product with GELU, pre-activation and the e4m3 copy of the activation
+        w1, s1 = operand(3072, 768, 0.03)
+        b1 = torch.randn(3072, generator=g).to(DEV)
+        res = []
+        probs = []
+        for x8, sx in ((xl, sl), (xv, sv)):
+            act8 = torch.empty((x8.shape[0], 3072), device=DEV, dtype=torch.uint8)
+            qa = torch.tensor([37.0], device=DEV)
+            amax = torch.zeros(1, device=DEV)
+            p, act, u = ops.p_fwd8(x8, w1, sx, s1, b1, act=ops.ACT_GELU, want_preact=True, emit8=(act8, qa, amax))
+            probs.append(p)
+            res.append((x8, sx, act, u, act8, qa, amax))
+        ops.gemm_group8(probs)
+        for x8, sx, act, u, act8, qa, amax in res:
+            pre = _deq(x8).double() @ _deq(w1).double().t() * float(sx) * float(s1) + b1.double()
+            assert rel_err(u, pre) < 4e-3
+            want = torch.nn.functional.gelu(u.float())
+            assert rel_err(act, want) < 4e-3
+            # the e4m3 copy is the quantised fp32 activation (before its bf16 rounding): compare through the values
+            assert rel_err(_deq(act8) / 37.0, want) < 5e-2  # 3 mantissa bits: <= 6.25 % per element, ~3 % rms
+            a = float(want.abs().max())
+            assert float(amax) == 0.0 or abs(float(amax) - a) < 1e-2 * a  # recorded only beyond half the range 448/37
+            assert (a > 0.5 * 448 / 37) == (float(amax) > 0)
+        # an uncalibrated entry (qscale <= 0): quantised with 1, maximum always recorded
+        act8 = torch.empty((640, 3072), device=DEV, dtype=torch.uint8)
+        qa, amax = torch.tensor([-1.0], device=DEV), torch.zeros(1, device=DEV)
+        p, act, u = ops.p_fwd8(xl, w1, sl, s1, b1, act=ops.ACT_GELU, want_preact=True, emit8=(act8, qa, amax))
+        ops.gemm_group8([p])
+        want = torch.nn.functional.gelu(u.float())
+        assert abs(float(amax) - float(want.abs().max())) < 1e-2 * float(want.abs().max())
+        assert rel_err(_deq(act8), want) < 5e-2
+        # FFN output product as 3 split-K slabs
+        a8, sa = operand(1152, 3072, 0.5)
+        w2, s2 = operand(768, 3072, 0.03)
+        p, part, _ = ops.p_fwd8(a8, w2, sa, s2, None, split=3)
+        ops.gemm_group8([p])
+        ref = _deq(a8).double() @ _deq(w2).double().t() * float(sa) * float(s2)
+        assert part.shape == (3, 1152, 768) and rel_err(part.sum(0), ref) < 1e-4
+    finally:
+        _lib.lib.xggm_gemm_set_group_tile(0)
+    with pytest.raises(RuntimeError, match="multiples of 16"):
+        p, _, _ = ops.p_fwd8(xl[:, :760], wq[:, :760], sl, sq, None)
+        ops.gemm_group8([p])
+
+
+def test_producers_emit_e4m3_copies(ops):
+    """the residual LayerNorm and the attention core write their output a second time as e4m3 (the operand of the
+    next fp8 product) with the site's scale, and record the maximum by the scale-table protocol"""
+    BF = torch.bfloat16
+    # LayerNorm: two problems in one launch, each with its own scale entry
+    reqs, refs = [], []
+    for i, M in enumerate((640, 1152)):
+        h, _ = rnd((M, 768), BF, 20 + i)
+        r, _ = rnd((M, 768), BF, 30 + i)
+        gam = (1 + 0.1 * torch.randn(768, generator=torch.Generator().manual_seed(40 + i))).to(DEV)
+        bet = (0.1 * torch.randn(768, generator=torch.Generator().manual_seed(50 + i))).to(DEV)
+        q = torch.tensor([50.0 if i == 0 else -1.0], device=DEV)  # calibrated / uncalibrated entry
+        amax = torch.zeros(1, device=DEV)
+        req = ops.LnFwdReq(h.clone(), None, r, gam, bet, 1e-12, emit8=(q, amax))
+        reqs.append(req)
+        refs.append((q, amax))
+    ops.launch_row_requests(reqs)
+    for req, (q, amax) in zip(reqs, refs):
+        out = req.out.float()
+        qq = float(q) if float(q) > 0 else 1.0
+        # quantised from the fp32 value the bf16 output was rounded from: equal up to one bf16 rounding before the cast
+        d = (_deq(req.out8) / qq - out).abs()
+        # (element-wise: <= 1/16 of the value in the normal range; with scale 1 values below 2^-6 sit on the 2^-9 subnormal grid)
+        assert float((d / (out.abs() + 2e-2)).max()) < 0.08 and rel_err(_deq(req.out8) / qq, out) < 5e-2
+        m = float(out.abs().max())
+        if float(q) > 0:
+            assert (float(amax) > 0) == (m > 0.5 * 448 / qq)
+        if float(amax) > 0:
+            assert abs(float(amax) - m) < 1e-2 * m
+    assert float(refs[1][1]) > 0  # the uncalibrated entry always records
+    # attention core: context as bf16 and as e4m3
+    B, heads, Sq, Sk = 3, 12, 20, 36
+    qh, _ = rnd((B * Sq, 768), BF, 60)
+    kh, _ = rnd((B * Sk, 768), BF, 61)
+    vh, _ = rnd((B * Sk, 768), BF, 62)
+    qs, amax = torch.tensor([100.0], device=DEV), torch.zeros(1, device=DEV)
+    rng = ops.make_rng(1, DEV)
+    a = ops.AttnFwdReq(qh, kh, vh, None, B, heads, Sq, Sk, 0.0, rng, 7, emit8=(qs, amax))
+    b = ops.AttnFwdReq(qh, kh, vh, None, B, heads, Sq, Sk, 0.0, rng, 7)
+    ops.launch_row_requests([a])
+    ops.launch_row_requests([b])
+    assert torch.equal(a.out, b.out)
+    assert torch.equal(a.out8.cpu(), _e4m3(a.out, 100.0).cpu())  # quantised from the bf16 value: bit-exact
+    m = float(a.out.float().abs().max())
+    assert (float(amax) > 0) == (m > 0.5 * 448 / 100) and (float(amax) == 0 or float(amax) == m)
+
+
+def test_bertadam_ex_writes_e4m3_shadow_and_reads_bf16_gradients(ops):
+    """xggm_bertadam_ex against xggm_bertadam_f32 on the same state: identical p / m / v / bf16 shadow; the e4m3 copy
+    equals the quantised new weights chunk by chunk with the table's scales, chunks with id 0 stay untouched, maxima
+    beyond 3/4 of an entry's range are recorded; bf16 gradients give the update of their fp32 values; the learning
+    rate can come from a device scalar."""
+    n = 256 * 40
+    g_ = torch.Generator().manual_seed(3)
+    p0 = (torch.randn(n, generator=g_) * 0.02).to(DEV)
+    gr = (torch.randn(n, generator=g_) * 1e-3).to(DEV)
+    m0 = (torch.randn(n, generator=g_) * 1e-4).to(DEV)
+    v0 = (torch.rand(n, generator=g_) * 1e-6).to(DEV)
+    sq = (gr.double() ** 2).sum().float().reshape(1)
+    lr_scale = torch.tensor([0.5], device=DEV)
+
+    def state():
+        return p0.clone(), m0.clone(), v0.clone(), torch.zeros(n, device=DEV, dtype=torch.bfloat16)
+
+    pa, ma, va, sa = state()
+    ops.bertadam(pa, gr, ma, va, sa, sq, 5.0, 1e-2, lr_scale, 0.9, 0.999, 1e-6, 0.01)
+    # e4m3 copy: chunks 0-9 entry 1, 10-19 none, 20-39 entry 2; the range starts at arena element 256 * 7
+    ids = torch.zeros(64, dtype=torch.int16, device=DEV)
+    ids[7:17] = 1
+    ids[27:47] = 2
+    big = float(p0.abs().max())
+    qtab = torch.tensor([1.0, 448.0 / (2.0 * big), 448.0 / (1.1 * big)], device=DEV)  # entry 1: max at half the range
+    amax = torch.zeros(3, device=DEV)
+    s8 = torch.full((n,), 0x55, dtype=torch.uint8, device=DEV)
+    pb, mb, vb, sb = state()
+    ops.bertadam_ex(pb, gr, mb, vb, sb, sq, 5.0, 123.0, lr_scale, 0.9, 0.999, 1e-6, 0.01,
+                    lr_dev=torch.tensor([1e-2], device=DEV), w8=(s8, ids, qtab, amax), elem0=256 * 7)
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb) and torch.equal(sa, sb)
+    assert torch.equal(s8[:2560].cpu(), _e4m3(pb[:2560], float(qtab[1])).cpu())
+    assert bool((s8[2560:5120] == 0x55).all())
+    assert torch.equal(s8[5120:].cpu(), _e4m3(pb[5120:], float(qtab[2])).cpu())
+    assert float(amax[1]) == 0.0  # nothing beyond 3/4 of entry 1's range
+    assert float(amax[2]) == float(pb[5120:].abs().max()) and float(amax[0]) == 0.0
+    # bf16 gradients
+    gb = gr.to(torch.bfloat16)
+    pc, mc, vc, sc = state()
+    ops.bertadam(pc, gb.float(), mc, vc, sc, sq, 5.0, 1e-2, lr_scale, 0.9, 0.999, 1e-6, 0.01)
+    pd, md, vd, sd = state()
+    ops.bertadam_ex(pd, gb, md, vd, sd, sq, 5.0, 1e-2, lr_scale, 0.9, 0.999, 1e-6, 0.01)
+    assert torch.equal(pc, pd) and torch.equal(mc, md) and torch.equal(vc, vd) and torch.equal(sc, sd)
+    # squared norm of a bf16 buffer
+    out = torch.zeros(1, device=DEV)
+    ops.sqnorm_bf16(gb, out)
+    assert abs(float(out) - float((gb.double() ** 2).sum())) < 1e-5 * float((gb.double() ** 2).sum())
+
+
+def test_fp8_scale_update_protocol(ops):
+    """xggm_fp8_scale_update on a 6-entry table over several calls: recorded maxima set range = margin x max of the
+    history, an uncalibrated entry stays uncalibrated until something is recorded, a silent entry keeps its scale
+    (weights) or halves its range once per wrapped history (activations), amax is cleared, pos advances only when
+    asked, and a sub-range call leaves the other entries alone."""
+    H = 4
+    amax = torch.zeros(8, device=DEV)
+    hist = torch.zeros(8 * H, device=DEV)
+    q = torch.tensor([1.0, -1.0, -1.0, 10.0, 10.0, 10.0, 7.0, 7.0], device=DEV)
+    d = torch.ones(8, device=DEV)
+    pos = torch.zeros(1, dtype=torch.int64, device=DEV)
+    amax[1], amax[3] = 2.0, 5.0
+    ops.fp8_scale_update(amax, hist, q, d, pos, 1, 5, H, 1.25, 1, 1)  # entries 1..5
+    assert int(pos) == 1 and float(amax.abs().max()) == 0.0
+    assert abs(float(q[1]) - 448 / (1.25 * 2.0)) < 1e-3 and float(q[2]) == -1.0          # calibrated / still not
+    assert abs(float(q[3]) - 448 / (1.25 * 5.0)) < 1e-3 and float(q[4]) == 10.0         # recorded / silent: kept
+    assert float(q[0]) == 1.0 and float(q[6]) == 7.0                                      # outside the range
+    assert abs(float(d[3]) * float(q[3]) - 1.0) < 1e-6
+    for step in range(2, 5):  # three more silent calls: the history of entry 3 still holds 5.0 until it wraps
+        ops.fp8_scale_update(amax, hist, q, d, pos, 1, 5, H, 1.25, 1, 1)
+        assert int(pos) == step
+    assert abs(float(q[3]) - 448 / (1.25 * 5.0)) < 1e-3
+    assert float(q[4]) == 20.0 and float(q[5]) == 20.0  # a whole history without a near-range value: range halves
+    ops.fp8_scale_update(amax, hist, q, d, pos, 1, 5, H, 1.25, 1, 1)  # slot 0 again: the 5.0 is overwritten
+    assert abs(float(q[3]) - 448 / (1.25 * 5.0)) < 1e-3  # kept until the history wraps with nothing recorded
+    # weights: no shrink, no bump
+    amax[6] = 3.0
+    ops.fp8_scale_update(amax, hist, q, d, pos, 6, 2, H, 4.0 / 3.0, 0, 0)
+    assert int(pos) == 5 and abs(float(q[6]) - 448 / (4.0 / 3.0 * 3.0)) < 1e-3 and float(q[7]) == 7.0

@@ -20,11 +20,41 @@ import torch
 
 from . import ops
 
-ALIGN = 8  # elements: 32 B fp32 / 16 B bf16
+ALIGN = 8        # elements: 32 B fp32 / 16 B bf16
+ALIGN_MAT = 256  # matrices start on 256-element chunks: the unit of the e4m3 scale-id table (fp8 forward) and of the
+                 # shard boundaries of a sharded update (any run of whole matrices divides by 2, 4, 8 ranks)
 
 
-def _align(n):
-    return (n + ALIGN - 1) // ALIGN * ALIGN
+def _align(n, a=ALIGN):
+    return (n + a - 1) // a * a
+
+
+def layout(named, group_of, model=None):
+    """offsets of every parameter in the flat buffers.  ``named``: [(name, p)] with p.dim() / p.numel() / p.shape.
+    -> (group order, {group: Group}, {name: (offset, numel, group, atomic)}, total elements)"""
+    order = []
+    for n, p in named:
+        g = group_of(n, model)
+        if g not in order:
+            order.append(g)
+    groups = {g: Group(g) for g in order}
+    info, off = {}, 0
+    for gname in order:
+        G = groups[gname]
+        G.start = off = _align(off, ALIGN_MAT)
+        members = [(n, p) for n, p in named if group_of(n, model) == gname]
+        for n, p in members:
+            if not is_atomic(n, p):
+                info[n] = (off, p.numel(), gname, False)
+                off = _align(off + p.numel(), ALIGN_MAT)
+        G.vec_start = off
+        for n, p in members:
+            if is_atomic(n, p):
+                info[n] = (off, p.numel(), gname, True)
+                off = _align(off + p.numel())
+        G.end = off
+        G.params = [p for _, p in members]
+    return order, groups, info, _align(off, ALIGN_MAT)
 
 
 def default_group_of(name, model=None):
@@ -56,36 +86,14 @@ class ParamArena:
                                "(no CPU fallback); call model.cuda()")
         self.device = dev
         self.compute_dtype = compute_dtype
-        order = []
-        for n, p in named:
-            g = group_of(n, model)
-            if g not in order:
-                order.append(g)
-        self.groups = {g: Group(g) for g in order}
-        off = 0
-        self.info = {}
-        for gname in order:
-            G = self.groups[gname]
-            G.start = off = _align(off)
-            members = [(n, p) for n, p in named if group_of(n, model) == gname]
-            mats = [(n, p) for n, p in members if not is_atomic(n, p)]
-            vecs = [(n, p) for n, p in members if is_atomic(n, p)]
-            for n, p in mats:
-                self.info[n] = (off, p.numel(), gname, False)
-                off = _align(off + p.numel())
-            G.vec_start = off
-            for n, p in vecs:
-                self.info[n] = (off, p.numel(), gname, True)
-                off = _align(off + p.numel())
-            G.end = off
-            G.params = [p for _, p in members]
-        self.total = _align(off)
+        order, self.groups, self.info, self.total = layout(named, group_of, model)
         self.params = torch.zeros(self.total, device=dev, dtype=torch.float32)
         self.grads = torch.zeros(self.total, device=dev, dtype=torch.float32)
         self.m = torch.zeros(self.total, device=dev, dtype=torch.float32)
         self.v = torch.zeros(self.total, device=dev, dtype=torch.float32)
         self.shadow = (torch.zeros(self.total, device=dev, dtype=torch.bfloat16)
                        if compute_dtype == torch.bfloat16 else None)
+        self.fp8 = None  # xggm_amd.fp8.Fp8State when the forward QKV / FFN products run on e4m3 operands
         # device scalars: per-group step counter + schedule value, global sum of squares
         self.steps = torch.zeros(len(order), device=dev, dtype=torch.int64)
         self.lr_scale = torch.ones(len(order), device=dev, dtype=torch.float32)
@@ -139,6 +147,8 @@ class ParamArena:
         """refresh the bf16 shadow weights from the fp32 masters (after init / load_state_dict)."""
         if self.shadow is not None:
             ops.cast_bf16(self.params, self.shadow)
+        if self.fp8 is not None:
+            self.fp8.requantize_weights()
 
     def w(self, p):
         """the tensor the GEMMs consume for parameter ``p``: bf16 shadow or the fp32 master."""

@@ -271,7 +271,9 @@ int attn_fwd_grouped(const xggm_attn_problem* probs, int n, int head_dim, const 
         const AttnArgs a = args_of(q, rng);
         if (int e = check("xggm_attn_fwd", a, head_dim)) return e;
         XGGM_REQUIRE(q.out, "xggm_attn_fwd: null output");
-        if (sizeof(T) == 2 && mfma_ok(q.q, q.k, q.v, nullptr, q.q_rs, q.k_rs, q.v_rs, 8)) {
+        XGGM_REQUIRE(!q.out8 || (sizeof(T) == 2 && reinterpret_cast<uintptr_t>(q.out8) % 8 == 0),
+                     "xggm_attn_fwd: the e4m3 output copy needs bf16 storage and an 8-byte aligned buffer");
+        if (sizeof(T) == 2 && mfma_ok(q.q, q.k, q.v, q.out, q.q_rs, q.k_rs, q.v_rs, q.o_rs)) {
             pend[np++] = q;
             if (np == 2 || i == n - 1) {
                 if (int e = xggm_attn_fwd_mfma_group(pend, np, rng, st)) return e;
@@ -279,6 +281,8 @@ int attn_fwd_grouped(const xggm_attn_problem* probs, int n, int head_dim, const 
             }
             continue;
         }
+        XGGM_REQUIRE(!q.out8, "xggm_attn_fwd: the e4m3 output copy is written by the matrix-core kernel only (16-byte "
+                              "aligned operands, strides multiples of 8)");
         const size_t lds = sizeof(float) * ((size_t)(q.Sq + 2 * q.Sk) * LD + 2 * (size_t)q.Sq * (q.Sk + 1));
         hipLaunchKernelGGL((attn_fwd_kernel<T>), dim3(q.B * q.heads), dim3(NT), lds, st, a, (T*)q.out);
         if (int e = xggm_check_launch("xggm_attn_fwd")) return e;

@@ -37,6 +37,9 @@ struct MArgs {
 struct MSeg {
     MArgs a;
     bf16* out;
+    unsigned char* out8;  // or null: e4m3 copy of the output (operand of the fp8 output projection)
+    const float* qscale;
+    float* amax;
     const bf16* d_out;
     bf16 *dq, *dk, *dv;
     int64_t dq_rs, dk_rs, dv_rs;
@@ -180,17 +183,48 @@ __global__ __launch_bounds__(NT) void attn_fwd_mfma_kernel(MGroup G) {
         }
     }
     __syncthreads();
-    // O = P V : tiles (ti, tc), k = j over RK
+    // O = P V : tiles (ti, tc), k = j over RK.  The tiles go back through LDS (the Q image is dead since the scores)
+    // so that the context leaves as whole 16-byte row pieces -- 128 contiguous bytes per (row, head) -- instead of
+    // 2-byte stores at a row stride, and, for the fp8 forward, as e4m3 next to it in the same pass.
     const int tq = RQ / 16;
+    bf16* Os = Qs;
     for (int t = wid; t < tq * 4; t += NT / 64) {
         const int ti = t >> 2, tc = t & 3;
         float4_t acc = {0.f, 0.f, 0.f, 0.f};
         for (int ks = 0; ks < RK; ks += 32)
             acc = MFMA(frag_rows(Pb, LDP, ti * 16, ks, lane), frag_tr(Vs, LDT, ks, tc * 16, lane), acc);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = ti * 16 + fq * 4 + r;
-            if (i < Sq) out[((int64_t)b * Sq + i) * a.o_rs + h * D + tc * 16 + fr] = __float2bfloat16(acc[r]);
+        for (int r = 0; r < 4; ++r) Os[(ti * 16 + fq * 4 + r) * LDT + tc * 16 + fr] = __float2bfloat16(acc[r]);
+    }
+    __syncthreads();
+    const Q8 qs(sg.out8 ? sg.qscale : nullptr);
+    const float q8 = qs.q;
+    float amax8 = 0.f;
+    for (int c = tid; c < Sq * 8; c += NT) {
+        const int i = c >> 3, cc = (c & 7) * 8;
+        const short8_t v = *reinterpret_cast<const short8_t*>(Os + i * LDT + cc);
+        const int64_t o = ((int64_t)b * Sq + i) * a.o_rs + h * D + cc;
+        *reinterpret_cast<short8_t*>(out + o) = v;
+        if (sg.out8) {
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                f[e] = __bfloat162float(__builtin_bit_cast(bf16, (short)v[e]));
+                amax8 = fmaxf(amax8, fabsf(f[e]));
+            }
+            *reinterpret_cast<int2*>(sg.out8 + o) = make_int2(pack4_e4m3(f[0], f[1], f[2], f[3], q8), pack4_e4m3(f[4], f[5], f[6], f[7], q8));
+        }
+    }
+    if (sg.out8 && sg.amax) {
+        __shared__ float red8[NT / 64];
+        const float wv = wave_max(amax8);
+        if (lane == 0) red8[wid] = wv;
+        __syncthreads();
+        if (tid == 0) {
+            float bm = red8[0];
+#pragma unroll
+            for (int w = 1; w < NT / 64; ++w) bm = fmaxf(bm, red8[w]);
+            if (bm > qs.thr) atomic_max_nonneg(sg.amax, bm);
         }
     }
 }
@@ -330,6 +364,9 @@ MSeg make_seg(const xggm_attn_problem& q, const uint64_t* rng) {
     g.a = MArgs{(const bf16*)q.q, (const bf16*)q.k, (const bf16*)q.v, q.mask, q.q_rs, q.k_rs, q.v_rs, q.o_rs,
                 q.B, q.heads, q.Sq, q.Sk, q.scale, q.p, rng, q.sid};
     g.out = (bf16*)q.out;
+    g.out8 = (unsigned char*)q.out8;
+    g.qscale = q.qscale;
+    g.amax = q.amax;
     g.d_out = (const bf16*)q.d_out;
     g.dq = (bf16*)q.dq; g.dk = (bf16*)q.dk; g.dv = (bf16*)q.dv;
     g.dq_rs = q.dq_rs; g.dk_rs = q.dk_rs; g.dv_rs = q.dv_rs;

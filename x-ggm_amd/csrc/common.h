@@ -164,5 +164,33 @@ __device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t offset, u
     return sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530717958647692f * u2);
 }
 
+// ---------------------------------------------------------------- OCP e4m3 packing (fp8 forward operands)
+// four floats -> one dword of e4m3fn bytes: scaled, saturated to +-448 (the largest e4m3 value), round to nearest even
+__device__ __forceinline__ int pack4_e4m3(float a, float b, float c, float d, float q) {
+    a = fminf(fmaxf(a * q, -448.f), 448.f);
+    b = fminf(fmaxf(b * q, -448.f), 448.f);
+    c = fminf(fmaxf(c * q, -448.f), 448.f);
+    d = fminf(fmaxf(d * q, -448.f), 448.f);
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    return __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+}
+// |x| >= 0: the IEEE bit pattern orders like the value, so the running maximum is one integer atomic
+__device__ __forceinline__ void atomic_max_nonneg(float* dst, float v) {
+    if (v > 0.f) atomicMax(reinterpret_cast<unsigned int*>(dst), __float_as_uint(v));
+}
+
+// Scale-table protocol of the e4m3 producers (xggm_fp8_scale_update): *qscale <= 0 marks an entry that has not been
+// calibrated -- quantise with 1 and record every maximum; otherwise only maxima beyond half the representable range
+// 448 / q are recorded (e4m3 is a floating-point format: a smaller stale range costs no precision, only a larger
+// one saturates), which keeps the same-address atomics of a launch to the rare workgroups that matter.
+struct Q8 {
+    float q, thr;
+    __device__ __forceinline__ explicit Q8(const float* qscale) {
+        const float s = qscale ? *qscale : 1.f;
+        q = s > 0.f ? s : 1.f;
+        thr = (qscale && s > 0.f) ? 0.5f * 448.f / s : 0.f;
+    }
+};
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -118,7 +118,7 @@ namespace {
 template <typename T>
 __global__ __launch_bounds__(NT) void quantize_fp8_kernel(const T* __restrict__ x, unsigned char* __restrict__ y, int64_t n,
                                                           const float* __restrict__ qscale, float* amax) {
-    const float s = qscale ? *qscale : 1.0f;
+    const float s = Q8(qscale).q;  // an uncalibrated entry (*qscale <= 0) quantises with 1
     float mx = 0.f;
     const int64_t n8 = n >> 3;
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n8; i += (int64_t)gridDim.x * NT) {

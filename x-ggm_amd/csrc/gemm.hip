@@ -34,6 +34,11 @@ struct GemmArgs {
     const void* aux;       // T, layout of C: pre-activation u for act == GELU_GRAD
     float* colsum;         // [N] or null: += column sums of the stored result (bias gradients)
     float* sqsum;          // or null: [ceil(M/64)][ceil(N/64)] sums of squares of the STORED fp32 values per 64 x 64 block
+    unsigned char* c8;     // or null: e4m3 copy of the stored result (layout of C), scaled by *c8_qscale
+    const float* c8_qscale;
+    float* c8_amax;        // or null: raised to max |stored value|
+    const float* scale_a;  // fp8 operands: reciprocal quantisation scales (device scalars, null = 1)
+    const float* scale_b;
     int act;
     int c_f32;         // store C as float regardless of T
     int accumulate;    // C += result
@@ -410,6 +415,9 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, const float4_
     float sq_acc[RS];
 #pragma unroll
     for (int r = 0; r < RS; ++r) sq_acc[r] = 0.f;
+    const Q8 qs(g.c8 ? g.c8_qscale : nullptr);
+    const float q8 = qs.q;
+    float amax8 = 0.f;
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {
         if ((wid >> 1) == h) {
@@ -491,6 +499,14 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, const float4_
                         *reinterpret_cast<float4*>(sp) = make_float4(v[0], v[1], v[2], v[3]);
                         *reinterpret_cast<float4*>(sp + 4) = make_float4(v[4], v[5], v[6], v[7]);
                     }
+                    if (g.c8) {
+                        // the operand of the next fp8 product leaves its producer as e4m3 (v_cvt_pk_fp8_f32 saturates
+                        // to +-448 and rounds to nearest even), no quantisation pass
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) amax8 = fmaxf(amax8, fabsf(v[e]));
+                        *reinterpret_cast<int2*>(g.c8 + idx[b]) =
+                            make_int2(pack4_e4m3(v[0], v[1], v[2], v[3], q8), pack4_e4m3(v[4], v[5], v[6], v[7], q8));
+                    }
                     if (g.c_f32) {
                         float* c = reinterpret_cast<float*>(g.C) + idx[b];
                         float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
@@ -562,6 +578,18 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, const float4_
             }
             lds_barrier();
         }
+    }
+    if (g.c8 && g.c8_amax) {
+        // non-negative floats order like their bit patterns: one integer atomic per workgroup.  The loop above ended
+        // with a barrier: the staging LDS is free.
+        const float wv = wave_max(amax8);
+        if (lane == 0) stage[wid] = wv;
+        lds_barrier();
+        if (tid == 0) {
+            const float bm = fmaxf(fmaxf(stage[0], stage[1]), fmaxf(stage[2], stage[3]));
+            if (bm > qs.thr) atomic_max_nonneg(g.c8_amax, bm);
+        }
+        lds_barrier();
     }
     if (g.sqsum && g.c_f32) {
         // one slot per 64 x 64 block of the output, written by exactly one workgroup, summed in a fixed order: the
@@ -865,6 +893,56 @@ template <int BM, int BN> int launch_grouped_tile(GroupArgs& ga, hipStream_t str
     return xggm_check_launch("xggm_gemm_grouped");
 }
 
+// The grouped launch with e4m3 operands (forward products of both modality streams of one layer): every problem
+// is k-major on both sides, so there is ONE k-loop instantiation; the per-problem dequantisation factor
+// scale_a * scale_b is folded into alpha before the (shared) epilogue.
+template <int BM, int BN> __global__ __launch_bounds__(NT, (min_waves<BM, BN>())) void gemm_grouped_fp8_kernel(GroupArgs ga) {
+    extern __shared__ __attribute__((aligned(16))) bf16 fsm[];
+    const int b = blockIdx.x;
+    int i = 0, t0 = 0, t1 = ga.tile_start[1];
+#pragma unroll
+    for (int k = 1; k < MAX_GROUP; ++k)
+        if (k < ga.nprob && b >= ga.tile_start[k]) { i = k; t0 = ga.tile_start[k]; t1 = ga.tile_start[k + 1]; }
+    GemmArgs g = ga.p[i];
+    const int local = g.xcd_swizzle ? xcd_remap(b - t0, t1 - t0) : b - t0;
+    const int gx = (g.N + BN - 1) / BN, gy = (g.M + BM - 1) / BM;
+    const int bz = g.batch == 1 ? 0 : local / (gx * gy);
+    const int lt = local - bz * gx * gy;
+    int tile_m, tile_n;
+    if (g.xcd_swizzle) {
+        tile_of_position(lt, gx, gy, g.M, g.N, tile_m, tile_n);
+    } else {
+        tile_m = lt / gx;
+        tile_n = lt - tile_m * gx;
+    }
+    constexpr int DK = (BM * BN <= 64 * 64) ? 4 : 2;
+    float4_t acc[BM / 32][BN / 32];
+    gemm_kloop<BM, BN, true, true, DK, true>(g, tile_m, tile_n, bz, fsm, acc);
+    g.alpha *= (g.scale_a ? *g.scale_a : 1.f) * (g.scale_b ? *g.scale_b : 1.f);
+    gemm_finish<BM, BN>(g, tile_m, tile_n, bz, fsm, acc);
+}
+
+template <int BM, int BN> int launch_grouped_fp8_tile(GroupArgs& ga, hipStream_t stream) {
+    int total = 0;
+    for (int i = 0; i < ga.nprob; ++i) {
+        ga.tile_start[i] = total;
+        total += ceil_div(ga.p[i].M, BM) * ceil_div(ga.p[i].N, BN) * ga.p[i].batch;
+    }
+    ga.tile_start[ga.nprob] = total;
+    // k-major images of 128 bytes per row (128 e4m3 values), double buffered; the staged epilogue needs
+    // (BM / 2) x (BN + 4) floats of the same memory
+    constexpr size_t lds = std::max(2 * sizeof(bf16) * (OpLds<BM, true>::ELEMS + OpLds<BN, true>::ELEMS),
+                                    sizeof(float) * (BM / 2) * (BN + 4));
+    static bool attr_set = false;
+    if (lds > 48 * 1024 && !attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_grouped_fp8_kernel<BM, BN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_grouped_fp8_kernel<BM, BN>), dim3(total), dim3(NT), lds, stream, ga);
+    return xggm_check_launch("xggm_gemm_grouped_fp8e4m3");
+}
+
 template <int BM, int BN, int D> int launch_fast_tile(const GemmArgs& g, int batch, hipStream_t stream) {
     dim3 grid(ceil_div(g.N, BN), ceil_div(g.M, BM), batch);
     const bool ak = g.a_mode == 1, bk = g.b_mode == 1;
@@ -975,6 +1053,7 @@ template <typename T> int launch(GemmArgs g, int batch, hipStream_t stream) {
         g.a_rs = a_rs; g.a_ks = a_ks; g.b_ns = b_ns; g.b_ks = b_ks; g.ldc = ldc;                                       \
         g.a_bs = a_bs; g.b_bs = b_bs; g.c_bs = c_bs;                                                                   \
         g.bias = bias; g.residual = residual; g.preact = preact; g.aux = aux; g.colsum = colsum; g.sqsum = nullptr;   \
+        g.c8 = nullptr; g.c8_qscale = nullptr; g.c8_amax = nullptr; g.scale_a = g.scale_b = nullptr;                     \
         g.act = act; g.c_f32 = c_f32; g.accumulate = accumulate; g.alpha = alpha;                                     \
         g.a_mode = g.b_mode = 0; g.xcd_swizzle = g_xcd_swizzle; g.batch = batch; SET_STAMP(g); \
         return launch<T>(g, batch, stream);                                                                            \
@@ -1002,6 +1081,7 @@ extern "C" int xggm_gemm_fp8e4m3(const void* A, const void* B, void* C, int M, i
     g.a_rs = a_rs; g.a_ks = 1; g.b_ns = b_ns; g.b_ks = 1; g.ldc = ldc;
     g.a_bs = g.b_bs = g.c_bs = 0;
     g.bias = bias; g.residual = residual; g.preact = preact; g.aux = nullptr; g.colsum = nullptr; g.sqsum = nullptr;
+    g.c8 = nullptr; g.c8_qscale = nullptr; g.c8_amax = nullptr; g.scale_a = g.scale_b = nullptr;
     g.act = act; g.c_f32 = c_f32; g.accumulate = 0; g.alpha = 1.0f;
     g.a_mode = g.b_mode = 1; g.a_tail = g.b_tail = 0; g.a_rows = M; g.b_rows = N;
     g.xcd_swizzle = g_xcd_swizzle; g.batch = 1; SET_STAMP(g);
@@ -1033,37 +1113,20 @@ GemmArgs from_problem(const xggm_gemm_problem& p) {
     g.a_rs = p.a_rs; g.a_ks = p.a_ks; g.b_ns = p.b_ns; g.b_ks = p.b_ks; g.ldc = p.ldc;
     g.a_bs = p.a_bs; g.b_bs = p.b_bs; g.c_bs = p.c_bs;
     g.bias = p.bias; g.residual = p.residual; g.preact = p.preact; g.aux = p.aux; g.colsum = p.colsum; g.sqsum = p.sqsum;
+    g.c8 = reinterpret_cast<unsigned char*>(p.c8); g.c8_qscale = p.c8_qscale; g.c8_amax = p.c8_amax;
+    g.scale_a = p.scale_a; g.scale_b = p.scale_b;
     g.act = p.act; g.c_f32 = p.c_f32; g.accumulate = p.accumulate; g.alpha = p.alpha;
     g.a_mode = g.b_mode = 0; g.xcd_swizzle = g_xcd_swizzle; g.batch = p.batch; SET_STAMP(g);
     return g;
 }
 
-template <typename T> int grouped(const xggm_gemm_problem* probs, int n, hipStream_t stream) {
-    XGGM_REQUIRE(probs && n > 0, "xggm_gemm_grouped: no problems");
-    bool fast = sizeof(T) == 2 && !g_force_generic && n <= MAX_GROUP;
-    GroupArgs ga;
-    ga.nprob = n;
-    for (int i = 0; i < n && fast; ++i) {
-        GemmArgs g = from_problem(probs[i]);
-        if (!(g.M > 0 && g.N > 0 && g.K > 0 && g.batch > 0 && g.A && g.B && g.C)) fast = false;
-        g.a_mode = pick_mode<T>(g.A, g.a_rs, g.a_ks, g.a_bs, g.M, g.K, &g.a_tail, &g.a_rows);
-        g.b_mode = pick_mode<T>(g.B, g.b_ns, g.b_ks, g.b_bs, g.N, g.K, &g.b_tail, &g.b_rows);
-        if (g.a_mode == 0 || g.b_mode == 0) fast = false;
-        ga.p[i] = g;
-    }
-    // longest k-loops first: their tiles start early and the short ones fill the tail
-    for (int i = 1; i < n && fast; ++i)
-        for (int j = i; j > 0 && ga.p[j].K > ga.p[j - 1].K; --j) std::swap(ga.p[j], ga.p[j - 1]);
-    if (!fast || n == 1) {  // odd shapes, fp32 mode or a single problem: one launch each
-        for (int i = 0; i < n; ++i)
-            if (int e = launch<T>(from_problem(probs[i]), probs[i].batch, stream)) return e;
-        return XGGM_OK;
-    }
-    // tile choice from a launch-time model fitted to tools/gemm_ktime.py and tools/bench_gemm.py on
-    // MI355X (microseconds): T = max(a + b r + s W, f + k nk_max), with r = tiles per CU,
-    // W = 64-deep k-tiles per CU and the second term the longest single tile (one CU's critical
-    // path: long-K problems need small tiles).  Big tiles run the k-loop ~1.3x more efficiently
-    // per flop, small ones have the shorter critical path and fill the CUs of a small group.
+// tile choice from a launch-time model fitted to tools/gemm_ktime.py and tools/bench_gemm.py on
+// MI355X (microseconds): T = max(a + b r + s W, f + k nk_max), with r = tiles per CU,
+// W = k-tiles per CU and the second term the longest single tile (one CU's critical
+// path: long-K problems need small tiles).  Big tiles run the k-loop ~1.3x more efficiently
+// per flop, small ones have the shorter critical path and fill the CUs of a small group.
+// `kt`: reduction elements per k-tile (64 bf16, 128 e4m3: the same bytes).
+int pick_group_tile(const GroupArgs& ga, int n, int kt) {
     struct TileModel { int bm, bn; float a, b, s, f, k; };
     static const TileModel models[3] = {{64, 64, 3.3f, 1.2f, 0.19f, 5.0f, 0.28f},
                                         {128, 64, 4.2f, 2.0f, 0.37f, 5.6f, 0.56f},
@@ -1092,7 +1155,7 @@ template <typename T> int grouped(const xggm_gemm_problem* probs, int n, hipStre
             int nkmax = 0;
             for (int i = 0; i < n; ++i) {
                 const double t = (double)ceil_div(ga.p[i].M, tm.bm) * ceil_div(ga.p[i].N, tm.bn) * ga.p[i].batch;
-                const int nk = ceil_div(ga.p[i].K, 64);
+                const int nk = ceil_div(ga.p[i].K, kt);
                 tiles += t;
                 work += t * nk;
                 nkmax = std::max(nkmax, nk);
@@ -1105,12 +1168,72 @@ template <typename T> int grouped(const xggm_gemm_problem* probs, int n, hipStre
             }
         }
     }
+    return v;
+}
+
+template <typename T> int grouped(const xggm_gemm_problem* probs, int n, hipStream_t stream) {
+    XGGM_REQUIRE(probs && n > 0, "xggm_gemm_grouped: no problems");
+    bool fast = sizeof(T) == 2 && !g_force_generic && n <= MAX_GROUP;
+    GroupArgs ga;
+    ga.nprob = n;
+    for (int i = 0; i < n && fast; ++i) {
+        GemmArgs g = from_problem(probs[i]);
+        if (!(g.M > 0 && g.N > 0 && g.K > 0 && g.batch > 0 && g.A && g.B && g.C)) fast = false;
+        g.a_mode = pick_mode<T>(g.A, g.a_rs, g.a_ks, g.a_bs, g.M, g.K, &g.a_tail, &g.a_rows);
+        g.b_mode = pick_mode<T>(g.B, g.b_ns, g.b_ks, g.b_bs, g.N, g.K, &g.b_tail, &g.b_rows);
+        if (g.a_mode == 0 || g.b_mode == 0) fast = false;
+        ga.p[i] = g;
+    }
+    // longest k-loops first: their tiles start early and the short ones fill the tail
+    for (int i = 1; i < n && fast; ++i)
+        for (int j = i; j > 0 && ga.p[j].K > ga.p[j - 1].K; --j) std::swap(ga.p[j], ga.p[j - 1]);
+    if (!fast || n == 1) {  // odd shapes, fp32 mode or a single problem: one launch each
+        for (int i = 0; i < n; ++i)
+            if (int e = launch<T>(from_problem(probs[i]), probs[i].batch, stream)) return e;
+        return XGGM_OK;
+    }
+    const int v = pick_group_tile(ga, n, 64);
     if (v == 3) return launch_grouped_tile<128, 128>(ga, stream);
     if (v == 2) return launch_grouped_tile<128, 64>(ga, stream);
     return launch_grouped_tile<64, 64>(ga, stream);
 }
 }  // namespace
 
+extern "C" int xggm_gemm_grouped_fp8e4m3(const xggm_gemm_problem* probs, int n, hipStream_t stream) {
+    XGGM_REQUIRE(probs && n > 0 && n <= MAX_GROUP, "xggm_gemm_grouped_fp8e4m3: 1..%d problems per launch (n = %d)", MAX_GROUP, n);
+    GroupArgs ga;
+    ga.nprob = n;
+    for (int i = 0; i < n; ++i) {
+        GemmArgs g = from_problem(probs[i]);
+        XGGM_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.batch > 0 && g.A && g.B && g.C,
+                     "xggm_gemm_grouped_fp8e4m3: empty problem or null operand (%d)", i);
+        XGGM_REQUIRE(g.a_ks == 1 && g.b_ks == 1, "xggm_gemm_grouped_fp8e4m3: e4m3 operands are k-contiguous");
+        XGGM_REQUIRE(g.K % 16 == 0 && g.a_rs % 16 == 0 && g.b_ns % 16 == 0 && g.a_rs >= g.K && g.b_ns >= g.K &&
+                         g.a_bs % 16 == 0 && g.b_bs % 16 == 0,
+                     "xggm_gemm_grouped_fp8e4m3: K, row and batch strides must be multiples of 16 (K = %d)", g.K);
+        XGGM_REQUIRE(reinterpret_cast<uintptr_t>(g.A) % 16 == 0 && reinterpret_cast<uintptr_t>(g.B) % 16 == 0,
+                     "xggm_gemm_grouped_fp8e4m3: operands must be 16-byte aligned");
+        XGGM_REQUIRE(g.act >= 0 && g.act < XGGM_ACT_GELU_GRAD && !g.aux && !g.colsum && !g.sqsum && !g.accumulate,
+                     "xggm_gemm_grouped_fp8e4m3: forward epilogues only");
+        XGGM_REQUIRE(g.ldc >= g.N, "xggm_gemm_grouped_fp8e4m3: ldc %lld < N %d", (long long)g.ldc, g.N);
+        XGGM_REQUIRE(!g.c8 || (g.ldc % 8 == 0 && g.N % 8 == 0 && reinterpret_cast<uintptr_t>(g.c8) % 8 == 0 && !g.c_f32),
+                     "xggm_gemm_grouped_fp8e4m3: the e4m3 copy needs an 8-aligned bf16 output");
+        XGGM_REQUIRE((int64_t)(g.M - 1) * g.a_rs + (int64_t)(g.batch - 1) * g.a_bs + g.K < OOB_OFFSET &&
+                         (int64_t)(g.N - 1) * g.b_ns + (int64_t)(g.batch - 1) * g.b_bs + g.K < OOB_OFFSET,
+                     "xggm_gemm_grouped_fp8e4m3: operand larger than 2 GiB");
+        g.a_mode = g.b_mode = 1;
+        g.a_tail = g.b_tail = 0;
+        g.a_rows = g.M;
+        g.b_rows = g.N;
+        ga.p[i] = g;
+    }
+    for (int i = 1; i < n; ++i)  // longest k-loops first
+        for (int j = i; j > 0 && ga.p[j].K > ga.p[j - 1].K; --j) std::swap(ga.p[j], ga.p[j - 1]);
+    const int v = pick_group_tile(ga, n, 128);
+    if (v == 3) return launch_grouped_fp8_tile<128, 128>(ga, stream);
+    if (v == 2) return launch_grouped_fp8_tile<128, 64>(ga, stream);
+    return launch_grouped_fp8_tile<64, 64>(ga, stream);
+}
 extern "C" int xggm_gemm_grouped_bf16(const xggm_gemm_problem* probs, int n, hipStream_t stream) {
     return grouped<bf16>(probs, n, stream);
 }

@@ -183,9 +183,32 @@ __global__ __launch_bounds__(NT) void sqnorm_finish_kernel(const float* __restri
     if (threadIdx.x == 0) *out += t;
 }
 
+// the same sum over a bf16 buffer (data-parallel wire arena): 8 elements per 16-byte load
+__global__ __launch_bounds__(NT) void sqnorm_bf16_kernel(const bf16* __restrict__ g, int64_t n, float* ws) {
+    float acc = 0.f;
+    const int64_t n8 = n >> 3;
+    typedef short __attribute__((ext_vector_type(8))) s8;
+    const s8* g8 = reinterpret_cast<const s8*>(g);
+    const int64_t stride = (int64_t)gridDim.x * NT;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n8; i += stride) {
+        const s8 v = __builtin_nontemporal_load(g8 + i);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float f = __bfloat162float(__builtin_bit_cast(bf16, (short)v[e]));
+            acc += f * f;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+        const float f = __bfloat162float(g[(n8 << 3) + threadIdx.x]);
+        acc += f * f;
+    }
+    acc = block_sum(acc);
+    if (threadIdx.x == 0) ws[blockIdx.x] = acc;
+}
+
 struct AdamArgs {
     float* p;
-    const float* g;
+    const void* g;          // fp32, or bf16 when GB16
     float* m;
     float* v;
     bf16* shadow;
@@ -193,38 +216,56 @@ struct AdamArgs {
     const float* sqnorm;    // device scalar: sum of squares over ALL grads of the step (or null)
     float max_norm;
     float lr;
+    const float* lr_dev;    // device scalar replacing lr (or null)
     const float* lr_scale;  // device scalar from xggm_sched_step (or null = 1)
     float b1, b2, eps, wd;
+    unsigned char* shadow8;     // e4m3 copy of the updated weights (or null)
+    const uint16_t* w8_id;      // per 256-element arena chunk: entry of the scale table, 0 = no e4m3 copy
+    const float* w8_qscale;
+    float* w8_amax;
+    int64_t elem0;              // arena offset of p[0] (multiple of 256 with shadow8)
 };
 
 // One float4 of each of p, g, m, v per step; UNR independent float4 quadruples per thread and
 // iteration (loads issued before any use).  g is read once and m, v, shadow are not re-read before the
 // next step: non-temporal accesses keep them from displacing the weights' bf16 shadow in L2/MALL.
-template <int UNR, bool NTMP>
+template <int UNR, bool NTMP, bool GB16>
 __global__ __launch_bounds__(NT) void bertadam_kernel(AdamArgs a) {
     float coef = 1.f;
     if (a.sqnorm) {
         const float total = sqrtf(*a.sqnorm);
         coef = fminf(a.max_norm / (total + 1e-6f), 1.f);  // torch.nn.utils.clip_grad_norm_
     }
-    const float lr = a.lr * (a.lr_scale ? *a.lr_scale : 1.f);
+    const float lr = (a.lr_dev ? *a.lr_dev : a.lr) * (a.lr_scale ? *a.lr_scale : 1.f);
     const int64_t n4 = a.n >> 2;
     typedef float __attribute__((ext_vector_type(4))) f4;
     typedef short __attribute__((ext_vector_type(4))) s4;
     const int64_t stride = (int64_t)gridDim.x * NT;
-    for (int64_t i0 = (int64_t)blockIdx.x * NT + threadIdx.x; i0 < n4; i0 += stride * UNR) {
+    const int lane = threadIdx.x & 63;
+    // every wave handles 64 consecutive float4 = one 256-element chunk of the arena per unrolled step, so the
+    // chunk's scale-table entry is wave-uniform.  The trip count is made block-uniform (i0 of thread 0) so that
+    // the wave reduction below runs with all lanes present; lanes beyond n4 only idle.
+    for (int64_t b0 = (int64_t)blockIdx.x * NT; b0 < n4; b0 += stride * UNR) {
+        const int64_t i0 = b0 + threadIdx.x;
         f4 p[UNR], g[UNR], m[UNR], v[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int64_t i = i0 + u * stride;
             if (i < n4) {
                 p[u] = NTMP ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(a.p) + i) : reinterpret_cast<const f4*>(a.p)[i];
-                if (NTMP) {
+                if (GB16) {
+                    const s4 gb = __builtin_nontemporal_load(reinterpret_cast<const s4*>(a.g) + i);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) g[u][k] = __bfloat162float(__builtin_bit_cast(bf16, (short)gb[k]));
+                } else if (NTMP) {
                     g[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(a.g) + i);
+                } else {
+                    g[u] = reinterpret_cast<const f4*>(a.g)[i];
+                }
+                if (NTMP) {
                     m[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(a.m) + i);
                     v[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(a.v) + i);
                 } else {
-                    g[u] = reinterpret_cast<const f4*>(a.g)[i];
                     m[u] = reinterpret_cast<const f4*>(a.m)[i];
                     v[u] = reinterpret_cast<const f4*>(a.v)[i];
                 }
@@ -233,35 +274,56 @@ __global__ __launch_bounds__(NT) void bertadam_kernel(AdamArgs a) {
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int64_t i = i0 + u * stride;
-            if (i >= n4) continue;
+            const bool on = i < n4;
+            if (on) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float gk = g[u][k] * coef;
-                m[u][k] = m[u][k] * a.b1 + (1.f - a.b1) * gk;
-                v[u][k] = v[u][k] * a.b2 + (1.f - a.b2) * gk * gk;
-                const float upd = m[u][k] / (sqrtf(v[u][k]) + a.eps) + a.wd * p[u][k];
-                p[u][k] -= lr * upd;
-            }
-            if (NTMP) __builtin_nontemporal_store(p[u], reinterpret_cast<f4*>(a.p) + i);
-            else reinterpret_cast<f4*>(a.p)[i] = p[u];
-            if (NTMP) {
-                __builtin_nontemporal_store(m[u], reinterpret_cast<f4*>(a.m) + i);
-                __builtin_nontemporal_store(v[u], reinterpret_cast<f4*>(a.v) + i);
-            } else {
-                reinterpret_cast<f4*>(a.m)[i] = m[u];
-                reinterpret_cast<f4*>(a.v)[i] = v[u];
-            }
-            if (a.shadow) {
-                s4 sh;
+                for (int k = 0; k < 4; ++k) {
+                    const float gk = g[u][k] * coef;
+                    m[u][k] = m[u][k] * a.b1 + (1.f - a.b1) * gk;
+                    v[u][k] = v[u][k] * a.b2 + (1.f - a.b2) * gk * gk;
+                    const float upd = m[u][k] / (sqrtf(v[u][k]) + a.eps) + a.wd * p[u][k];
+                    p[u][k] -= lr * upd;
+                }
+                if (NTMP) __builtin_nontemporal_store(p[u], reinterpret_cast<f4*>(a.p) + i);
+                else reinterpret_cast<f4*>(a.p)[i] = p[u];
+                if (NTMP) {
+                    __builtin_nontemporal_store(m[u], reinterpret_cast<f4*>(a.m) + i);
+                    __builtin_nontemporal_store(v[u], reinterpret_cast<f4*>(a.v) + i);
+                } else {
+                    reinterpret_cast<f4*>(a.m)[i] = m[u];
+                    reinterpret_cast<f4*>(a.v)[i] = v[u];
+                }
+                if (a.shadow) {
+                    s4 sh;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) sh[k] = __builtin_bit_cast(short, __float2bfloat16(p[u][k]));
-                reinterpret_cast<s4*>(a.shadow)[i] = sh;
+                    for (int k = 0; k < 4; ++k) sh[k] = __builtin_bit_cast(short, __float2bfloat16(p[u][k]));
+                    reinterpret_cast<s4*>(a.shadow)[i] = sh;
+                }
+            }
+            if (a.shadow8) {
+                // chunk of lane 0 == chunk of every lane of the wave; lanes past the end contribute nothing
+                const int64_t iw = (b0 + (threadIdx.x & ~63)) + u * stride;
+                const unsigned id = iw < n4 ? a.w8_id[(a.elem0 + 4 * iw) >> 8] : 0u;
+                if (id) {
+                    const float q = a.w8_qscale[id];
+                    float mx = 0.f;
+                    if (on) {
+                        mx = fmaxf(fmaxf(fabsf(p[u][0]), fabsf(p[u][1])), fmaxf(fabsf(p[u][2]), fabsf(p[u][3])));
+                        reinterpret_cast<int*>(a.shadow8)[i] = pack4_e4m3(p[u][0], p[u][1], p[u][2], p[u][3], q);
+                    }
+                    // Only maxima near or beyond the representable range matter to the next scale (e4m3 is a
+                    // floating-point format: a stale smaller range costs nothing until values shrink by orders of
+                    // magnitude, see xggm_fp8_scale_update): a few per cent of the waves issue the atomic.
+                    mx = wave_max(mx);
+                    if (lane == 0 && mx > 0.75f * 448.f / q) atomic_max_nonneg(a.w8_amax + id, mx);
+                }
             }
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {
+    if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {  // (ranges with an e4m3 copy are multiples of 256: no tail there)
         const int64_t i = (n4 << 2) + threadIdx.x;
-        const float gk = a.g[i] * coef;
+        const float gi = GB16 ? __bfloat162float(reinterpret_cast<const bf16*>(a.g)[i]) : reinterpret_cast<const float*>(a.g)[i];
+        const float gk = gi * coef;
         const float m = a.m[i] * a.b1 + (1.f - a.b1) * gk;
         const float v = a.v[i] * a.b2 + (1.f - a.b2) * gk * gk;
         const float p = a.p[i] - lr * (m / (sqrtf(v) + a.eps) + a.wd * a.p[i]);
@@ -270,6 +332,34 @@ __global__ __launch_bounds__(NT) void bertadam_kernel(AdamArgs a) {
         a.p[i] = p;
         if (a.shadow) a.shadow[i] = __float2bfloat16(p);
     }
+}
+
+// Delayed scaling of the e4m3 operands (weights and activation sites share one table).  Producers record the
+// maximum of a step only when it comes near the representable range 448 / q (> 1/2 of it; the weight update
+// > 3/4), so per entry: a recorded maximum m within the history -> range = margin * m; nothing recorded for a whole
+// history -> the range halves when `shrink` (values have shrunk a lot; still no overflow, finer subnormals) or stays
+// (weights).  qscale <= 0 marks an entry that has not been calibrated: its producers quantise with 1 and record
+// every maximum, and it stays uncalibrated until something was recorded.
+__global__ void fp8_scale_update_kernel(float* amax, float* hist, float* qscale, float* dscale, int64_t* pos, int n,
+                                        int hist_len, float margin, int shrink, int bump) {
+    const int i = threadIdx.x;
+    const int slot = (int)(*pos % hist_len);
+    if (i < n) {
+        const float q0 = qscale[i];
+        hist[(int64_t)i * hist_len + slot] = amax[i];
+        amax[i] = 0.f;
+        float m = 0.f;
+        for (int j = 0; j < hist_len; ++j) m = fmaxf(m, hist[(int64_t)i * hist_len + j]);
+        float q = q0;
+        if (m > 0.f) q = 448.f / (m * margin);
+        else if (q0 > 0.f && shrink && slot == hist_len - 1) q = fminf(q0 * 2.f, 1.0995e12f);
+        if (q > 0.f) {
+            qscale[i] = q;
+            dscale[i] = 1.f / q;
+        }
+    }
+    __syncthreads();  // every thread has read *pos
+    if (bump && i == 0) *pos += 1;
 }
 
 // lr_scale = warmup_linear(step / t_total, warmup); step += 1   (t_total <= 0: scale = 1)
@@ -393,6 +483,17 @@ extern "C" int xggm_sqnorm_f32(const float* g, int64_t n, float* out, float* ws,
     return xggm_check_launch("xggm_sqnorm_f32");
 }
 
+namespace {
+int launch_adam(const AdamArgs& a, bool g_bf16, hipStream_t st) {
+    // measured on MI355X (tools/bench_adam.py, 110 M parameters): 4.7 TB/s with plain accesses and a 4096-block
+    // grid-stride loop, 6.3 TB/s with non-temporal g/m/v and one or two float4 quadruples per thread
+    const dim3 grid(grid1d(a.n / 8 + 1, 65536));
+    if (g_bf16) hipLaunchKernelGGL((bertadam_kernel<2, true, true>), grid, dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL((bertadam_kernel<2, true, false>), grid, dim3(NT), 0, st, a);
+    return xggm_check_launch("xggm_bertadam");
+}
+}  // namespace
+
 extern "C" int xggm_bertadam_f32(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n,
                                  const float* sqnorm, float max_norm, float lr, const float* lr_scale, float b1, float b2,
                                  float eps, float weight_decay, hipStream_t st) {
@@ -401,11 +502,43 @@ extern "C" int xggm_bertadam_f32(float* p, const float* g, float* m, float* v, v
                   reinterpret_cast<uintptr_t>(v)) % 16 == 0,
                  "xggm_bertadam_f32: pointers must be 16-byte aligned");
     XGGM_REQUIRE(!shadow_bf16 || reinterpret_cast<uintptr_t>(shadow_bf16) % 8 == 0, "xggm_bertadam_f32: shadow misaligned");
-    AdamArgs a{p, g, m, v, (bf16*)shadow_bf16, n, sqnorm, max_norm, lr, lr_scale, b1, b2, eps, weight_decay};
-    // measured on MI355X (tools/bench_adam.py, 110 M parameters): 4.7 TB/s with plain accesses and a 4096-block
-    // grid-stride loop, 6.3 TB/s with non-temporal g/m/v and one or two float4 quadruples per thread
-    hipLaunchKernelGGL((bertadam_kernel<2, true>), dim3(grid1d(n / 8 + 1, 65536)), dim3(NT), 0, st, a);
-    return xggm_check_launch("xggm_bertadam_f32");
+    AdamArgs a{p, g, m, v, (bf16*)shadow_bf16, n, sqnorm, max_norm, lr, nullptr, lr_scale, b1, b2, eps, weight_decay,
+               nullptr, nullptr, nullptr, nullptr, 0};
+    return launch_adam(a, false, st);
+}
+
+extern "C" int xggm_bertadam_ex(const xggm_adam_args* x, hipStream_t st) {
+    XGGM_REQUIRE(x && x->p && x->g && x->m && x->v && x->n > 0, "xggm_bertadam_ex: bad arguments");
+    XGGM_REQUIRE((reinterpret_cast<uintptr_t>(x->p) | reinterpret_cast<uintptr_t>(x->m) | reinterpret_cast<uintptr_t>(x->v)) % 16 == 0 &&
+                     reinterpret_cast<uintptr_t>(x->g) % (x->g_bf16 ? 8 : 16) == 0,
+                 "xggm_bertadam_ex: pointers must be 16-byte aligned (bf16 gradients: 8)");
+    XGGM_REQUIRE(!x->shadow_bf16 || reinterpret_cast<uintptr_t>(x->shadow_bf16) % 8 == 0, "xggm_bertadam_ex: shadow misaligned");
+    XGGM_REQUIRE(!x->shadow8 || (x->w8_id && x->w8_qscale && x->w8_amax && x->elem0 % 256 == 0 && x->n % 4 == 0 &&
+                                 reinterpret_cast<uintptr_t>(x->shadow8) % 4 == 0),
+                 "xggm_bertadam_ex: the e4m3 copy needs the chunk table, the scale table and a range that starts on a "
+                 "256-element chunk of the arena");
+    AdamArgs a{x->p, x->g, x->m, x->v, (bf16*)x->shadow_bf16, x->n, x->sqnorm, x->max_norm, x->lr, x->lr_dev, x->lr_scale,
+               x->b1, x->b2, x->eps, x->weight_decay, (unsigned char*)x->shadow8, x->w8_id, x->w8_qscale, x->w8_amax, x->elem0};
+    return launch_adam(a, x->g_bf16 != 0, st);
+}
+
+extern "C" int xggm_sqnorm_bf16(const void* g, int64_t n, float* out, float* ws, hipStream_t st) {
+    XGGM_REQUIRE(g && out && ws && n > 0, "xggm_sqnorm_bf16: bad arguments");
+    XGGM_REQUIRE(reinterpret_cast<uintptr_t>(g) % 16 == 0, "xggm_sqnorm_bf16: pointer must be 16-byte aligned");
+    const int nblk = grid1d(n / 64 + 1, 4096);
+    hipLaunchKernelGGL(sqnorm_bf16_kernel, dim3(nblk), dim3(NT), 0, st, (const bf16*)g, n, ws);
+    hipLaunchKernelGGL(sqnorm_finish_kernel, dim3(1), dim3(NT), 0, st, ws, nblk, out);
+    return xggm_check_launch("xggm_sqnorm_bf16");
+}
+
+extern "C" int xggm_fp8_scale_update(float* amax, float* hist, float* qscale, float* dscale, int64_t* pos, int n,
+                                     int hist_len, float margin, int shrink, int bump, hipStream_t st) {
+    XGGM_REQUIRE(amax && hist && qscale && dscale && pos && n > 0 && n <= 1024 && hist_len > 0 && hist_len <= 64 && margin >= 1.f,
+                 "xggm_fp8_scale_update: bad arguments (n = %d <= 1024 entries, history %d <= 64, margin %g >= 1)", n,
+                 hist_len, (double)margin);
+    hipLaunchKernelGGL(fp8_scale_update_kernel, dim3(1), dim3(1024), 0, st, amax, hist, qscale, dscale, pos, n, hist_len,
+                       margin, shrink, bump);
+    return xggm_check_launch("xggm_fp8_scale_update");
 }
 
 extern "C" int xggm_sched_step(int64_t* step, float* lr_scale, int64_t t_total, float warmup, hipStream_t st) {

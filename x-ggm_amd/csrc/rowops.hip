@@ -179,6 +179,10 @@ __global__ __launch_bounds__(LN_FWD_W * 64) void ln_fwd_kernel(LnFwdGroup G, int
     rng_load(d.rng, seed, off);
     const float ik_pre = d.p_pre > 0.f ? 1.f / (1.f - d.p_pre) : 1.f;
     const float ik_post = d.p_post > 0.f ? 1.f / (1.f - d.p_post) : 1.f;
+    unsigned char* out8 = sizeof(T) == 2 ? reinterpret_cast<unsigned char*>(sg.out8) : nullptr;
+    const Q8 qs(out8 ? sg.qscale : nullptr);
+    const float q8 = qs.q;
+    float amax8 = 0.f;
     for (int row = blk * LN_FWD_W + wid; row < M; row += nblk * LN_FWD_W) {
         const int64_t rb = (int64_t)row * H;
         float z[NV][4];
@@ -268,7 +272,23 @@ __global__ __launch_bounds__(LN_FWD_W * 64) void ln_fwd_kernel(LnFwdGroup G, int
                     for (int i = 0; i < 4; ++i) y[i] += o4[i];
                 }
                 store4(out + rb + c, y);
+                if (out8) {  // e4m3 operand of the next fp8 product: 4 bytes per lane, 256 contiguous bytes per wave
+                    amax8 = fmaxf(fmaxf(amax8, fmaxf(fabsf(y[0]), fabsf(y[1]))), fmaxf(fabsf(y[2]), fabsf(y[3])));
+                    *reinterpret_cast<int*>(out8 + rb + c) = pack4_e4m3(y[0], y[1], y[2], y[3], q8);
+                }
             }
+        }
+    }
+    if (out8 && sg.amax) {  // one atomic per workgroup
+        __shared__ float red8[LN_FWD_W];
+        const float wv = wave_max(amax8);
+        if (lane == 0) red8[wid] = wv;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float bm = red8[0];
+#pragma unroll
+            for (int w = 1; w < LN_FWD_W; ++w) bm = fmaxf(bm, red8[w]);
+            if (bm > qs.thr) atomic_max_nonneg(sg.amax, bm);
         }
     }
 }
@@ -751,7 +771,7 @@ template <typename T>
 int ln_fwd(const void* in, const float* bias, const void* residual, const float* gamma, const float* beta, void* out,
            void* z_out, float* stats, int M, int H, float eps, float p_pre, float p_post, const uint64_t* rng,
            uint32_t s_pre, uint32_t s_post, int accumulate, float out_scale, hipStream_t st) {
-    const xggm_ln_fwd_problem q{in, bias, residual, gamma, beta, out, z_out, stats, M, s_pre, s_post, 0};
+    const xggm_ln_fwd_problem q{in, bias, residual, gamma, beta, out, z_out, stats, M, s_pre, s_post, 0, nullptr, nullptr, nullptr};
     return ln_fwd_grouped<T>(&q, 1, H, eps, p_pre, p_post, rng, accumulate, out_scale, st);
 }
 

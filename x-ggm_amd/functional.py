@@ -93,6 +93,8 @@ class Runtime:
     def advance(self):
         """new dropout masks / noise for the next pass (graph-capturable)."""
         ops.rng_advance(self.rng, 1)
+        if self.arena.fp8 is not None:
+            self.arena.fp8.step()  # delayed scaling: the activation maxima of this pass set the next pass's scales
 
 
 def _w(rt, p):
@@ -194,7 +196,12 @@ def drive(dt, gens):
         if rows:
             ops.launch_row_requests(rows)
         if probs:
-            ops.gemm_group(dt, probs)
+            p8 = [p for p in probs if getattr(p, "is8", False)]
+            if p8:
+                ops.gemm_group8(p8)
+                probs = [p for p in probs if not getattr(p, "is8", False)]
+            if probs:
+                ops.gemm_group(dt, probs)
         alive = nxt
     return out
 
@@ -214,25 +221,54 @@ def g_attn_fwd(rt, att, outm, xq, xkv, mask, B, Sq, Sk, salt):
     wq, wk, wv = att.query.weight, att.key.weight, att.value.weight
     bq, bk, bv = att.query.bias, att.key.bias, att.value.bias
     self_att = xkv is None
+    # fp8 forward (xggm_amd.fp8): ``emit`` = producers write e4m3 copies and record maxima (also while calibrating),
+    # ``use8`` = the products read them
+    f8 = a.fp8 if xq.dtype == torch.bfloat16 else None
+    emit, use8 = f8 is not None, f8 is not None and f8.active
+    if emit:
+        xq8, sq = f8.get(xq, ("in", id(att), salt, 0))
+        if not self_att:
+            xkv8, skv = f8.get(xkv, ("in", id(att), salt, 1))
     if self_att:
-        p1, qkv, _ = ops.p_fwd(xq, a.fused([wq, wk, wv]), a.fused([bq, bk, bv]))
+        if use8:
+            w8, sw = f8.w8([wq, wk, wv])
+            p1, qkv, _ = ops.p_fwd8(xq8, w8, sq, sw, a.fused([bq, bk, bv]))
+            p1.is8 = True
+        else:
+            p1, qkv, _ = ops.p_fwd(xq, a.fused([wq, wk, wv]), a.fused([bq, bk, bv]))
         kv = None
         yield [p1]
         q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
     else:
-        p1, qkv, _ = ops.p_fwd(xq, a.w(wq), bq.data)
-        p2, kv, _ = ops.p_fwd(xkv, a.fused([wk, wv]), a.fused([bk, bv]))
+        if use8:
+            w8q, sw = f8.w8(wq)
+            w8kv, _ = f8.w8([wk, wv])
+            p1, qkv, _ = ops.p_fwd8(xq8, w8q, sq, sw, bq.data)
+            p2, kv, _ = ops.p_fwd8(xkv8, w8kv, skv, sw, a.fused([bk, bv]))
+            p1.is8 = p2.is8 = True
+        else:
+            p1, qkv, _ = ops.p_fwd(xq, a.w(wq), bq.data)
+            p2, kv, _ = ops.p_fwd(xkv, a.fused([wk, wv]), a.fused([bk, bv]))
         yield [p1, p2]
         q, k, v = qkv, kv[:, :H], kv[:, H:]
     p_att, p_hid = rt.p(rt.p_attn), rt.p(rt.p_hidden)
-    core = ops.AttnFwdReq(q, k, v, mask, B, heads, Sq, Sk, p_att, rt.rng, att._sid + salt)
+    e_ctx = f8.emit(("ctx", id(att), salt)) if emit else (None, None)
+    core = ops.AttnFwdReq(q, k, v, mask, B, heads, Sq, Sk, p_att, rt.rng, att._sid + salt, emit8=e_ctx[0])
     yield core
     c = core.out
-    p3, h, _ = ops.p_fwd(c, a.w(outm.dense.weight), None)
+    if use8 and core.out8 is not None:
+        w8o, swo = f8.w8(outm.dense.weight)
+        p3, h, _ = ops.p_fwd8(core.out8, w8o, f8.dscale[e_ctx[1]:e_ctx[1] + 1], swo, None)
+        p3.is8 = True
+    else:
+        p3, h, _ = ops.p_fwd(c, a.w(outm.dense.weight), None)
     yield [p3]
+    e_ln = f8.emit(("ln", id(outm), salt)) if emit else (None, None)
     ln = ops.LnFwdReq(h, outm.dense.bias.data, xq, outm.LayerNorm.weight.data, outm.LayerNorm.bias.data, 1e-12,
-                      p_pre=p_hid, rng=rt.rng, sid_pre=outm._sid + salt)
+                      p_pre=p_hid, rng=rt.rng, sid_pre=outm._sid + salt, emit8=e_ln[0])
     yield ln
+    if emit:
+        f8.put(ln.out, ln.out8, e_ln[1])
     return ln.out, (att, outm, (B, Sq, Sk, heads, H, p_att, p_hid, self_att, salt),
                     (xq, xkv, mask, qkv, kv, c, ln.z, ln.stats))
 
@@ -309,20 +345,41 @@ def g_ffn_fwd(rt, inter, outm, x):
     """BertIntermediate + BertOutput (src/lxrt/modeling.py:428-445):
     y = LN(dropout(W_2 gelu(W_1 x + b_1) + b_2) + x)."""
     a = rt.arena
-    p1, act, u = ops.p_fwd(x, a.w(inter.dense.weight), inter.dense.bias.data, act=ops.ACT_GELU, want_preact=True)
+    f8 = a.fp8 if x.dtype == torch.bfloat16 else None
+    emit, use8 = f8 is not None, f8 is not None and f8.active
+    act8 = e_act = None
+    if emit:
+        x8, sx = f8.get(x, ("in", id(inter), 0, 0))
+        e_act = f8.emit(("act", id(inter)))
+        act8 = torch.empty((x.shape[0], inter.dense.weight.shape[0]), device=x.device, dtype=torch.uint8)
+        e8 = (act8,) + e_act[0]
+    if use8:
+        w8, sw = f8.w8(inter.dense.weight)
+        p1, act, u = ops.p_fwd8(x8, w8, sx, sw, inter.dense.bias.data, act=ops.ACT_GELU, want_preact=True, emit8=e8)
+        p1.is8 = True
+    else:
+        p1, act, u = ops.p_fwd(x, a.w(inter.dense.weight), inter.dense.bias.data, act=ops.ACT_GELU, want_preact=True,
+                               emit8=e8 if emit else None)
     yield [p1]
     w2 = a.w(outm.dense.weight)
-    S = _SPLIT_K if (x.dtype == torch.bfloat16 and w2.shape[1] >= 2048 and w2.shape[1] % (64 * max(_SPLIT_K, 1)) == 0) else 0
-    if S > 1:
+    S = _SPLIT_K if (x.dtype == torch.bfloat16 and w2.shape[1] >= 2048 and w2.shape[1] % (128 * max(_SPLIT_K, 1)) == 0) else 0
+    if use8:
+        w8, sw = f8.w8(outm.dense.weight)
+        p2, h, _ = ops.p_fwd8(act8, w8, f8.dscale[e_act[1]:e_act[1] + 1], sw, None, split=S if S > 1 else 0)
+        p2.is8 = True
+    elif S > 1:
         # K = 3072, N = 768: too few tiles for their long k-loop -> S slices of K, summed by the LayerNorm below
         p2, h = ops.p_fwd_splitk(act, w2, S)
     else:
         p2, h, _ = ops.p_fwd(act, w2, None)
     yield [p2]
     p_hid = rt.p(rt.p_hidden)
+    e_ln = f8.emit(("ln", id(outm), 0)) if emit else (None, None)
     ln = ops.LnFwdReq(h, outm.dense.bias.data, x, outm.LayerNorm.weight.data, outm.LayerNorm.bias.data, 1e-12,
-                      p_pre=p_hid, rng=rt.rng, sid_pre=outm._sid, dtype=x.dtype)
+                      p_pre=p_hid, rng=rt.rng, sid_pre=outm._sid, dtype=x.dtype, emit8=e_ln[0])
     yield ln
+    if emit:
+        f8.put(ln.out, ln.out8, e_ln[1])
     return ln.out, (inter, outm, p_hid, (x, u, act, ln.z, ln.stats))
 
 

@@ -355,6 +355,8 @@ class LXRTEncoder(nn.Module):
         # the vector region are the only gradients that are final last: the exposed tail of the exchange), after
         # the first two layer pairs, before the first and before the second-to-last cross-modality layer.
         rt = runtime_of(self)
+        if rt.arena.fp8 is not None:
+            rt.arena.fp8.begin_forward()
         cutting = rt.cut_enabled and torch.is_grad_enabled()
         pair_cut = 2 if n_pair >= 4 else None
         x_mid = self.num_x_layers - 2 if self.num_x_layers >= 4 else None

@@ -224,9 +224,19 @@ class BertAdam(Optimizer):
             todo.append((G, pg, arena.group_index[g]))
         if todo:  # schedule values and step counters of all groups: one launch
             ops.sched_step_multi(arena.steps, arena.lr_scale, [(gi, pg['t_total'], pg['warmup']) for _, pg, gi in todo])
+        f8 = arena.fp8
         for G, pg, gi in todo:
             scale_t = arena.lr_scale[gi:gi + 1]
             sl = slice(G.start, G.end)
+            w8 = f8.adam_w8(G.name) if f8 is not None else None
+            if w8 is not None:
+                # fp8 forward: this group's weight operands get their e4m3 copies from the same pass over p, with
+                # the scales the delayed update derives from the maxima earlier steps recorded
+                f8.update_weight_scales(G.name)
+                ops.bertadam_ex(arena.params[sl], arena.grads[sl], arena.m[sl], arena.v[sl], arena.shadow[sl], sq, max_norm,
+                                pg['lr'], scale_t, pg['b1'], pg['b2'], pg['e'], pg['weight_decay'],
+                                w8=(f8.shadow8[sl],) + w8, elem0=G.start)
+                continue
             ops.bertadam(arena.params[sl], arena.grads[sl], arena.m[sl], arena.v[sl],
                          None if arena.shadow is None else arena.shadow[sl], sq, max_norm, pg['lr'], scale_t,
                          pg['b1'], pg['b2'], pg['e'], pg['weight_decay'])

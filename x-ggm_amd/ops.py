@@ -77,13 +77,17 @@ FP8 = torch.float8_e4m3fn
 FP8_MAX = 448.0
 
 
-def quantize_fp8(x, qscale=None, amax=None):
+def quantize_fp8(x, qscale=None, amax=None, out=None):
     """x (fp32 / bf16, contiguous, numel % 8 == 0) -> e4m3fn(clamp(x * qscale, +-448)); ``qscale``: 1-element fp32
-    device tensor or None (1); ``amax``: 1-element fp32 device tensor raised to max |x|, or None."""
+    device tensor or None (1); ``amax``: 1-element fp32 device tensor raised to max |x|, or None; ``out``: a
+    contiguous 1-byte tensor of the same number of elements to write into."""
     _c(x)
     if x.dtype not in (F32, BF16):
         raise RuntimeError("quantize_fp8: fp32 or bf16 input expected, got %s" % x.dtype)
-    y = torch.empty(x.shape, device=x.device, dtype=FP8)
+    if out is not None:
+        _c(out)
+        assert out.numel() == x.numel() and out.element_size() == 1
+    y = out if out is not None else torch.empty(x.shape, device=x.device, dtype=FP8)
     call("xggm_quantize_fp8e4m3_" + sfx(x.dtype), ptr(x), ptr(y), x.numel(), ptr(qscale), ptr(amax), stream())
     return y
 
@@ -158,7 +162,9 @@ class GemmProblem(_ct.Structure):
                 ("a_bs", _ct.c_int64), ("b_bs", _ct.c_int64), ("c_bs", _ct.c_int64),
                 ("bias", _ct.c_void_p), ("residual", _ct.c_void_p), ("preact", _ct.c_void_p), ("aux", _ct.c_void_p),
                 ("colsum", _ct.c_void_p), ("act", _ct.c_int), ("c_f32", _ct.c_int), ("accumulate", _ct.c_int), ("alpha", _ct.c_float),
-                ("sqsum", _ct.c_void_p)]
+                ("sqsum", _ct.c_void_p),
+                ("scale_a", _ct.c_void_p), ("scale_b", _ct.c_void_p), ("c8", _ct.c_void_p), ("c8_qscale", _ct.c_void_p),
+                ("c8_amax", _ct.c_void_p)]
 
 
 def _problem(A, B, C, M, N, K, a_rs, a_ks, b_ns, b_ks, ldc, bias=None, residual=None, preact=None, aux=None,
@@ -171,14 +177,21 @@ def _problem(A, B, C, M, N, K, a_rs, a_ks, b_ns, b_ks, ldc, bias=None, residual=
     return p
 
 
-def p_fwd(x, w, bias=None, act=ACT_NONE, want_preact=False, out_f32=False):
-    """problem for y = act(x @ w^T + bias); returns (problem, y, preact)."""
+def p_fwd(x, w, bias=None, act=ACT_NONE, want_preact=False, out_f32=False, emit8=None):
+    """problem for y = act(x @ w^T + bias); returns (problem, y, preact).  ``emit8`` = (y8, qscale, amax): also
+    write y as e4m3 (see p_fwd8)."""
     M, K, a_rs = _rows(_chk(x))
     N = w.shape[0]
     assert w.shape[1] == K and w.dtype == x.dtype and w.is_contiguous()
     y = torch.empty((M, N), device=x.device, dtype=F32 if out_f32 else x.dtype)
     pre = torch.empty((M, N), device=x.device, dtype=x.dtype) if want_preact else None
-    return _problem(x, w, y, M, N, K, a_rs, 1, K, 1, N, bias=bias, preact=pre, act=act, c_f32=out_f32), y, pre
+    p = _problem(x, w, y, M, N, K, a_rs, 1, K, 1, N, bias=bias, preact=pre, act=act, c_f32=out_f32)
+    if emit8 is not None:
+        y8, q, amax = emit8
+        assert y8.shape == y.shape and y8.element_size() == 1 and y8.is_contiguous() and x.dtype == BF16 and not out_f32
+        p.c8, p.c8_qscale, p.c8_amax = ptr(y8), ptr(q), ptr(amax)
+        p.keep = p.keep + (y8, q, amax)
+    return p, y, pre
 
 
 def p_fwd_splitk(x, w, S):
@@ -194,6 +207,44 @@ def p_fwd_splitk(x, w, S):
     p = _problem(x, w, part, M, N, K // S, a_rs, 1, K, 1, N, c_f32=True)
     p.batch, p.a_bs, p.b_bs, p.c_bs = S, K // S, K // S, M * N
     return p, part
+
+
+def p_fwd8(x8, w8, sx, sw, bias=None, act=ACT_NONE, want_preact=False, emit8=None, split=0):
+    """problem for y = act(sx * sw * (x8 @ w8^T) + bias) with e4m3 operands x8 [M, K], w8 [N, K] (1-byte tensors, k
+    contiguous); ``sx`` / ``sw``: 1-element fp32 device tensors (reciprocal quantisation scales).  ``emit8`` =
+    (y8, qscale, amax): the producer also writes y as e4m3 (operand of the next fp8 product).  ``split`` > 1: the
+    partial products over K / split wide slices as fp32 [split, M, N] (see p_fwd_splitk).
+    Returns (problem, y, preact)."""
+    M, K, a_rs = _rows(_chk(x8))
+    N = w8.shape[0]
+    assert w8.shape[1] == K and x8.element_size() == 1 and w8.element_size() == 1 and w8.stride(1) == 1
+    if split > 1:
+        if K % (128 * split):
+            raise RuntimeError("p_fwd8: K = %d is not a multiple of 128 * %d" % (K, split))
+        y = torch.empty((split, M, N), device=x8.device, dtype=F32)
+        p = _problem(x8, w8, y, M, N, K // split, a_rs, 1, w8.stride(0), 1, N, c_f32=True)
+        p.batch, p.a_bs, p.b_bs, p.c_bs = split, K // split, K // split, M * N
+        pre = None
+    else:
+        y = torch.empty((M, N), device=x8.device, dtype=BF16)
+        pre = torch.empty((M, N), device=x8.device, dtype=BF16) if want_preact else None
+        p = _problem(x8, w8, y, M, N, K, a_rs, 1, w8.stride(0), 1, N, bias=bias, preact=pre, act=act)
+    p.scale_a, p.scale_b = ptr(sx), ptr(sw)
+    p.keep = p.keep + (sx, sw)
+    if emit8 is not None:
+        y8, q, amax = emit8
+        assert y8.shape == y.shape and y8.element_size() == 1 and y8.is_contiguous()
+        p.c8, p.c8_qscale, p.c8_amax = ptr(y8), ptr(q), ptr(amax)
+        p.keep = p.keep + (y8, q, amax)
+    return p, y, pre
+
+
+def gemm_group8(problems):
+    """launch up to 4 e4m3 forward products in one grid (more: consecutive groups of 4)."""
+    for i in range(0, len(problems), 4):
+        chunk = problems[i:i + 4]
+        arr = (GemmProblem * len(chunk))(*chunk)
+        call("xggm_gemm_grouped_fp8e4m3", _ct.cast(arr, _ct.c_void_p), len(chunk), stream())
 
 
 def p_dgrad(dy, w, residual=None, gelu_aux=None, colsum=None, into=None):
@@ -300,13 +351,16 @@ class AttnProblem(_ct.Structure):
                 ("scale", _ct.c_float), ("p", _ct.c_float), ("sid", _ct.c_uint32),
                 ("d_out", _ct.c_void_p), ("dq", _ct.c_void_p), ("dk", _ct.c_void_p), ("dv", _ct.c_void_p),
                 ("dq_rs", _ct.c_int64), ("dk_rs", _ct.c_int64), ("dv_rs", _ct.c_int64),
-                ("dbq", _ct.c_void_p), ("dbk", _ct.c_void_p), ("dbv", _ct.c_void_p)]
+                ("dbq", _ct.c_void_p), ("dbk", _ct.c_void_p), ("dbv", _ct.c_void_p),
+                ("out8", _ct.c_void_p), ("qscale", _ct.c_void_p), ("amax", _ct.c_void_p)]
 
 
 class AttnFwdReq:
     """attention core forward handed to ``functional.drive`` (see LnFwdReq).  Result: ``out``."""
 
-    def __init__(self, q, k, v, mask, B, heads, Sq, Sk, p, rng, sid):
+    def __init__(self, q, k, v, mask, B, heads, Sq, Sk, p, rng, sid, emit8=None):
+        """``emit8`` = (qscale, amax): 1-element fp32 device tensors; the context is then ALSO written as e4m3
+        (``out8``), the operand of the fp8 output projection"""
         d = 64
         H = heads * d
         for t, S in ((q, Sq), (k, Sk), (v, Sk)):
@@ -319,9 +373,14 @@ class AttnFwdReq:
         self.key = ("attn_fwd", q.dtype)
         self.rng = rng
         self.out = torch.empty((B * Sq, H), device=q.device, dtype=q.dtype)
+        self.out8 = None
         self.keep = (q, k, v, mask)
         self.prob = AttnProblem(ptr(q), ptr(k), ptr(v), ptr(mask), ptr(self.out), B, heads, Sq, Sk, q.stride(0), k.stride(0),
                                 v.stride(0), H, 0.125, float(p), sid, None, None, None, None, 0, 0, 0, None, None, None)
+        if emit8 is not None:
+            self.out8 = torch.empty((B * Sq, H), device=q.device, dtype=torch.uint8)
+            self.prob.out8, self.prob.qscale, self.prob.amax = ptr(self.out8), ptr(emit8[0]), ptr(emit8[1])
+            self.keep = self.keep + tuple(emit8)
 
 
 class AttnBwdReq:
@@ -376,7 +435,8 @@ class LnFwdProblem(_ct.Structure):
     """mirror of ``xggm_ln_fwd_problem`` (include/xggm.h)"""
     _fields_ = [("inp", _ct.c_void_p), ("bias", _ct.c_void_p), ("residual", _ct.c_void_p), ("gamma", _ct.c_void_p),
                 ("beta", _ct.c_void_p), ("out", _ct.c_void_p), ("z_out", _ct.c_void_p), ("stats", _ct.c_void_p),
-                ("M", _ct.c_int), ("sid_pre", _ct.c_uint32), ("sid_post", _ct.c_uint32), ("in_slabs", _ct.c_int)]
+                ("M", _ct.c_int), ("sid_pre", _ct.c_uint32), ("sid_post", _ct.c_uint32), ("in_slabs", _ct.c_int),
+                ("out8", _ct.c_void_p), ("qscale", _ct.c_void_p), ("amax", _ct.c_void_p)]
 
 
 class LnBwdProblem(_ct.Structure):
@@ -391,9 +451,10 @@ class LnFwdReq:
     """a residual-LayerNorm forward a block generator hands to ``functional.drive``: requests of the
     same round (language + vision stream) are launched together.  Results: ``out``, ``z``, ``stats``."""
 
-    def __init__(self, x, bias, residual, gamma, beta, eps, p_pre=0.0, rng=None, sid_pre=0, dtype=None):
+    def __init__(self, x, bias, residual, gamma, beta, eps, p_pre=0.0, rng=None, sid_pre=0, dtype=None, emit8=None):
         """``x``: [M, H] activations, or the fp32 split-K partial sums [S, M, H] of ``p_fwd_splitk`` (then
-        ``dtype`` = the activation type of out / z / residual)."""
+        ``dtype`` = the activation type of out / z / residual).  ``emit8`` = (qscale, amax): ``out`` is also
+        written as e4m3 (``out8``), the operand of the next fp8 product."""
         _c(x)
         slabs = 0
         if x.dim() == 3:
@@ -419,6 +480,12 @@ class LnFwdReq:
         self.keep = (x, bias, residual, gamma, beta)
         self.prob = LnFwdProblem(ptr(x), ptr(bias), ptr(residual), ptr(gamma), ptr(beta), ptr(self.out), ptr(self.z),
                                  ptr(self.stats), M, sid_pre, 0, slabs)
+        self.out8 = None
+        if emit8 is not None:
+            assert dtype == BF16
+            self.out8 = torch.empty((M, H), device=x.device, dtype=torch.uint8)
+            self.prob.out8, self.prob.qscale, self.prob.amax = ptr(self.out8), ptr(emit8[0]), ptr(emit8[1])
+            self.keep = self.keep + tuple(emit8)
 
 
 class LnBwdReq:
@@ -771,6 +838,51 @@ def bertadam(p, g, m, v, shadow, sqn, max_norm, lr, lr_scale, b1, b2, eps, wd):
         assert shadow.numel() == p.numel()
     call("xggm_bertadam_f32", ptr(p), ptr(g), ptr(m), ptr(v), ptr(shadow), p.numel(), ptr(sqn), float(max_norm),
          float(lr), ptr(lr_scale), float(b1), float(b2), float(eps), float(wd), stream())
+
+
+class AdamArgs(_ct.Structure):
+    """mirror of ``xggm_adam_args`` (include/xggm.h)"""
+    _fields_ = [("p", _ct.c_void_p), ("g", _ct.c_void_p), ("m", _ct.c_void_p), ("v", _ct.c_void_p),
+                ("shadow_bf16", _ct.c_void_p), ("n", _ct.c_int64), ("sqnorm", _ct.c_void_p), ("max_norm", _ct.c_float),
+                ("lr", _ct.c_float), ("lr_dev", _ct.c_void_p), ("lr_scale", _ct.c_void_p),
+                ("b1", _ct.c_float), ("b2", _ct.c_float), ("eps", _ct.c_float), ("weight_decay", _ct.c_float),
+                ("g_bf16", _ct.c_int), ("shadow8", _ct.c_void_p), ("w8_id", _ct.c_void_p), ("w8_qscale", _ct.c_void_p),
+                ("w8_amax", _ct.c_void_p), ("elem0", _ct.c_int64)]
+
+
+def bertadam_ex(p, g, m, v, shadow, sqn, max_norm, lr, lr_scale, b1, b2, eps, wd, lr_dev=None, w8=None, elem0=0):
+    """the update with device-resident lr (``lr_dev``), bf16 gradients (``g.dtype``) and/or the e4m3 weight copy
+    ``w8`` = (shadow8 slice, id table, qscale table, amax table); ``elem0``: arena offset of p[0]."""
+    for t in (p, m, v):
+        _c(t, F32)
+        assert t.numel() == p.numel()
+    _c(g)
+    assert g.numel() == p.numel() and g.dtype in (F32, BF16)
+    a = AdamArgs(ptr(p), ptr(g), ptr(m), ptr(v), ptr(shadow), p.numel(), ptr(sqn), float(max_norm), float(lr), ptr(lr_dev),
+                 ptr(lr_scale), float(b1), float(b2), float(eps), float(wd), int(g.dtype == BF16), None, None, None, None,
+                 int(elem0))
+    if w8 is not None:
+        s8, ids, q, amax = w8
+        assert s8.numel() == p.numel() and s8.element_size() == 1 and ids.dtype == torch.int16
+        a.shadow8, a.w8_id, a.w8_qscale, a.w8_amax = ptr(s8), ptr(ids), ptr(q), ptr(amax)
+    call("xggm_bertadam_ex", _ct.byref(a), stream())
+
+
+def sqnorm_bf16(g, out):
+    _c(g, BF16), _c(out, F32)
+    ws = _SQNORM_WS.get(g.device)
+    if ws is None:
+        ws = _SQNORM_WS[g.device] = torch.zeros(4100, device=g.device, dtype=F32)
+    call("xggm_sqnorm_bf16", ptr(g), g.numel(), ptr(out), ptr(ws), stream())
+
+
+def fp8_scale_update(amax, hist, qscale, dscale, pos, i0, n, hist_len, margin, shrink, bump):
+    """entries [i0, i0 + n) of a scale table (xggm_fp8_scale_update)"""
+    for t in (amax, hist, qscale, dscale):
+        _c(t, F32)
+    _c(pos, torch.int64)
+    call("xggm_fp8_scale_update", amax.data_ptr() + 4 * i0, hist.data_ptr() + 4 * i0 * hist_len, qscale.data_ptr() + 4 * i0,
+         dscale.data_ptr() + 4 * i0, ptr(pos), n, hist_len, float(margin), int(shrink), int(bump), stream())
 
 
 def sched_step(step, lr_scale, t_total, warmup):
