@@ -132,6 +132,8 @@ def build(args, device):
     rank = int(os.environ.get("RANK", 0))
     b = synth.vqa_batch(args.batch, A=args.answers, seed=1000 + rank)
     batch = {k: torch.from_numpy(v).to(device) for k, v in b.items() if k != "randn_adj"}
+    if dt == torch.bfloat16:
+        batch["feats"] = batch["feats"].to(torch.bfloat16)  # as the shard format stores them (tools/shards.py)
     n_iters = args.steps + args.warmup + 64
     lr = 5e-6 if args.order == "gqa" else 1e-6  # script/gqa_ood.sh:27, script/vqacpv2.sh:26; t_total = 2 * iterations
     optim = make_optimizer(model, lr, 2 * n_iters)
@@ -159,62 +161,45 @@ def synthetic_tokenizer():
         os.unlink(path)
 
 
-class HostLoader:
-    """what the reference's DataLoaderX hands the loop (src/tools/data_loader.py:8-10, src/vqa/vqacpv2.py:164-171):
-    host batches (feats, boxes, sent strings, target, adj) -- here a ring of seeded synthetic batches in PINNED
-    memory, a different one every step.  ``stage(i)`` tokenises batch i and queues its H2D copies on a copy
-    stream into one of two device staging sets; ``commit()`` makes the trainer's static input buffers take the
-    staged batch (device-to-device, on the compute stream, behind the copy's event).  Staging batch i + 1 while
-    step i runs hides PCIe behind the step."""
+def make_loader(model, args, device, n_batches=8):
+    """the input pipeline of the package on synthetic data: a shard file (xggm_amd.tools.shards: bf16 features,
+    normalised boxes, adjacency -- what replaces the reference's per-image h5 groups, src/vqa/vqacpv2_data.py:95-127)
+    of ``n_batches`` x batch images, question annotations over the synthetic vocabulary, the dataset mirror and the
+    prefetching ``DataLoaderX`` (src/tools/data_loader.py:8-10) with tokenisation and H2D on its producer thread."""
+    import tempfile
+    import numpy as np
+    from xggm_amd import synth
+    from xggm_amd.tools.shards import ShardWriter
+    from xggm_amd.tools.data_loader import DataLoaderX
+    from xggm_amd.vqa.vqacpv2_data import VQADataset, VQATorchDataset
+    rank = int(os.environ.get("RANK", 0))
+    rng = random.Random(args.seed + 77 * rank)
+    tmp = tempfile.mkdtemp(prefix="xggm_bench_")
+    path = os.path.join(tmp, "train_obj36.xgs")
+    w = ShardWriter(path, n_objects=36, feat_dim=2048)
+    data, img = [], 0
+    for i in range(n_batches):
+        b = synth.vqa_batch(args.batch, A=args.answers, seed=5000 + 100 * rank + i)
+        for k in range(args.batch):
+            w.add(img, b["feats"][k], b["boxes"][k] * np.float32(0.999), 1.0, 1.0, b["adj_true"][k])
+            lab = int(b["target"][k].argmax())
+            data.append({"question_id": img, "image_id": img, "label": [lab], "score": [1.0],
+                         "question": " ".join(rng.choice(_WORDS) for _ in range(rng.randint(3, 17)))})
+            img += 1
+    w.close()
+    label2ans = ["a%d" % k for k in range(args.answers)]
+    ds = VQADataset("train", data=data, ans2label={a: k for k, a in enumerate(label2ans)}, label2ans=label2ans)
+    ts = VQATorchDataset(ds, shard=path)
+    loader = DataLoaderX(ts, args.batch, shuffle=True, drop_last=True, device=device, batcher=model.lxrt_encoder.batcher,
+                         depth=3, seed=args.seed + rank, epochs=None)
+    host_bytes = args.batch * (36 * 2048 * 2 + 36 * 4 * 4 + args.answers * 4 + 36 * 36 * 4 + 3 * 20 * 8)
+    return loader, host_bytes, tmp
 
-    def __init__(self, trainer, model, args, device, n_batches=8):
-        from xggm_amd import synth
-        rank = int(os.environ.get("RANK", 0))
-        rng = random.Random(args.seed + 77 * rank)
-        self.trainer, self.batcher = trainer, model.lxrt_encoder.batcher
-        self.host = []
-        for i in range(n_batches):
-            b = synth.vqa_batch(args.batch, A=args.answers, seed=5000 + 100 * rank + i)
-            hb = {k: torch.from_numpy(b[k]).pin_memory() for k in ("feats", "boxes", "target", "adj_true")}
-            hb["sent"] = [" ".join(rng.choice(_WORDS) for _ in range(rng.randint(3, 17))) for _ in range(args.batch)]
-            self.host.append(hb)
-        self.copy = torch.cuda.Stream()
-        keys = ("feats", "boxes", "target", "adj_true")
-        self.stage_bufs = [{k: torch.empty_like(trainer.static[k]) for k in keys} for _ in range(2)]
-        for s in self.stage_bufs:
-            s["ids"] = torch.empty((3,) + tuple(trainer.static["input_ids"].shape), dtype=torch.long, device=device)
-        self.events = [torch.cuda.Event(), torch.cuda.Event()]
-        self.free = [torch.cuda.Event(), torch.cuda.Event()]  # staging set consumed by the compute stream
-        self.slot = 0
-        self.staged = None
-        self.bytes = sum(v.numel() * v.element_size() for k, v in self.host[0].items() if k != "sent") + \
-            3 * 8 * trainer.static["input_ids"].numel()
 
-    def stage(self, i):
-        hb = self.host[i % len(self.host)]
-        s = self.slot
-        ids = self.batcher.host_batch(hb["sent"])  # cached WordPiece ids -> pinned [3, B, T]
-        self.copy.wait_event(self.free[s])
-        with torch.cuda.stream(self.copy):
-            for k in ("feats", "boxes", "target", "adj_true"):
-                self.stage_bufs[s][k].copy_(hb[k], non_blocking=True)
-            self.stage_bufs[s]["ids"].copy_(ids, non_blocking=True)
-            self.batcher.record_copy()
-            self.events[s].record(self.copy)
-        self.staged = s
-        self.slot ^= 1
-
-    def commit(self):
-        s = self.staged
-        main = torch.cuda.current_stream()
-        main.wait_event(self.events[s])
-        st, sb = self.trainer.static, self.stage_bufs[s]
-        for k in ("feats", "boxes", "target", "adj_true"):
-            st[k].copy_(sb[k], non_blocking=True)
-        st["input_ids"].copy_(sb["ids"][0], non_blocking=True)
-        st["input_mask"].copy_(sb["ids"][1], non_blocking=True)
-        st["segment_ids"].copy_(sb["ids"][2], non_blocking=True)
-        self.free[s].record(main)
+def batch_of(item):
+    qid, feats, boxes, sent, target, adj = item
+    return dict(feats=feats, boxes=boxes, input_ids=sent[0], input_mask=sent[1], segment_ids=sent[2], target=target,
+                adj_true=adj)
 
 
 # ------------------------------------------------------------------------------------------ kernel timing
@@ -574,10 +559,14 @@ def main():
     barrier()
     log("warmup done")
     t0 = time.perf_counter()
+    host_s = 0.0
     for _ in range(args.steps):
+        h0 = time.perf_counter()
         trainer.iteration(branch())
+        host_s += time.perf_counter() - h0
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
+    log("host time in iteration(): %.3f ms/step" % (1000 * host_s / args.steps))
     ms_step = 1000.0 * dt / args.steps
     value = args.batch * world * args.steps / dt
     log("timed region: %.3f ms/step, %.1f samples/s" % (ms_step, value))
@@ -585,25 +574,42 @@ def main():
     # the same steps with the loader boundary inside the timed region (never `value`)
     with_loader = None
     if not args.no_loader:
-        loader = HostLoader(trainer, model, args, device)
-        for i in range(3):
-            loader.stage(i)
-            loader.commit()
-            trainer.iteration(branch())
-        loader.stage(0)
-        barrier()
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            loader.commit()             # batch i: staged while step i - 1 ran
-            trainer.iteration(branch())
-            loader.stage(i + 1)         # batch i + 1: tokenise + H2D on the copy stream, under step i
-        barrier()
-        dtl = max_over_ranks(time.perf_counter() - t1)
+        import shutil
+        loader, host_bytes, tmp = make_loader(model, args, device)
+        it = iter(loader)
+        try:
+            for i in range(3):
+                trainer.load_batch(batch_of(next(it)))
+                trainer.iteration(branch())
+            barrier()
+            t1 = time.perf_counter()
+            dbg = [0.0, 0.0, 0.0] if os.environ.get("XGGM_LOADER_DEBUG") else None
+            for i in range(args.steps):
+                # batch i was assembled, tokenised and copied to the device by the producer thread while step i - 1
+                # ran; load_batch hands it to the captured graphs' input buffers (device to device)
+                if dbg is None:
+                    trainer.load_batch(batch_of(next(it)))
+                    trainer.iteration(branch())
+                else:  # host-side time of the three calls
+                    a = time.perf_counter(); item = next(it)
+                    b_ = time.perf_counter(); trainer.load_batch(batch_of(item))
+                    c = time.perf_counter(); trainer.iteration(branch())
+                    d = time.perf_counter()
+                    dbg[0] += b_ - a; dbg[1] += c - b_; dbg[2] += d - c
+            barrier()
+            dtl = max_over_ranks(time.perf_counter() - t1)
+            if dbg is not None:
+                log("loader leg host ms/step: next %.3f, load_batch %.3f, iteration %.3f"
+                    % tuple(1000 * x / args.steps for x in dbg))
+        finally:
+            it.close()
+            shutil.rmtree(tmp, ignore_errors=True)
         with_loader = {"value": round(args.batch * world * args.steps / dtl, 2),
-                       "ms_per_step": round(1000.0 * dtl / args.steps, 3), "host_bytes_per_step": loader.bytes,
-                       "what": "fresh pinned host batch every step: cached WordPiece tokenisation of %d question "
-                               "strings, H2D on a copy stream into double-buffered staging, device-side hand-over "
-                               "to the captured graphs' input buffers" % args.batch}
+                       "ms_per_step": round(1000.0 * dtl / args.steps, 3), "host_bytes_per_step": host_bytes,
+                       "what": "a fresh batch every step through the package's input pipeline: memory-mapped shard "
+                               "(bf16 features) -> pinned buffers -> cached WordPiece tokenisation of %d question "
+                               "strings -> H2D on a copy stream (producer thread, 3 batches in flight) -> device-side "
+                               "hand-over to the captured graphs' input buffers" % args.batch}
         log("with loader: %.3f ms/step" % with_loader["ms_per_step"])
 
     # per-branch step time (diagnostic; not part of the timed region)

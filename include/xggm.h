@@ -426,6 +426,15 @@ int xggm_bce_bwd_f32(const float* logit, const float* target, const float* gout,
 int xggm_bce_bwd_bf16(const float* logit, const float* target, const float* gout, void* dlogit, int64_t n, float coef,
                       xggm_stream_t stream);
 
+/* ---- preprocessing that feeds the path ----------------------------------------------------
+ * adj_true of every sample: data/preprocess/vqa/compute_adjacency.py:38-45 (compute_cosin_sim_v2) + :90.
+ *   c[i][j] = cos(cls[i], attr[j]) for j >= i, 0 below the diagonal  (torch.cosine_similarity, eps 1e-6: each
+ *   norm clamped from below by eps);  a = c + c^T (the diagonal counts twice);  adj = a / max(a).
+ * cls, attr: fp32 [n_img][N][D] (BERT pooled embeddings of the objects' class and attribute names), adj: fp32
+ * [n_img][N][N]; N <= 64, D % 4 == 0. */
+int xggm_cosine_adjacency_f32(const float* cls, const float* attr, float* adj, int n_img, int N, int D, float eps,
+                              xggm_stream_t stream);
+
 /* ---- optimiser ---------------------------------------------------------------------------
  * *out += sum g^2 over a flat fp32 range (clip_grad_norm_, src/vqa/vqacpv2.py:175).  The sum is taken in a
  * fixed order (per-workgroup partials in `ws`, added up by a second one-workgroup launch), so data-parallel

@@ -479,3 +479,53 @@ def train_pass(P, M, V, step, batch, cfg, kind, base_lr, t_total, **kw):
     total, Gc = clip_grad_norm(G, 5.0)
     bert_adam_step(P, Gc, M, V, step, vqa_lr_of(base_lr), t_total)
     return loss.detach(), total, G, out
+
+
+# --------------------------------------------------------------------------- preprocessing / data (section 8f)
+def compute_cosin_sim_v2(matrix1, matrix2):
+    """adj_cos[i, j] = cosine_similarity(matrix1[i], matrix2[j]) for j >= i; adj_cos + adj_cos^T.
+    ref: data/preprocess/vqa/compute_adjacency.py:38-45 (restated as the same double loop)"""
+    n = matrix1.shape[0]
+    adj_cos = torch.zeros((n, n), dtype=torch.float32)
+    for i in range(n):
+        for j in range(n):
+            if j >= i:
+                adj_cos[i, j] = torch.cosine_similarity(matrix1[i], matrix2[j], dim=0, eps=1e-6)
+    return adj_cos + adj_cos.transpose(0, 1)
+
+
+def adjacency_of(matrix_class, matrix_attribute):
+    """ref: compute_adjacency.py:89-90"""
+    m = compute_cosin_sim_v2(matrix_class, matrix_attribute)
+    return m / m.max()
+
+
+def normalize_boxes(boxes, img_w, img_h):
+    """ref: src/vqa/vqacpv2_data.py:108-117 (numpy; incl. the (img_h,) tuple the reference divides by)"""
+    import numpy as np
+    boxes = boxes.copy()
+    boxes[:, (0, 2)] /= img_w
+    boxes[:, (1, 3)] /= (img_h,)
+    np.testing.assert_array_less(boxes, 1 + 1e-5)
+    np.testing.assert_array_less(-boxes, 0 + 1e-5)
+    return boxes
+
+
+def vqa_target(num_answers, labels, scores):
+    """ref: vqacpv2_data.py:120-123"""
+    target = torch.zeros(num_answers)
+    for ans, score in zip(labels, scores):
+        target[ans] = score
+    return target
+
+
+def vqa_score(quesid2ans, id2datum, ans2label):
+    """VQAEvaluator.evaluate, ref: vqacpv2_data.py:134-142"""
+    score = 0.
+    for quesid, ans in quesid2ans.items():
+        datum = id2datum[quesid]
+        label = dict(zip(datum['label'], datum['score']))
+        aid = ans2label[ans]
+        if aid in label:
+            score += label[aid]
+    return score / len(quesid2ans)

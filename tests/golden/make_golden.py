@@ -442,12 +442,126 @@ def answer_table_case(seed=11):
                    "converted": converted, "gqa_only": gqa_only}, f, indent=0)
 
 
+def adjacency_case(seed=12):
+    """the reference's ``compute_cosin_sim_v2`` + ``matrix / matrix.max()`` (data/preprocess/vqa/compute_adjacency.py
+    :38-45, :90) on synthetic embeddings.  The module cannot be imported -- it downloads bert-base-uncased at import
+    (:16-17) -- so ONLY that function is executed: its source text is cut out of the file where it lies, with the
+    ``.cuda()`` placements dropped (no GPU in the build container), and run as it stands."""
+    import ast
+    path = "/root/reference/data/preprocess/vqa/compute_adjacency.py"
+    src = open(path).read()
+    tree = ast.parse(src)
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "compute_cosin_sim_v2")
+    code = "\n".join(src.splitlines()[fn.lineno - 1:fn.end_lineno]).replace(".cuda()", "")
+    ns = {"torch": torch}
+    exec(compile(code, path, "exec"), ns)
+    ref_fn = ns["compute_cosin_sim_v2"]
+    D, n_img, N = 768, 4, 36
+    cls_tab = torch.from_numpy(synth._rng(seed, "adj_class_table").standard_normal((60, D), dtype=np.float32))
+    att_tab = torch.from_numpy(synth._rng(seed, "adj_attr_table").standard_normal((45, D), dtype=np.float32))
+    att_tab[7] = 0.0  # a label whose embedding is the zero vector: the eps clamp of cosine_similarity
+    att_tab[8] = cls_tab[8]  # identical class / attribute embedding: cosine exactly 1 (doubled on the diagonal)
+    r = synth._rng(seed, "adj_ids")
+    oid = r.integers(0, 60, size=(n_img, N))
+    aid = r.integers(0, 45, size=(n_img, N))
+    oid[0, :4] = 8
+    aid[0, :4] = 8      # ties at the maximum
+    aid[1, 5] = 7       # zero vector
+    out = []
+    for i in range(n_img):
+        m = ref_fn(cls_tab[oid[i]], att_tab[aid[i]])
+        out.append((m / m.max()).numpy())
+    np.savez_compressed(os.path.join(HERE, "adjacency.npz"), seed=seed, D=D, objects_id=oid, attrs_id=aid,
+                        adj=np.stack(out).astype(np.float32))
+
+
+def dataset_case(seed=13):
+    """the reference's ``VQATorchDataset.__getitem__`` / ``GQATorchDataset.__getitem__`` (box normalisation, target
+    rows, item tuple: src/vqa/vqacpv2_data.py:95-127, src/gqa/gqa_ood_data.py:105-143) and both evaluators on
+    synthetic records.  The datasets' constructors open h5 / json files that do not exist; the objects are created
+    without them and handed dict-backed stand-ins for the h5 groups (``group[name][:]`` is all the code uses)."""
+    import json
+    from vqa import vqacpv2_data as VD
+    from gqa import gqa_ood_data as GD
+    r = synth._rng(seed, "dataset_case")
+    n_img, N, F, A = 6, 36, 64, 17
+    img_ids = [int(x) for x in r.integers(1000, 900000, size=n_img)]
+    info, h5, adj = {}, {}, {}
+    for i in img_ids:
+        w, h = int(r.integers(300, 800)), int(r.integers(200, 700))
+        x1 = r.random((N, 1), dtype=np.float32) * (w - 2)
+        y1 = r.random((N, 1), dtype=np.float32) * (h - 2)
+        x2 = x1 + r.random((N, 1), dtype=np.float32) * (w - x1)
+        y2 = y1 + r.random((N, 1), dtype=np.float32) * (h - y1)
+        boxes = np.concatenate([x1, y1, x2, y2], axis=1).astype(np.float32)
+        feats = (3.0 * r.random((N, F), dtype=np.float32)).astype(np.float32)
+        u = np.triu(r.random((N, N), dtype=np.float32))
+        a = u + u.T
+        info[i] = {"img_id": i, "img_h": h, "img_w": w, "num_boxes": N}
+        h5[str(i)] = {"features": feats, "boxes": boxes}
+        adj[str(i)] = (a / a.max()).astype(np.float32)
+    label2ans = ["ans%d" % k for k in range(A)]
+    ans2label = {a: k for k, a in enumerate(label2ans)}
+    vqa_data, gqa_data = [], []
+    for q in range(14):
+        img = img_ids[q % n_img]
+        k = int(r.integers(1, 4))
+        labs = [int(x) for x in r.choice(A, size=k, replace=False)]
+        scs = [float(x) for x in r.choice([0.3, 0.6, 0.9, 1.0], size=k)]
+        vqa_data.append({"question_id": 5000 + q, "image_id": img, "question": "what is w%d ?" % q, "label": labs,
+                         "score": scs})
+        gqa_data.append({"question_id": "g%d" % q, "img_id": img, "sent": "is w%d there ?" % q,
+                         "label": {label2ans[l]: s for l, s in zip(labs, scs)}})
+
+    class Raw:
+        pass
+
+    def raw(data):
+        o = Raw()
+        o.data, o.ans2label, o.label2ans, o.num_answers = data, ans2label, label2ans, A
+        o.id2datum = {d["question_id"]: d for d in data}
+        return o
+
+    outs = {}
+    for tag, mod, cls, data in (("vqa", VD, "VQATorchDataset", vqa_data), ("gqa", GD, "GQATorchDataset", gqa_data)):
+        ds = object.__new__(getattr(mod, cls))
+        ds.raw_dataset = raw(data)
+        ds.obj_h5, ds.adj_h5 = h5, adj
+        ds.obj_info = info
+        ds.data = data
+        items = [ds[i] for i in range(len(data))]
+        outs[tag + "_feats"] = np.stack([np.asarray(it[1]) for it in items])
+        outs[tag + "_boxes"] = np.stack([np.asarray(it[2]) for it in items])
+        outs[tag + "_target"] = np.stack([it[4].numpy() for it in items])
+        outs[tag + "_adj"] = np.stack([np.asarray(it[5]) for it in items])
+        assert [it[0] for it in items] == [d["question_id"] for d in data]
+        assert [it[3] for it in items] == [d["question" if tag == "vqa" else "sent"] for d in data]
+    # evaluators on a fixed prediction
+    pred_v = {d["question_id"]: label2ans[(d["label"][0] if i % 3 else (d["label"][0] + 1) % A)] for i, d in enumerate(vqa_data)}
+    pred_g = {d["question_id"]: label2ans[(ans2label[list(d["label"])[0]] + (0 if i % 4 else 2)) % A] for i, d in enumerate(gqa_data)}
+    ev = VD.VQAEvaluator(raw(vqa_data))
+    eg = GD.GQAEvaluator(raw(gqa_data))
+    np.savez_compressed(os.path.join(HERE, "dataset.npz"), seed=seed, score_vqa=ev.evaluate(pred_v),
+                        score_gqa=eg.evaluate(pred_g), **outs)
+    with open(os.path.join(HERE, "dataset.json"), "w") as f:
+        json.dump({"info": [info[i] for i in img_ids], "label2ans": label2ans, "vqa": vqa_data, "gqa": gqa_data,
+                   "pred_vqa": {str(k): v for k, v in pred_v.items()}, "pred_gqa": pred_g,
+                   "raw_boxes": {str(i): h5[str(i)]["boxes"].tolist() for i in img_ids},
+                   "raw_feats_seed": seed}, f, indent=0)
+    np.savez_compressed(os.path.join(HERE, "dataset_raw.npz"), **{"feats_%d" % i: h5[str(i)]["features"] for i in img_ids},
+                        **{"adj_%d" % i: adj[str(i)] for i in img_ids})
+
+
 if __name__ == "__main__":
     which = _WHICH or ["all"]
     if "all" in which or "tok" in which:
         tokenizer_case()
     if "all" in which or "ans" in which:
         answer_table_case()
+    if "all" in which or "adj" in which:
+        adjacency_case()
+    if "all" in which or "data" in which:
+        dataset_case()
     torch.manual_seed(0)
     if "all" in which or "enc" in which:
         encoder_case("enc_tiny", TINY, 3, 1)

@@ -20,11 +20,13 @@ def _gpu():
         pytest.skip("no GPU")
 
 
-def _tiny(seed_w, seed_rt, layers=(3, 2, 2)):
+def _tiny(seed_w, seed_rt, layers=(3, 2, 2), vocab=None):
     from oracle import shapes
     from test_model_gpu import build_model
     from xggm_amd.vqa.vqacpv2 import make_optimizer
     cfg = dict(shapes.TINY, l_layers=layers[0], x_layers=layers[1], r_layers=layers[2])
+    if vocab is not None:
+        cfg["vocab"] = vocab
     m = build_model(cfg, 29, seed=seed_w, dt=BF16)
     m.seed = seed_rt
     return cfg, m, make_optimizer(m, 2e-3, 40)
@@ -225,6 +227,66 @@ def test_bench_c4_stress_line():
     rf = line["roofline"]
     assert rf["kernel"] == "xggm_aggregate_bf16" and rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["achieved"] > 0
     assert line["cpu_baseline"]["value"] > 0 and line["value"] > line["cpu_baseline"]["value"]
+
+
+def test_prefetching_loader_feeds_the_captured_trainer(tmp_path):
+    """shard -> VQATorchDataset -> DataLoaderX(device=cuda, batcher) -> CapturedTrainer.load_batch: what arrives in
+    the trainer's static input buffers equals the host items (features as their bf16 values), question strings have
+    become the tokenised triple, batches keep arriving while earlier ones are still in use on the GPU, and training
+    on loader batches gives the losses of the same batches fed as plain tensors."""
+    from xggm_amd.engine import CapturedTrainer
+    from xggm_amd.tools.shards import ShardWriter
+    from xggm_amd.tools.data_loader import DataLoaderX
+    from xggm_amd.vqa.vqacpv2_data import VQADataset, VQATorchDataset
+    from xggm_amd.lxrt.entry import SentenceBatcher
+    from xggm_amd.lxrt.tokenization import BertTokenizer
+    from helpers import GOLDEN
+    import os
+    B, A, n_img = 4, 29, 12
+    cfg, m, opt = _tiny(5, 11, vocab=96)  # the test vocabulary has 81 entries: every id inside the embedding table
+    _, m2, opt2 = _tiny(5, 11, vocab=96)
+    tok = BertTokenizer(os.path.join(GOLDEN, "vocab_small.txt"), do_lower_case=True)
+    words = [w for w in open(os.path.join(GOLDEN, "vocab_small.txt")).read().split() if w.isalpha()][:40]
+    rng = np.random.default_rng(0)
+    w = ShardWriter(str(tmp_path / "train_obj36.xgs"), n_objects=36, feat_dim=cfg["feat_dim"])
+    data = []
+    bsrc = synth.vqa_batch(n_img, A=A, F=cfg["feat_dim"], vocab=cfg["vocab"], seed=21)
+    for i in range(n_img):
+        w.add(i, bsrc["feats"][i], bsrc["boxes"][i] * 0.99, 1.0, 1.0, bsrc["adj_true"][i])
+        data.append({"question_id": i, "image_id": i, "label": [int(bsrc["target"][i].argmax())], "score": [1.0],
+                     "question": " ".join(rng.choice(words, size=int(rng.integers(3, 9))))})
+    l2a = ["a%d" % k for k in range(A)]
+    ts = VQATorchDataset(VQADataset("train", data=data, ans2label={a: k for k, a in enumerate(l2a)}, label2ans=l2a),
+                         shard=w.close())
+    batcher = SentenceBatcher(tok, 20)
+    first = next(iter(DataLoaderX(ts, B, device=DEV, batcher=batcher)))
+    batch0 = dict(feats=first[1].clone(), boxes=first[2].clone(), input_ids=first[3][0].clone(), input_mask=first[3][1].clone(),
+                  segment_ids=first[3][2].clone(), target=first[4].clone(), adj_true=first[5].clone())
+    tr = CapturedTrainer(m, opt, batch0, warmup_iters=1)
+    tr2 = CapturedTrainer(m2, opt2, batch0, warmup_iters=1)
+    held, losses, losses2 = [], [], []
+    for k, item in enumerate(DataLoaderX(ts, B, device=DEV, batcher=batcher, depth=2)):
+        qid, feats, boxes, sent, target, adj = item
+        assert feats.is_cuda and feats.dtype == torch.bfloat16 and sent[0].is_cuda
+        host = [ts[k * B + b] for b in range(B)]
+        assert qid == [h[0] for h in host]
+        assert torch.equal(feats.float().cpu(), torch.from_numpy(np.stack([h[1] for h in host])))
+        assert torch.equal(boxes.cpu(), torch.from_numpy(np.stack([h[2] for h in host])))
+        assert torch.equal(target.cpu(), torch.stack([h[4] for h in host]))
+        assert torch.equal(adj.cpu(), torch.from_numpy(np.stack([h[5] for h in host])))
+        bt = dict(feats=feats, boxes=boxes, input_ids=sent[0], input_mask=sent[1], segment_ids=sent[2], target=target,
+                  adj_true=adj)
+        tr.load_batch(bt)
+        (lp, _, _), (lg, _, _) = tr.iteration("rel")
+        losses.append((float(lp), float(lg)))
+        # the same batch as independent tensors through a second, identical engine
+        tr2.load_batch({kk: v.clone() for kk, v in bt.items()})
+        (lp2, _, _), (lg2, _, _) = tr2.iteration("rel")
+        losses2.append((float(lp2), float(lg2)))
+        assert torch.equal(tr.static["feats"], feats) and torch.equal(tr.static["input_ids"], sent[0])
+        held.append((feats, feats.clone()))
+    assert len(losses) == n_img // B and losses == losses2
+    torch.cuda.synchronize()
 
 
 def test_training_state_restored_under_live_graphs(tmp_path):

@@ -1045,3 +1045,40 @@ def test_fp8_scale_update_protocol(ops):
     amax[6] = 3.0
     ops.fp8_scale_update(amax, hist, q, d, pos, 6, 2, H, 4.0 / 3.0, 0, 0)
     assert int(pos) == 5 and abs(float(q[6]) - 448 / (4.0 / 3.0 * 3.0)) < 1e-3 and float(q[7]) == 7.0
+
+
+# ------------------------------------------------------------------------------------------------ preprocessing
+def test_cosine_adjacency_matches_reference_golden_and_oracle(ops):
+    """xggm_cosine_adjacency_f32 (data/preprocess/vqa/compute_adjacency.py:38-45, :90) against the fixture the
+    reference's own function produced (ties at the maximum, a zero embedding under the eps clamp) and against the
+    oracle's double loop at other sizes (N = 5, 36, 64; D = 768 and a width that is not a multiple of the 64-wide
+    chunk); the batched builder gathers label embeddings by id."""
+    from helpers import load_golden
+    from oracle import xggm_oracle as O
+    from xggm_amd import synth
+    from xggm_amd.preprocess.compute_adjacency import compute_cosin_sim_v2, build_adjacency
+    g = load_golden("adjacency")
+    seed, D = int(g["seed"]), int(g["D"])
+    cls = torch.from_numpy(synth._rng(seed, "adj_class_table").standard_normal((60, D), dtype=np.float32))
+    att = torch.from_numpy(synth._rng(seed, "adj_attr_table").standard_normal((45, D), dtype=np.float32))
+    att[7] = 0.0
+    att[8] = cls[8]
+    oid, aid = torch.from_numpy(g["objects_id"]), torch.from_numpy(g["attrs_id"])
+    adj = build_adjacency(cls.to(DEV), att.to(DEV), oid, aid, chunk=3)
+    assert adj.shape == (4, 36, 36)
+    # fp32 sums over D = 768 in another order than torch's, then a division by the maximum: a few ulp of 1
+    assert float((adj.cpu() - torch.from_numpy(g["adj"])).abs().max()) < 5e-6
+    assert float(adj.max()) == 1.0 and torch.equal(adj, adj.transpose(1, 2))
+    gen = torch.Generator().manual_seed(2)
+    for N, Dm in ((5, 768), (36, 100), (64, 768), (1, 64)):
+        a = torch.randn(3, N, Dm, generator=gen)
+        b = torch.randn(3, N, Dm, generator=gen)
+        got = compute_cosin_sim_v2(a.to(DEV), b.to(DEV), normalize=True).cpu()
+        for i in range(3):
+            assert float((got[i] - O.adjacency_of(a[i], b[i])).abs().max()) < 5e-6, (N, Dm)
+        raw = compute_cosin_sim_v2(a[0].to(DEV), b[0].to(DEV)).cpu()  # the reference signature: one image, no / max
+        assert float((raw - O.compute_cosin_sim_v2(a[0], b[0])).abs().max()) < 1e-5
+    with pytest.raises(RuntimeError, match="multiple of 4"):
+        compute_cosin_sim_v2(torch.zeros(1, 4, 6, device=DEV), torch.zeros(1, 4, 6, device=DEV))
+    with pytest.raises(RuntimeError, match="GPU"):
+        compute_cosin_sim_v2(torch.zeros(4, 8), torch.zeros(4, 8))

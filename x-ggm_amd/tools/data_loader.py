@@ -1,0 +1,170 @@
+"""Prefetching batch loader: the role of the reference's ``DataLoaderX`` (src/tools/data_loader.py:8-10: a
+``torch.utils.data.DataLoader`` whose iterator runs in a ``BackgroundGenerator`` thread) for a loop whose step
+takes milliseconds.
+
+What the reference does per batch on the critical path of ``VQA.train`` (src/vqa/vqacpv2.py:164-171): collate
+B python items (each a fresh fp32 array out of an h5 group), ``.cuda()`` four tensors one after the other on the
+compute stream, then tokenise B strings inside ``model.forward``.  Here a producer thread
+  1. assembles batch k + 1 .. k + depth straight from the memory-mapped shard into PINNED host buffers
+     (``dataset.collate``: row copies, no per-item objects; features are already bf16),
+  2. tokenises its questions through the cached ``SentenceBatcher`` (ids / mask / segment ids, one pinned tensor),
+  3. queues ALL host-to-device copies of the batch on a copy stream into a ring of device buffers and records an
+     event,
+while the consumer trains on batch k.  Iterating yields the reference's tuple
+``(ques_id, feats, boxes, sent, target, adj)`` -- with ``device`` set the tensors are device tensors whose copies
+the current stream has been made to wait for (the trainer's own ``.cuda()`` calls become no-ops), and ``sent`` is
+the ``(input_ids, input_mask, segment_ids)`` triple the encoder accepts in place of strings when a batcher was
+given.  A slot of the ring is rewritten only after the consumer has asked for the next batch AND the work it
+queued on the buffers has passed an event -- however far the host runs ahead.
+"""
+import queue
+import threading
+
+import numpy as np
+import torch
+
+
+class DataLoaderX:
+    def __init__(self, dataset, batch_size, shuffle=False, drop_last=False, device=None, batcher=None, depth=3, seed=0,
+                 epochs=1):
+        """``dataset``: object with ``__len__``, ``alloc(batch_size, pin)`` and ``collate(items, out)``
+        (vqa.vqacpv2_data.VQATorchDataset); ``batcher``: lxrt.entry.SentenceBatcher or None (strings are passed
+        through); ``depth``: batches in flight (>= 2); ``epochs``: passes over the data per ``iter`` (None: endless)."""
+        if depth < 2:
+            raise ValueError("depth >= 2: one batch is consumed while the next is produced")
+        self.ds, self.B, self.shuffle, self.drop_last = dataset, batch_size, shuffle, drop_last
+        self.device = torch.device(device) if device is not None else None
+        if self.device is not None and self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.batcher, self.depth, self.seed, self.epochs = batcher, depth, seed, epochs
+        self._epoch = 0
+        pin = self.device is not None and self.device.type == "cuda"
+        self.host = [dataset.alloc(batch_size, pin) for _ in range(depth)]
+        self.dev = None
+        if pin:
+            self.dev = [{k: torch.empty_like(v, device=self.device) for k, v in h.items()} for h in self.host]
+            if batcher is not None:
+                for d in self.dev:
+                    d["ids"] = torch.zeros((3, batch_size, batcher.T), dtype=torch.long, device=self.device)
+            self.copy_stream = torch.cuda.Stream(device=self.device)
+
+    def __len__(self):
+        n = len(self.ds)
+        return n // self.B if self.drop_last else (n + self.B - 1) // self.B
+
+    def _batches(self):
+        e = 0
+        while self.epochs is None or e < self.epochs:
+            n = len(self.ds)
+            order = np.random.default_rng([self.seed, self._epoch]).permutation(n) if self.shuffle else np.arange(n)
+            self._epoch += 1
+            for s in range(0, n, self.B):
+                items = order[s:s + self.B]
+                if len(items) < self.B and self.drop_last:
+                    break
+                yield items
+            e += 1
+
+    def __iter__(self):
+        return _Iter(self)
+
+
+class _Iter:
+    def __init__(self, L):
+        self.L = L
+        self.q = queue.Queue(maxsize=L.depth - 1)
+        self.free = [threading.Event() for _ in range(L.depth)]   # slot may be rewritten (host side)
+        for f in self.free:
+            f.set()
+        self.released = [None] * L.depth                         # CUDA event: consumer's work on the slot is queued
+        self.stop = False
+        self.err = None
+        self.held = None
+        self.t = threading.Thread(target=self._produce, daemon=True)
+        self.t.start()
+
+    def _produce(self):
+        L = self.L
+        try:
+            if L.dev is not None:
+                torch.cuda.set_device(L.device)
+            slot = 0
+            for items in L._batches():
+                self.free[slot].wait()
+                if self.stop:
+                    return
+                self.free[slot].clear()
+                host = L.host[slot]
+                ids, sents, B = L.ds.collate(items, host)
+                sent = sents
+                ev = None
+                if L.dev is not None:
+                    rel = self.released[slot]
+                    dev = L.dev[slot]
+                    with torch.cuda.stream(L.copy_stream):
+                        if rel is not None:
+                            L.copy_stream.wait_event(rel)  # the consumer's kernels on this slot's buffers are done
+                        for k, v in host.items():
+                            dev[k][:B].copy_(v[:B], non_blocking=True)
+                        if L.batcher is not None:
+                            dev["ids"][:, :B].copy_(L.batcher.host_batch(sents), non_blocking=True)
+                            L.batcher.record_copy(L.copy_stream)
+                            sent = (dev["ids"][0, :B], dev["ids"][1, :B], dev["ids"][2, :B])
+                        ev = torch.cuda.Event()
+                        ev.record(L.copy_stream)
+                    out = {k: v[:B] for k, v in dev.items() if k != "ids"}
+                else:
+                    out = {k: v[:B] for k, v in host.items()}
+                    if L.batcher is not None:
+                        hb = L.batcher.host_batch(sents)
+                        sent = (hb[0].clone(), hb[1].clone(), hb[2].clone())
+                self.q.put((slot, ids, out, sent, ev))
+                slot = (slot + 1) % L.depth
+        except BaseException as ex:  # surfaced in the consumer
+            self.err = ex
+        finally:
+            self.q.put(None)
+
+    def _release(self):
+        if self.held is not None:
+            slot = self.held
+            if self.L.dev is not None:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.L.device))
+                self.released[slot] = ev
+            self.free[slot].set()
+            self.held = None
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        self._release()  # the previous batch has been consumed (its work is queued on the current stream)
+        item = self.q.get()
+        if item is None:
+            if self.err is not None:
+                raise self.err
+            raise StopIteration
+        slot, ids, out, sent, ev = item
+        if ev is not None:
+            torch.cuda.current_stream(self.L.device).wait_event(ev)
+        self.held = slot
+        if "adj" in out:
+            return ids, out["feats"], out["boxes"], sent, out["target"], out["adj"]
+        return ids, out["feats"], out["boxes"], sent
+
+    def close(self):
+        self.stop = True
+        for f in self.free:
+            f.set()
+        try:
+            while self.q.get_nowait() is not None:
+                pass
+        except queue.Empty:
+            pass
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,147 @@
+"""VQA-CP v2 datasets with the reference's class names and item layout (src/vqa/vqacpv2_data.py:26-167) on the
+shard format of ``xggm_amd.tools.shards`` instead of per-image h5 groups.
+
+    VQADataset        annotations + answer tables (json, as in the reference)
+    VQATorchDataset   __getitem__ -> (ques_id, feats [36, 2048], boxes [36, 4], ques, target [A], adj [36, 36]),
+                      the tuple src/vqa/vqacpv2.py:164 unpacks; ``collate`` assembles a whole batch from the
+                      memory map into pinned buffers without per-item objects (tools/data_loader.py)
+    VQAEvaluator      soft-score accuracy and result dump (:130-167)
+Paths are constructor arguments (the reference hard-codes ``data/vqacpv2/`` and ``data/mscoco_imgfeat/``)."""
+import json
+import os
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+from ..tools.shards import ShardReader
+
+TINY_IMG_NUM = 512
+FAST_IMG_NUM = 5000
+VQA_DATA_ROOT = 'data/vqacpv2/'
+MSCOCO_IMGFEAT_ROOT = 'data/mscoco_imgfeat/'
+
+
+def load_json(path):
+    with open(path, "r") as f:
+        return json.load(f)
+
+
+class VQADataset:
+    """ref :26-52.  ``data`` may be given directly (list of annotation dicts) instead of read from
+    ``<root>/<splits>_annotations.json``; likewise the answer tables."""
+
+    img_key = 'image_id'
+    sent_key = 'question'
+
+    def __init__(self, splits: str, root=VQA_DATA_ROOT, data=None, ans2label=None, label2ans=None):
+        self.name = splits
+        self.splits = splits.split(',')
+        self.data = data if data is not None else load_json(os.path.join(root, '%s_annotations.json' % self.name))
+        self.id2datum = {datum['question_id']: datum for datum in self.data}
+        print(f"Loading {self.name} data: {len(self.data)}")
+        self.ans2label = ans2label if ans2label is not None else load_json(os.path.join(root, 'trainval_ans2label.json'))
+        self.label2ans = label2ans if label2ans is not None else load_json(os.path.join(root, 'trainval_label2ans.json'))
+        assert len(self.ans2label) == len(self.label2ans)
+
+    @property
+    def num_answers(self):
+        return len(self.ans2label)
+
+    def __len__(self):
+        return len(self.data)
+
+
+class VQATorchDataset(Dataset):
+    """ref :55-127.  ``shard``: path of ``<split>_obj36.xgs`` (features, normalised boxes, adjacency) or an open
+    ``ShardReader``.  Only data whose image is in the shard are kept (:82-85)."""
+
+    def __init__(self, dataset, shard=None, imgfeat_root=MSCOCO_IMGFEAT_ROOT, tiny=False, fast=False):
+        super().__init__()
+        self.raw_dataset = dataset
+        if shard is None:
+            shard = os.path.join(imgfeat_root, '%s_obj36.xgs' % dataset.splits[0])
+        self.shard = shard if isinstance(shard, ShardReader) else ShardReader(shard)
+        key = dataset.img_key
+        self.data = [d for d in dataset.data if d[key] in self.shard.row_of]
+        if tiny:
+            self.data = self.data[:TINY_IMG_NUM]
+        elif fast:
+            self.data = self.data[:FAST_IMG_NUM]
+        self.rows = np.asarray([self.shard.row_of[d[key]] for d in self.data], dtype=np.int64)
+        print("Use %d data in torch dataset" % (len(self.data)))
+
+    def __len__(self):
+        return len(self.data)
+
+    def target_of(self, datum, out=None):
+        """soft-score target row (:120-123)"""
+        t = out if out is not None else torch.zeros(self.raw_dataset.num_answers)
+        for ans, score in zip(datum['label'], datum['score']):
+            t[ans] = score
+        return t
+
+    def __getitem__(self, item: int):
+        datum = self.data[item]
+        row = int(self.rows[item])
+        feats = self.shard.feats_f32(row)
+        boxes = np.array(self.shard.boxes[row])
+        ques_id, ques = datum['question_id'], datum[self.raw_dataset.sent_key]
+        if 'label' in datum:
+            return ques_id, feats, boxes, ques, self.target_of(datum), np.array(self.shard.adj[row])
+        return ques_id, feats, boxes, ques
+
+    # ---- batch assembly for tools.data_loader.DataLoaderX
+    def alloc(self, batch_size, pin):
+        N, F, A = self.shard.N, self.shard.F, self.raw_dataset.num_answers
+        out = {"feats": torch.zeros((batch_size, N, F), dtype=torch.bfloat16), "boxes": torch.zeros((batch_size, N, 4)),
+               "target": torch.zeros((batch_size, A))}
+        if self.shard.adj is not None:
+            out["adj"] = torch.zeros((batch_size, N, N))
+        if pin:
+            out = {k: v.pin_memory() for k, v in out.items()}
+        return out
+
+    def collate(self, items, out):
+        """fill the host buffers ``out`` (``alloc``) with the samples ``items``; returns (ques_ids, sents, B).
+        numpy on views of the (pinned) buffers only: a torch CPU op here would spin up the intra-op thread pool on the
+        producer thread next to a training loop that needs the host for nothing but graph launches."""
+        B = self.shard.gather(self.rows[np.asarray(items, dtype=np.int64)], out)
+        tgt = out["target"].numpy()
+        tgt[:B] = 0.0
+        ids, sents = [], []
+        for b, it in enumerate(items):
+            d = self.data[it]
+            ids.append(d['question_id'])
+            sents.append(d[self.raw_dataset.sent_key])
+            if 'label' in d:
+                self.fill_target(d, tgt[b])
+        return ids, sents, B
+
+    def fill_target(self, datum, row):
+        """the soft scores of ``datum`` into a zeroed numpy target row (:120-123)"""
+        for ans, score in zip(datum['label'], datum['score']):
+            row[ans] = score
+
+
+class VQAEvaluator:
+    """ref :130-167"""
+
+    def __init__(self, dataset: VQADataset):
+        self.dataset = dataset
+
+    def evaluate(self, quesid2ans: dict):
+        score = 0.
+        for quesid, ans in quesid2ans.items():
+            datum = self.dataset.id2datum[quesid]
+            label = dict(zip(datum['label'], datum['score']))
+            aid = self.dataset.ans2label[ans]
+            if aid in label:
+                score += label[aid]
+        return score / len(quesid2ans)
+
+    @staticmethod
+    def dump_result(quesid2ans: dict, path):
+        with open(path, 'w') as f:
+            result = [{'question_id': ques_id, 'answer': ans} for ques_id, ans in quesid2ans.items()]
+            json.dump(result, f, indent=4, sort_keys=True)
