@@ -442,6 +442,13 @@ int xggm_cosine_adjacency_f32(const float* cls, const float* attr, float* adj, i
  * scratch of XGGM_SQNORM_WS_FLOATS floats (contents irrelevant before, undefined after). */
 #define XGGM_SQNORM_WS_FLOATS 4100
 int xggm_sqnorm_f32(const float* g, int64_t n, float* out, float* ws, xggm_stream_t stream);
+/* The same sum over up to 16 ranges [offsets[i], offsets[i] + lengths[i]) of ONE fp32 buffer (HOST arrays; offsets
+ * multiples of 4) in two launches, partials added in (range, slice) order: *out = (overwrite ? 0 : *out) + sum;
+ * *norm (or NULL) = sqrt(*out) -- the total norm nn.utils.clip_grad_norm_ returns.  n == 0 only seeds / finishes.
+ * square == 0 sums the VALUES instead of their squares: the gradient-norm slots of the weight-gradient GEMMs
+ * (xggm_gemm_problem.sqsum) already hold sums of squares and are added to the running sum by a second call. */
+int xggm_sqnorm_multi_f32(const float* base, const int64_t* offsets, const int64_t* lengths, int n, float* out, float* norm,
+                          float* ws, int overwrite, int square, xggm_stream_t stream);
 /* BertAdam.step (src/lxrt/optimization.py:159-193) fused with the clip scale
  * min(1, max_norm/(sqrt(*sqnorm)+1e-6)) and the bf16 shadow-weight write. */
 int xggm_bertadam_f32(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, const float* sqnorm,
@@ -486,6 +493,10 @@ int xggm_sched_step(int64_t* step, float* lr_scale, int64_t t_total, float warmu
 int xggm_sched_step_multi(int64_t* steps, float* lr_scale, const int* index, const int64_t* t_total, const float* warmup,
                           int n, xggm_stream_t stream);
 
+/* out = in with the diagonal of every [N, N] matrix zeroed: adj_true.triu(1) + adj_true.tril(-1), src/vqa/vqacpv2.py:188 */
+int xggm_zero_diag_f32(const float* in, float* out, int B, int N, xggm_stream_t stream);
+/* *out = *a + *b + *c + *d (NULL terms skipped): the sum of the loss terms of a pass, src/vqa/vqacpv2.py:220-221 */
+int xggm_add_scalars_f32(const float* a, const float* b, const float* c, const float* d, float* out, xggm_stream_t stream);
 /* zero up to 16 element ranges [offset[i], offset[i] + length[i]) of one fp32 buffer in ONE launch: the
  * atomically accumulated gradient ranges of all parameter groups at the start of a backward pass.
  * offsets / lengths are HOST arrays (copied into the kernel arguments); both multiples of 4. */

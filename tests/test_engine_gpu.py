@@ -285,7 +285,9 @@ def test_prefetching_loader_feeds_the_captured_trainer(tmp_path):
         losses2.append((float(lp2), float(lg2)))
         assert torch.equal(tr.static["feats"], feats) and torch.equal(tr.static["input_ids"], sent[0])
         held.append((feats, feats.clone()))
-    assert len(losses) == n_img // B and losses == losses2
+    # two engines that started equal: fp32 atomics make the last bits of a pass run-dependent and the updates carry
+    # that forward, so the trajectories agree to rounding, not bit for bit
+    assert len(losses) == n_img // B and np.allclose(np.asarray(losses), np.asarray(losses2), rtol=2e-3)
     torch.cuda.synchronize()
 
 

@@ -123,6 +123,7 @@ class ParamArena:
         for gname in order:
             if gname not in ("enc_main", "enc_tail"):
                 continue
+            n_slots = (n_slots + 3) // 4 * 4  # a group's slots start float4-aligned (xggm_sqnorm_multi_f32 ranges)
             first = n_slots
             for n, p in named:
                 o, k, g_, atomic = self.info[n]
@@ -130,7 +131,7 @@ class ParamArena:
                     self.sq_base[n] = n_slots
                     n_slots += k // 4096
             self.sq_range[gname] = (first, n_slots)
-        self.sq_slots = torch.zeros(max(n_slots, 1), device=dev, dtype=torch.float32)
+        self.sq_slots = torch.zeros(_align(max(n_slots, 1)), device=dev, dtype=torch.float32)
         self.sq_covered = set()  # names whose gradient of this pass is accounted for in the slots
         self.sq_clean = False    # slots zeroed since the last zero_grad()
         self.named = dict(named)
@@ -230,7 +231,7 @@ class ParamArena:
                 return None
             k += p.numel() // 4096
         if not self.sq_clean:
-            self.sq_slots.zero_()
+            ops.zero_ranges(self.sq_slots, [(0, self.sq_slots.numel())])
             self.sq_clean = True
         self.sq_covered.update(names)
         return self.sq_slots[base:base + k]
@@ -247,7 +248,7 @@ class ParamArena:
             self.vec_zeroed = True
         if self.all_dirty or not p._xg[4] or name in self.touched:
             o, k = p._xg[1], p._xg[2]
-            self.grads[o:o + k].zero_()
+            ops.zero_ranges(self.grads, [(o, o + (k + 3) // 4 * 4)])  # offsets are 8-aligned: the padding is ours
         self.touched.add(name)
 
     def atomic_target(self, ps):

@@ -108,6 +108,33 @@ extern "C" int xggm_zero_ranges_f32(float* base, const int64_t* offsets, const i
 EW_API(f32, float)
 EW_API(bf16, bf16)
 
+// ---- scalar / input glue of the training pass, so that a captured pass holds no framework kernels
+namespace {
+// adj.triu(1) + adj.tril(-1): the diagonal of the input adjacency removed (src/vqa/vqacpv2.py:188)
+__global__ __launch_bounds__(NT) void zero_diag_kernel(const float* __restrict__ in, float* out, int64_t total, int N) {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int e = (int)(i % ((int64_t)N * N));
+        out[i] = (e / N == e % N) ? 0.f : in[i];
+    }
+}
+__global__ void add_scalars_kernel(const float* a, const float* b, const float* c, const float* d, float* out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *out = (a ? *a : 0.f) + (b ? *b : 0.f) + (c ? *c : 0.f) + (d ? *d : 0.f);
+}
+}  // namespace
+
+extern "C" int xggm_zero_diag_f32(const float* in, float* out, int B, int N, hipStream_t st) {
+    XGGM_REQUIRE(in && out && B > 0 && N > 0, "xggm_zero_diag_f32: bad arguments");
+    const int64_t total = (int64_t)B * N * N;
+    hipLaunchKernelGGL(zero_diag_kernel, dim3(grid1d(total)), dim3(NT), 0, st, in, out, total, N);
+    return xggm_check_launch("xggm_zero_diag_f32");
+}
+
+extern "C" int xggm_add_scalars_f32(const float* a, const float* b, const float* c, const float* d, float* out, hipStream_t st) {
+    XGGM_REQUIRE(out, "xggm_add_scalars_f32: null output");
+    hipLaunchKernelGGL(add_scalars_kernel, dim3(1), dim3(64), 0, st, a, b, c, d, out);
+    return xggm_check_launch("xggm_add_scalars_f32");
+}
+
 
 // ---- fp8 operands of the mixed-precision forward (BASELINE config C5): y = e4m3(clamp(x * qscale, +-448)),
 // OCP e4m3fn as gfx950's matrix cores read it, round-to-nearest-even (v_cvt_pk_fp8_f32).  Per-tensor scaling:

@@ -183,6 +183,63 @@ __global__ __launch_bounds__(NT) void sqnorm_finish_kernel(const float* __restri
     if (threadIdx.x == 0) *out += t;
 }
 
+// clip_grad_norm_ over SEVERAL ranges of one fp32 buffer in two launches: every workgroup owns one slice of one
+// range (ranges get workgroups in proportion to their length), partials land in ws in (range, slice) order and one
+// workgroup adds them in that order -- the same bits whatever the scheduling.  The finish also seeds / extends the
+// running sum and writes the norm, so the host issues no fill, add or sqrt kernels around it.
+constexpr int MAX_SPANS = 16;
+struct Spans {
+    int64_t off[MAX_SPANS], len[MAX_SPANS];
+    int blk0[MAX_SPANS + 1];  // first workgroup of each range
+    int n;
+};
+template <bool SQ>
+__global__ __launch_bounds__(NT) void sqnorm_multi_kernel(const float* __restrict__ base, Spans sp, float* ws) {
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < MAX_SPANS; ++j)
+        if (j < sp.n && (int)blockIdx.x >= sp.blk0[j]) k = j;
+    const int nb = sp.blk0[k + 1] - sp.blk0[k], b = blockIdx.x - sp.blk0[k];
+    const float* g = base + sp.off[k];
+    const int64_t n = sp.len[k], n4 = n >> 2;
+    typedef float __attribute__((ext_vector_type(4))) f4;
+    const f4* g4 = reinterpret_cast<const f4*>(g);
+    const int64_t stride = (int64_t)nb * NT;
+    float acc = 0.f;
+    int64_t i = (int64_t)b * NT + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const f4 a = __builtin_nontemporal_load(g4 + i), bb = __builtin_nontemporal_load(g4 + i + stride),
+                 c = __builtin_nontemporal_load(g4 + i + 2 * stride), d = __builtin_nontemporal_load(g4 + i + 3 * stride);
+        if (SQ)
+            acc += (a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w) + (bb.x * bb.x + bb.y * bb.y + bb.z * bb.z + bb.w * bb.w) +
+                   (c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w) + (d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w);
+        else
+            acc += ((a.x + a.y) + (a.z + a.w)) + ((bb.x + bb.y) + (bb.z + bb.w)) + ((c.x + c.y) + (c.z + c.w)) +
+                   ((d.x + d.y) + (d.z + d.w));
+    }
+    for (; i < n4; i += stride) {
+        const f4 v = g4[i];
+        acc += SQ ? v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w : (v.x + v.y) + (v.z + v.w);
+    }
+    if (b == 0 && threadIdx.x < (n & 3)) {
+        const float v = g[(n4 << 2) + threadIdx.x];
+        acc += SQ ? v * v : v;
+    }
+    acc = block_sum(acc);
+    if (threadIdx.x == 0) ws[blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(NT) void sqnorm_multi_finish_kernel(const float* __restrict__ ws, int nblk, float* out, float* norm,
+                                                                 int overwrite) {
+    float t = 0.f;
+    for (int b = threadIdx.x; b < nblk; b += NT) t += ws[b];
+    t = block_sum(t);
+    if (threadIdx.x == 0) {
+        const float s = (overwrite ? 0.f : *out) + t;
+        *out = s;
+        if (norm) *norm = sqrtf(s);
+    }
+}
+
 // the same sum over a bf16 buffer (data-parallel wire arena): 8 elements per 16-byte load
 __global__ __launch_bounds__(NT) void sqnorm_bf16_kernel(const bf16* __restrict__ g, int64_t n, float* ws) {
     float acc = 0.f;
@@ -505,6 +562,38 @@ extern "C" int xggm_bertadam_f32(float* p, const float* g, float* m, float* v, v
     AdamArgs a{p, g, m, v, (bf16*)shadow_bf16, n, sqnorm, max_norm, lr, nullptr, lr_scale, b1, b2, eps, weight_decay,
                nullptr, nullptr, nullptr, nullptr, 0};
     return launch_adam(a, false, st);
+}
+
+extern "C" int xggm_sqnorm_multi_f32(const float* base, const int64_t* offsets, const int64_t* lengths, int n, float* out,
+                                     float* norm, float* ws, int overwrite, int square, hipStream_t st) {
+    XGGM_REQUIRE(base && offsets && lengths && out && ws && n >= 0 && n <= MAX_SPANS,
+                 "xggm_sqnorm_multi_f32: bad arguments (n = %d, at most %d ranges)", n, MAX_SPANS);
+    XGGM_REQUIRE(reinterpret_cast<uintptr_t>(base) % 16 == 0, "xggm_sqnorm_multi_f32: base must be 16-byte aligned");
+    Spans sp;
+    sp.n = n;
+    int64_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        XGGM_REQUIRE(offsets[i] >= 0 && lengths[i] > 0 && offsets[i] % 4 == 0, "xggm_sqnorm_multi_f32: range %d (offset %lld, "
+                     "length %lld) must be non-empty and start on a multiple of 4", i, (long long)offsets[i], (long long)lengths[i]);
+        sp.off[i] = offsets[i];
+        sp.len[i] = lengths[i];
+        total += lengths[i];
+    }
+    // 4096 workgroups in all (the partials fit XGGM_SQNORM_WS_FLOATS), at least 8 float4 per thread, at least one each
+    int nblk = 0;
+    for (int i = 0; i < n; ++i) {
+        sp.blk0[i] = nblk;
+        const int64_t want = std::max<int64_t>(1, std::min<int64_t>(ceil_div64(lengths[i], (int64_t)NT * 32), (4096 - n) * lengths[i] / total + 1));
+        nblk += (int)want;
+    }
+    sp.blk0[n] = nblk;
+    XGGM_REQUIRE(nblk <= 4100, "xggm_sqnorm_multi_f32: internal: %d partials", nblk);
+    if (nblk > 0) {
+        if (square) hipLaunchKernelGGL(sqnorm_multi_kernel<true>, dim3(nblk), dim3(NT), 0, st, base, sp, ws);
+        else hipLaunchKernelGGL(sqnorm_multi_kernel<false>, dim3(nblk), dim3(NT), 0, st, base, sp, ws);
+    }
+    hipLaunchKernelGGL(sqnorm_multi_finish_kernel, dim3(1), dim3(NT), 0, st, ws, nblk, out, norm, overwrite);
+    return xggm_check_launch("xggm_sqnorm_multi_f32");
 }
 
 extern "C" int xggm_bertadam_ex(const xggm_adam_args* x, hipStream_t st) {

@@ -18,6 +18,13 @@ from . import ops
 F32 = torch.float32
 
 
+class ScalarSlot:
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
+
+
 class Runtime:
     """per-model execution state shared by all blocks: RNG words, training flag, dropout."""
 
@@ -37,6 +44,19 @@ class Runtime:
         self.n_stages = 1
         self._cuts = []       # cuts recorded by the running forward, in forward order: (tag, outputs, leaves)
         self.cut_layout = {}  # filled by LXRTEncoder.forward: where the cuts of this model sit (dist.stage_ranges)
+        self.one = torch.ones((), device=arena.device, dtype=F32)  # d loss / d loss: the root of every backward
+        self._slots = None    # zeroed scalar slots for the loss kernels of the running pass (one launch for all)
+
+    def begin_losses(self, n=4):
+        """the loss kernels of one pass accumulate into slots of ONE buffer zeroed by one launch"""
+        self._slots = [ScalarSlot(t) for t in ops.zeros_f32(n, self.arena.device).split(1)]
+
+    def scalar_slot(self):
+        """a zeroed 1-element accumulator (wrapped so autograd does not see an input tensor that the loss function
+        would then return a view of), or None outside ``begin_losses``"""
+        if self._slots:
+            return self._slots.pop()
+        return None
 
     def make_cut(self, tag, *tensors):
         """called by LXRTEncoder.forward at a cut: returns detached leaves to continue with"""
@@ -50,7 +70,9 @@ class Runtime:
         continues below it, ... -- ``between`` is not called after the final stage."""
         cuts, self._cuts = self._cuts, []
         self.n_stages = len(cuts) + 1
-        loss.backward()
+        self._slots = None
+        # explicit root gradient: autograd would otherwise launch a fill kernel for ones_like(loss)
+        loss.backward(self.one if loss.dim() == 0 and loss.dtype == F32 and loss.device == self.one.device else None)
         for k, (_, outs, leaves) in enumerate(reversed(cuts)):
             if between is not None:
                 between(k)
@@ -787,48 +809,62 @@ class DSMFn(Function):
     """loss_func (src/vqa/vqacpv2.py:48-51)."""
 
     @staticmethod
-    def forward(ctx, score, g, sigma, scale=1.0):
+    def forward(ctx, score, g, sigma, scale=1.0, slot=None):
         score = score.contiguous()
         coef = scale * 0.5 * sigma ** 2 / score.numel()  # 0.5 s^2 / (d1 d2) * mean over the batch
         ctx.saved = (score, g, coef)
-        return ops.dsm_fwd(score, g.contiguous(), coef)
+        return ops.dsm_fwd(score, g.contiguous(), coef, out=slot.t if slot is not None else None)
 
     @staticmethod
     def backward(ctx, gout):
         score, g, coef = ctx.saved
-        return ops.dsm_bwd(score, g, gout.contiguous(), coef), None, None, None
+        return ops.dsm_bwd(score, g, gout.contiguous(), coef), None, None, None, None
 
 
 class SymKLFn(Function):
     """compute_kl_loss (src/vqa/vqacpv2.py:54-61)."""
 
     @staticmethod
-    def forward(ctx, x, y, scale=1.0):
+    def forward(ctx, x, y, scale=1.0, slot=None):
         x, y = x.contiguous(), y.contiguous()
         coef = scale / x.numel()
         ctx.saved = (x, y, coef)
-        return ops.symkl_fwd(x, y, coef)
+        return ops.symkl_fwd(x, y, coef, out=slot.t if slot is not None else None)
 
     @staticmethod
     def backward(ctx, gout):
         x, y, coef = ctx.saved
-        return ops.symkl_bwd(x, y, gout.contiguous(), coef, ctx.needs_input_grad[0], ctx.needs_input_grad[1]) + (None,)
+        return ops.symkl_bwd(x, y, gout.contiguous(), coef, ctx.needs_input_grad[0], ctx.needs_input_grad[1]) + (None, None)
 
 
 class BCEFn(Function):
     """nn.BCEWithLogitsLoss()(logit, target) (mean).  fp32 logits."""
 
     @staticmethod
-    def forward(ctx, logit, target, scale=1.0):
+    def forward(ctx, logit, target, scale=1.0, slot=None):
         logit, target = logit.contiguous(), target.contiguous()
         coef = scale / logit.numel()
         ctx.saved = (logit, target, coef)
-        return ops.bce_fwd(logit, target, coef)
+        return ops.bce_fwd(logit, target, coef, out=slot.t if slot is not None else None)
 
     @staticmethod
     def backward(ctx, gout):
         logit, target, coef = ctx.saved
-        return ops.bce_bwd(logit, target, gout.contiguous(), coef, F32), None, None
+        return ops.bce_bwd(logit, target, gout.contiguous(), coef, F32), None, None, None
+
+
+class LossSumFn(Function):
+    """loss = sum of the (already weighted) loss terms of a pass (src/vqa/vqacpv2.py:220-221, 249-250): one kernel
+    instead of a framework add per ``+``; the backward hands the upstream gradient to every term unchanged."""
+
+    @staticmethod
+    def forward(ctx, *terms):
+        ctx.n = len(terms)
+        return ops.add_scalars([t.contiguous() for t in terms])
+
+    @staticmethod
+    def backward(ctx, gout):
+        return (gout,) * ctx.n
 
 
 class GATFn(Function):

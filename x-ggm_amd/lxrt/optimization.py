@@ -53,10 +53,9 @@ def clip_grad_norm_(parameters, max_norm):
     arena = _arena_of_params(params)
     if arena is None:
         raise RuntimeError("clip_grad_norm_: parameters are not arena-managed; run a forward first")
-    arena.sqnorm.zero_()
     # ranges of the flat gradient buffer the norm pass has to READ: everything of the active groups except the
     # matrices whose weight-gradient GEMM already left its sum of squares in the slot table (arena.sq_target);
-    # adjacent ranges are one launch
+    # adjacent ranges are merged
     spans, slot_spans = [], []
 
     def add(a, b):
@@ -78,12 +77,14 @@ def clip_grad_norm_(parameters, max_norm):
             pos = o + k  # alignment gaps hold zeros
         add(pos, G.end)
         slot_spans.append(arena.sq_range[g])
-    for a, b in spans:
-        ops.sqnorm(arena.grads[a:b], arena.sqnorm)
-    for a, b in slot_spans:  # torch's sum is a fixed reduction tree: deterministic
-        arena.sqnorm.add_(arena.sq_slots[a:b].sum())
+    # two launches for all ranges, two more for the slot table; sums in a fixed order (deterministic replicas); the
+    # finish kernels seed the running sum and write the norm: no framework fill / add / sqrt kernels in the pass
+    total = torch.empty(1, device=arena.grads.device, dtype=torch.float32)
+    ops.sqnorm_multi(arena.grads, spans, arena.sqnorm, None if slot_spans else total, overwrite=True)
+    if slot_spans:
+        ops.sqnorm_multi(arena.sq_slots, slot_spans, arena.sqnorm, total, overwrite=False, square=False)
     arena.pending_clip = float(max_norm)
-    return arena.sqnorm.sqrt()
+    return total.view(())
 
 
 class BertAdam(Optimizer):

@@ -758,10 +758,23 @@ def sum_rows(g):
 
 
 # ----------------------------------------------------------------------------- losses
-def dsm_fwd(s, g, coef):
+def zeros_f32(n, device):
+    """n zeroed floats from ONE custom launch (no framework fill kernel inside a captured pass)"""
+    m = (n + 3) // 4 * 4
+    t = torch.empty(m, device=device, dtype=F32)
+    zero_ranges(t, [(0, m)])
+    return t[:n]
+
+
+def _scalar(out, device):
+    """the 0-dim accumulator of a loss kernel: a caller-provided zeroed slot, or a fresh zeroed one"""
+    return out.view(()) if out is not None else zeros_f32(1, device).view(())
+
+
+def dsm_fwd(s, g, coef, out=None):
     _c(s), _c(g, F32, "grad_log_noise")
     assert s.shape == g.shape
-    loss = torch.zeros((), device=s.device, dtype=F32)
+    loss = _scalar(out, s.device)
     call("xggm_dsm_loss_fwd_" + sfx(s.dtype), ptr(s), ptr(g), ptr(loss), s.numel(), float(coef), stream())
     return loss
 
@@ -772,11 +785,11 @@ def dsm_bwd(s, g, gout, coef):
     return ds
 
 
-def symkl_fwd(x, y, coef):
+def symkl_fwd(x, y, coef, out=None):
     _c(x), _c(y, x.dtype)
     assert x.shape == y.shape
     W = x.shape[-1]
-    loss = torch.zeros((), device=x.device, dtype=F32)
+    loss = _scalar(out, x.device)
     call("xggm_symkl_" + sfx(x.dtype), ptr(x), ptr(y), ptr(loss), None, None, None, x.numel() // W, W,
          float(coef), 0, stream())
     return loss
@@ -791,10 +804,10 @@ def symkl_bwd(x, y, gout, coef, need_x, need_y):
     return dx, dy
 
 
-def bce_fwd(logit, target, coef):
+def bce_fwd(logit, target, coef, out=None):
     _c(logit, F32, "logit"), _c(target, F32, "target")
     assert logit.shape == target.shape
-    loss = torch.zeros((), device=logit.device, dtype=F32)
+    loss = _scalar(out, logit.device)
     call("xggm_bce_fwd", ptr(logit), ptr(target), ptr(loss), logit.numel(), float(coef), stream())
     return loss
 
@@ -827,6 +840,46 @@ def sqnorm(g, out):
     if ws is None:  # zeroed once; the kernel leaves its arrival counter at zero
         ws = _SQNORM_WS[g.device] = torch.zeros(4100, device=g.device, dtype=F32)
     call("xggm_sqnorm_f32", ptr(g), g.numel(), ptr(out), ptr(ws), stream())
+
+
+def sqnorm_multi(buf, spans, out, norm=None, overwrite=True, square=True):
+    """out (1 fp32) = [out +] sum over the (start, end) element ranges ``spans`` of buf^2 (``square`` False: of buf),
+    fixed summation order; ``norm`` (1 fp32 or None) = sqrt(out).  Any number of ranges (16 per launch pair; none:
+    only seeds / finishes)."""
+    _c(buf, F32), _c(out, F32)
+    if norm is not None:
+        _c(norm, F32)
+    ws = _SQNORM_WS.get(buf.device)
+    if ws is None:
+        ws = _SQNORM_WS[buf.device] = torch.zeros(4100, device=buf.device, dtype=F32)
+    rs = [(s, e) for s, e in spans if e > s]
+    chunks = [rs[i:i + 16] for i in range(0, len(rs), 16)] or [[]]
+    for ci, ch in enumerate(chunks):
+        offs = (_ct.c_int64 * max(len(ch), 1))(*[s for s, _ in ch])
+        lens = (_ct.c_int64 * max(len(ch), 1))(*[e - s for s, e in ch])
+        last = ci == len(chunks) - 1
+        call("xggm_sqnorm_multi_f32", ptr(buf), _ct.cast(offs, _ct.c_void_p), _ct.cast(lens, _ct.c_void_p), len(ch), ptr(out),
+             ptr(norm) if last else None, ptr(ws), int(overwrite and ci == 0), int(square), stream())
+
+
+def zero_diag(adj):
+    """adj.triu(1) + adj.tril(-1) for fp32 [B, N, N]"""
+    _c(adj, F32, "adjacency")
+    B, N, N2 = adj.shape
+    assert N == N2
+    out = torch.empty_like(adj)
+    call("xggm_zero_diag_f32", ptr(adj), ptr(out), B, N, stream())
+    return out
+
+
+def add_scalars(terms):
+    """sum of up to four 0-dim fp32 device tensors"""
+    ts = [_c(t, F32) for t in terms]
+    assert 1 <= len(ts) <= 4
+    out = torch.empty((), device=ts[0].device, dtype=F32)
+    ps = [ptr(t) for t in ts] + [None] * (4 - len(ts))
+    call("xggm_add_scalars_f32", ps[0], ps[1], ps[2], ps[3], ptr(out), stream())
+    return out
 
 
 def bertadam(p, g, m, v, shadow, sqn, max_norm, lr, lr_scale, b1, b2, eps, wd):

@@ -20,24 +20,26 @@ from ..runtime import runtime_of
 # backward.  The training passes use it for the loss weights (x num_answers, x 6 (8 KL + DSM), ...): every
 # ``scalar * loss`` written in torch is a kernel of its own in forward and another one in backward, ~5 us each for
 # one float.
-def loss_func(score, grad_log_q_noise, sigma=0.2, scale=1.0):
+# ``slot``: a zeroed 1-element fp32 tensor the kernel accumulates into (Runtime.scalar_slot: the loss terms of a pass
+# share one buffer zeroed by one launch); None = the op zeroes its own.
+def loss_func(score, grad_log_q_noise, sigma=0.2, scale=1.0, slot=None):
     """0.5 sigma^2 mean_b sum_ij (score - g)^2 / (d1 d2).  ref: src/vqa/vqacpv2.py:48-51"""
-    return XF.DSMFn.apply(score, grad_log_q_noise, sigma, scale)
+    return XF.DSMFn.apply(score, grad_log_q_noise, sigma, scale, slot)
 
 
-def compute_kl_loss(x, y, scale=1.0):
+def compute_kl_loss(x, y, scale=1.0, slot=None):
     """symmetric KL of the last-dim softmaxes, mean over all elements.
     ref: src/vqa/vqacpv2.py:54-61"""
     if x.dtype != y.dtype:
         x, y = x.float(), y.float()
-    return XF.SymKLFn.apply(x, y, scale)
+    return XF.SymKLFn.apply(x, y, scale, slot)
 
 
 class BCEWithLogitsLoss(nn.Module):
     """nn.BCEWithLogitsLoss() of src/vqa/vqacpv2.py:131 on fp32 logits."""
 
-    def forward(self, logit, target, scale=1.0):
-        return XF.BCEFn.apply(logit.float(), target.float(), scale)
+    def forward(self, logit, target, scale=1.0, slot=None):
+        return XF.BCEFn.apply(logit.float(), target.float(), scale, slot)
 
 
 class _Scaled:
@@ -55,7 +57,8 @@ class _Scaled:
 
 def remove_diagonal(adj_true):
     """adj_true.triu(1) + adj_true.tril(-1)   (src/vqa/vqacpv2.py:188): input preparation"""
-    return adj_true.triu(1) + adj_true.tril(-1)
+    from .. import ops
+    return ops.zero_diag(adj_true.float().contiguous())
 
 
 def enable_data_parallel(model, group=None, wire_dtype=None, overlap=None, zero1=False):
@@ -101,10 +104,11 @@ def forward_backward_plain(model, bce_loss, feats, boxes, sent, target, between=
     """step A up to backward: src/vqa/vqacpv2.py:170-174.  ``between``: callback between the two backward
     stages when the runtime cuts the graph (Runtime.backward)."""
     model.zero_grad()
+    rt = runtime_of(model)
     _, _, x = model(feats, boxes, sent)
     logit = model.logit_fc(x)
     loss = bce_loss(logit, target, scale=target.size(1))
-    runtime_of(model).backward(loss, between)
+    rt.backward(loss, between)
     return loss.detach(), logit.detach()
 
 
@@ -116,17 +120,18 @@ def forward_backward_ggm(model, bce_loss, feats, boxes, sent, target, adj_true, 
     model.zero_grad()
     rt = runtime_of(model)
     feat_seq, _, x = model(feats, boxes, sent)
-    adj_true = remove_diagonal(adj_true.float())
+    adj_true = remove_diagonal(adj_true)
     N = feat_seq[1].shape[1]
     A = target.size(1)
+    rt.begin_losses(4)  # the three loss kernels accumulate into slots of one buffer zeroed by one launch
     if branch == "rel":
         e = model.encoder_adj(x)
         adj_noise, grad_log_noise = XF.AdjInitFn.apply(e, N, sigma, randn, None if randn is not None else rt.rng, 9001)
         node_feats, adj_noise = model.generator(feat_seq[1], adj_noise)
         # loss = bce * A + 6 * (kl_weight * (kl * A) + dsm), the weights folded into the loss kernels
         w_kl, w_dsm = 6.0 * kl_weight * A, 6.0
-        loss_grad = loss_func(adj_noise, grad_log_noise, sigma=sigma, scale=w_dsm)
-        d_loss = compute_kl_loss(adj_true, adj_noise, scale=w_kl)
+        loss_grad = loss_func(adj_noise, grad_log_noise, sigma=sigma, scale=w_dsm, slot=rt.scalar_slot())
+        d_loss = compute_kl_loss(adj_true, adj_noise, scale=w_kl, slot=rt.scalar_slot())
     elif branch == "node":
         node_feats = XF.BcastRowsFn.apply(model.node_fc(x), N)  # == node_fc(x.unsqueeze(1).repeat(1, N, 1))
         node_feats, feat_grad = XF.FeatureNoiseFn.apply(node_feats, sigma, randn,
@@ -134,13 +139,13 @@ def forward_backward_ggm(model, bce_loss, feats, boxes, sent, target, adj_true, 
         node_feats, _ = model.generator(node_feats, adj_true)
         # loss = bce * A + 1.1 * (0.15 * (kl * A) + 6 * dsm)
         w_kl, w_dsm = 1.1 * 0.15 * A, 1.1 * 6.0
-        d_loss = compute_kl_loss(node_feats, feat_seq[1], scale=w_kl)
-        loss_grad = loss_func(node_feats, feat_grad, sigma=sigma, scale=w_dsm)
+        d_loss = compute_kl_loss(node_feats, feat_seq[1], scale=w_kl, slot=rt.scalar_slot())
+        loss_grad = loss_func(node_feats, feat_grad, sigma=sigma, scale=w_dsm, slot=rt.scalar_slot())
     else:
         raise ValueError(branch)
     x_gen = model.fusion_fc(XF.PoolConcatFn.apply(x, node_feats))
     logit = model.logit_fc(x_gen)
-    loss = bce_loss(logit, target, scale=A) + d_loss + loss_grad
+    loss = XF.LossSumFn.apply(bce_loss(logit, target, scale=A, slot=rt.scalar_slot()), d_loss, loss_grad)
     rt.backward(loss, between)
     # reported as the reference logs them: d_loss = KL * A, loss_grad = the unweighted DSM term
     return loss.detach(), logit.detach(), dict(d_loss=_Scaled(d_loss, w_kl / A), loss_grad=_Scaled(loss_grad, w_dsm))
