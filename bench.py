@@ -60,7 +60,7 @@ def parse(argv=None):
     p.add_argument("--no-loader", action="store_true", help="skip the loader-inclusive leg")
     p.add_argument("--wire", default="bf16", choices=["bf16", "f32"], help="gradient all-reduce dtype")
     p.add_argument("--zero1", type=int, default=None, help="1: shard the update over the ranks (reduce-scatter -> "
-                   "BertAdam on the shard -> all-gather of the weights); default: on for N > 1")
+                   "BertAdam on the shard -> all-gather of the weights); default: on from 8 ranks")
     p.add_argument("--seed", type=int, default=9595)
     a = p.parse_args(argv)
     if a.answers is None:
@@ -263,6 +263,9 @@ def kernel_timing(run_passes):
             f["flops"] += work
         elif name == "xggm_bertadam_f32":
             f["bytes"] += a[5] * (16 + 12 + (2 if a[4] else 0))
+        elif name == "xggm_bertadam_ex":
+            st = a[0]._obj  # the argument block: p, g (fp32 or bf16), m, v read; p, m, v (+ bf16 / e4m3 copies) written
+            f["bytes"] += st.n * ((14 if st.g_bf16 else 16) + 12 + (2 if st.shadow_bf16 else 0) + (1 if st.shadow8 else 0))
         elif name == "xggm_sqnorm_f32":
             f["bytes"] += a[1] * 4
         elif name.startswith("xggm_aggregate_"):
@@ -338,7 +341,8 @@ def pmc_traffic(family):
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this bench in separate eager runs, gfx950 correction applied by
     tools/pmc_summary.py); the newest round's file that covers the family wins; None when none does."""
     import glob
-    key = {"xggm_gemm_bf16": "gemm_", "xggm_bertadam_f32": "bertadam_kernel", "xggm_ln_bwd_bf16": "ln_bwd_kernel",
+    key = {"xggm_gemm_bf16": "gemm_", "xggm_bertadam_f32": "bertadam_kernel", "xggm_bertadam_ex": "bertadam_kernel",
+           "xggm_ln_bwd_bf16": "ln_bwd_kernel",
            "xggm_ln_fwd_bf16": "ln_fwd_kernel", "xggm_attn_bwd_bf16": "attn_bwd", "xggm_attn_fwd_bf16": "attn_fwd",
            "xggm_aggregate_bf16": "aggregate_kernel"}.get(family)
     if key is None:
@@ -378,7 +382,7 @@ def roofline_of(fam, prefer=None):
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
                     "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": pmc_traffic(dom),
                     "launches": f["n"], "avg_us": round(1000 * f["ms"] / f["n"], 2)}
-    for k in ("xggm_bertadam_f32", "xggm_aggregate_bf16"):  # the HBM-bound families: always with their rate
+    for k in ("xggm_bertadam_f32", "xggm_bertadam_ex", "xggm_aggregate_bf16"):  # the HBM-bound families: always with their rate
         if k in fam and fam[k]["ms"] > 0 and fam[k]["bytes"]:
             kernels.setdefault(k, {"ms": round(fam[k]["ms"], 3), "launches": fam[k]["n"],
                                    "share": round(fam[k]["ms"] / tot, 4)})
@@ -531,7 +535,8 @@ def main():
     zero1 = False
     if world > 1 or force_dp:
         from xggm_amd.vqa.vqacpv2 import enable_data_parallel
-        zero1 = bool(args.zero1) if args.zero1 is not None else False
+        # the sharded update trades the update's HBM traffic for an exposed all-gather: it pays with 7 links per GPU, not 1 - 3
+        zero1 = bool(args.zero1) if args.zero1 is not None else (world >= 8 and args.wire == "bf16" and args.dtype == "bf16")
         enable_data_parallel(model, wire_dtype=torch.bfloat16 if args.wire == "bf16" else None, zero1=zero1)
     trainer = CapturedTrainer(model, optim, batch, sigma=1.0, order=args.order, use_graph=not args.no_graph)
     log("trainer ready (hip_graph=%s)" % (not args.no_graph))

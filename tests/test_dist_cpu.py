@@ -148,3 +148,100 @@ def test_stage_ranges_tile_the_full_size_arena():
     # a forward that recorded another number of cuts than the layout predicts: everything after the last stage
     st = stage_ranges(fake, active, dict(pair_cut=2, x_mid=3, emb_cut=True), 3)
     assert [len(x) for x in st[:2]] == [0, 0] and sum(e - s_ for s_, e in st[2]) == sum(e - s_ for s_, e in active)
+
+
+def _sharded_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from xggm_amd.dist import ShardedUpdate, GradSync
+
+        class Grp:
+            def __init__(self, start, vec_start, end):
+                self.start, self.vec_start, self.end = start, vec_start, end
+
+        class Arena:
+            pass
+
+        a = Arena()
+        a.groups = {"g0": Grp(0, 1024, 1200), "g1": Grp(1280, 1792, 1800)}  # matrices on 256-element chunks
+        n = 2048
+        a.total = n
+        base = torch.arange(n, dtype=torch.float32) / 64.0
+        a.grads = base * (rank + 1)                       # vector gradients (fp32, cast in at the exchange)
+        a.wire = (base * (rank + 1)).to(torch.bfloat16)   # matrix gradients are born here
+        a.wire[1024:1200] = 0
+        a.wire[1792:1800] = 0
+        a.shadow = torch.full((n,), float(rank + 1), dtype=torch.bfloat16)
+        a.params = torch.full((n,), float(rank + 1))
+        a.m = torch.full((n,), 10.0 * (rank + 1))
+        a.v = torch.full((n,), 100.0 * (rank + 1))
+        z = ShardedUpdate(a)
+        ok = z.world == world and z.rank == rank
+        mean = (base * (sum(range(1, world + 1)) / world))
+        # two "stages": part of g0's matrices first, the rest + everything else second
+        st0, st1 = [(0, 512)], [(512, 1200), (1280, 1800)]
+        h0 = z.begin(st0)
+        h1 = z.begin(st1)
+        z.finish(h0)
+        z.finish(h1)
+        ok &= z.runs == [(0, 512), (512, 1024), (1280, 1792)]
+        for run in z.runs:
+            o0, o1 = z.own(run)
+            ok &= (o1 - o0) * world == run[1] - run[0] and o0 == run[0] + rank * (o1 - o0)
+            ok &= bool(((a.wire[o0:o1].float() - mean[o0:o1]).abs() <= 8e-3 * mean[o0:o1].abs() + 1e-6).all())
+        for s, e in ((1024, 1200), (1792, 1800)):  # vector ranges: averaged on every rank, from the fp32 gradients
+            ok &= bool(((a.wire[s:e].float() - mean[s:e]).abs() <= 8e-3 * mean[s:e].abs() + 1e-6).all())
+        own, vec = z.norm_spans(st0 + st1)
+        ok &= own == [z.own(r) for r in z.runs] and vec == [(1024, 1200), (1792, 1800)]
+        # the norm: own slices summed locally, one scalar all-reduced, vector ranges added by everyone
+        sq = sum((a.wire[o0:o1].double() ** 2).sum() for o0, o1 in own).float().reshape(1)
+        z.exchange_norm(sq)
+        full = sum((a.wire[s:e].double() ** 2).sum() for s, e in z.runs)
+        # (gloo path: every rank holds the whole averaged run, so the reference is computable locally)
+        ok &= abs(float(sq) - float(full)) <= 1e-4 * float(full)
+        # all-gather of the updated weights: every slice arrives from its owner
+        for run in z.runs:
+            o0, o1 = z.own(run)
+            a.shadow[o0:o1] = 50.0 + rank
+        z.gather()
+        for run in z.runs:
+            c = (run[1] - run[0]) // world
+            for r in range(world):
+                ok &= bool((a.shadow[run[0] + r * c:run[0] + (r + 1) * c] == 50.0 + r).all())
+        ok &= bool((a.shadow[1024:1280] == rank + 1).all())  # nothing outside the runs is touched
+        z.gather_state()
+        for run in z.runs:
+            c = (run[1] - run[0]) // world
+            for r in range(world):
+                sl = slice(run[0] + r * c, run[0] + (r + 1) * c)
+                ok &= bool((a.params[sl] == r + 1).all()) and bool((a.m[sl] == 10.0 * (r + 1)).all()) and bool((a.v[sl] == 100.0 * (r + 1)).all())
+        z.reset()
+        ok &= z.runs == []
+        # the plain in-place exchange (no sharding) on the same arena
+        a.wire = (base * (rank + 1)).to(torch.bfloat16)
+        g = GradSync(a.grads, wire_dtype=torch.bfloat16, arena=a)
+        g.sync([(0, 1200), (1280, 1800)])
+        ok &= bool(((a.wire[:1200].float() - mean[:1200]).abs() <= 8e-3 * mean[:1200].abs() + 1e-6).all())
+        ok &= torch.equal(a.wire[1200:1280], (base * (rank + 1)).to(torch.bfloat16)[1200:1280])
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_update_bookkeeping_world2():
+    """ZeRO-1 host logic over gloo (world size 2, CPU tensors): runs cut at the groups' matrix / vector borders, the
+    own slices, the in-place exchange on the wire arena (matrices reduced where the GEMMs wrote them, vectors cast in
+    from fp32), the scalar norm exchange, the all-gather of the updated weights and of the optimiser state."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)]

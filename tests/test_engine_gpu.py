@@ -150,6 +150,9 @@ def test_two_data_parallel_ranks_on_one_gpu_stay_identical():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("replicas identical: True") == 4 and "replicas identical: False" not in r.stdout
     assert "overlapped vs plain exchange: relative parameter difference 0.00e+00" in r.stdout
+    # the sharded update (ZeRO-1) on the wire arena: eager, two-graph and staged engines
+    assert r.stdout.count("bf16 weights identical on both ranks: True") == 3
+    assert "sharded vs replicated update: relative parameter difference" in r.stdout
 
 
 def test_bench_on_a_one_rank_rccl_group():
@@ -193,8 +196,9 @@ def test_bench_gpus_2_spawns_two_ranks():
     XGGM_DIST_BACKEND): the process group, the staged exchange, the max-over-ranks timing and the JSON are those
     of the real N = 2 run, only the transport differs."""
     line = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8", "--no-cpu-baseline",
-                       "--no-kernel-timing"], {"XGGM_DIST_BACKEND": "gloo", "XGGM_SHARE_GPU": "1"})
+                       "--no-kernel-timing", "--zero1", "1"], {"XGGM_DIST_BACKEND": "gloo", "XGGM_SHARE_GPU": "1"})
     assert line["n_gpus"] == 2 and line["config"]["world_size"] == 2 and line["config"]["backend"] == "gloo"
+    assert line["config"]["zero1"] is True
     assert line["config"]["global_batch"] == 16 and line["config"]["parallelism"] == "dp2"
     assert line["value"] > 0 and line["scaling"] == "weak" and line["steps"] == 2
     assert line["value_with_loader"]["value"] > 0
@@ -289,6 +293,41 @@ def test_prefetching_loader_feeds_the_captured_trainer(tmp_path):
     # that forward, so the trajectories agree to rounding, not bit for bit
     assert len(losses) == n_img // B and np.allclose(np.asarray(losses), np.asarray(losses2), rtol=2e-3)
     torch.cuda.synchronize()
+
+
+def test_learning_rate_edit_reaches_replayed_graphs_and_split_param_groups_are_refused():
+    """BertAdam reads the learning rate from a device table: editing ``param_groups[i]['lr']`` + ``sync_hyper()``
+    between replays changes the captured update (lr 0 freezes the parameters, the original lr moves them again);
+    an optimiser whose param_groups cut through an arena group (bias / LayerNorm in a no-decay group) is refused."""
+    from xggm_amd.engine import CapturedTrainer
+    from xggm_amd.lxrt.optimization import BertAdam
+    from xggm_amd.vqa.vqacpv2 import plain_pass, BCEWithLogitsLoss
+    B, A = 4, 29
+    cfg, m, opt = _tiny(5, 11)
+    batch = batch_tensors(synth.vqa_batch(B, A=A, F=cfg["feat_dim"], vocab=cfg["vocab"], seed=3), DEV)
+    tr = CapturedTrainer(m, opt, batch, warmup_iters=1)
+    tr.iteration("rel")
+    w = m.logit_fc[3].weight
+    lrs = [pg["lr"] for pg in opt.param_groups]
+    for pg in opt.param_groups:
+        pg["lr"] = 0.0
+    opt.sync_hyper()
+    before = w.detach().clone()
+    tr.iteration("rel")
+    assert torch.equal(w.detach(), before)
+    for pg, lr in zip(opt.param_groups, lrs):
+        pg["lr"] = lr
+    opt.sync_hyper()
+    tr.iteration("rel")
+    assert not torch.equal(w.detach(), before)
+    # a no-decay group that takes the biases out of every arena group
+    _, m2, _ = _tiny(5, 11)
+    decay = [p for n, p in m2.named_parameters() if not n.endswith("bias")]
+    no_decay = [p for n, p in m2.named_parameters() if n.endswith("bias")]
+    bad = BertAdam([{"params": decay}, {"params": no_decay, "weight_decay": 0.0}], lr=1e-3, warmup=0.1, t_total=10)
+    sent = (batch["input_ids"], batch["input_mask"], batch["segment_ids"])
+    with pytest.raises(ValueError, match="param_groups"):
+        plain_pass(m2, bad, BCEWithLogitsLoss(), batch["feats"], batch["boxes"], sent, batch["target"])
 
 
 def test_training_state_restored_under_live_graphs(tmp_path):

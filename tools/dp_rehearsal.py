@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def run(overlap, rank, use_graph=True, iters=("rel", "node", "rel"), layers=(2, 2, 1)):
+def run(overlap, rank, use_graph=True, iters=("rel", "node", "rel"), layers=(2, 2, 1), zero1=False, want="params"):
     from xggm_amd import synth
     from xggm_amd.engine import CapturedTrainer
     from xggm_amd.vqa.vqacpv2 import enable_data_parallel, make_optimizer
@@ -26,12 +26,17 @@ def run(overlap, rank, use_graph=True, iters=("rel", "node", "rel"), layers=(2, 
     b = batch_tensors(bn, "cuda")
     m(b["feats"], b["boxes"], (b["input_ids"], b["input_mask"], b["segment_ids"]))
     opt = make_optimizer(m, 1e-3, 20)
-    enable_data_parallel(m, wire_dtype=torch.bfloat16, overlap=overlap)
+    enable_data_parallel(m, wire_dtype=torch.bfloat16, overlap=overlap, zero1=zero1)
     tr = CapturedTrainer(m, opt, b, sigma=1.0, order="vqa", use_graph=use_graph, warmup_iters=1)
     for br in iters:
         tr.iteration(br)
     torch.cuda.synchronize()
     run.names = [(n, p.numel()) for n, p in m.named_parameters()]
+    arena = m.arena()
+    if want == "shadow":  # what the GEMMs read: must be identical on every rank after the all-gather
+        return arena.shadow.float().clone()
+    if zero1:
+        arena.zero1.gather_state()  # the fp32 masters of the other ranks' slices (as before a checkpoint)
     return torch.cat([p.detach().float().flatten() for p in m.parameters()])
 
 
@@ -56,7 +61,33 @@ def main():
     report(run(False, rank, use_graph=False, iters=("rel",)), rank, "eager, 1 iteration")
     for layers in ((2, 2, 1), (5, 4, 4)):  # two cuts (three backward stages) / four cuts (five stages)
         check(rank, layers)
+    check_sharded(rank)
     dist.destroy_process_group()
+
+
+def check_sharded(rank):
+    """ZeRO-1: reduce-scatter (gloo: all-reduce + own slice) -> BertAdam on the own slices -> all-gather of the bf16
+    weights.  The weights every rank computes with stay identical; after gather_state so do the fp32 masters; and the
+    training equals the unsharded one (same averaged gradients, element-wise update; the clip norm is summed in
+    another order)."""
+    for overlap, use_graph in ((False, False), (False, True), (True, True)):
+        sh = run(overlap, rank, use_graph=use_graph, layers=(5, 4, 4), zero1=True, want="shadow")
+        other = [torch.empty_like(sh) for _ in range(2)]
+        dist.all_gather(other, sh)
+        same = bool(torch.equal(other[0], other[1]))
+        if rank == 0:
+            print("sharded update overlap=%s graphs=%s: bf16 weights identical on both ranks: %s" % (overlap, use_graph, same),
+                  flush=True)
+        assert same
+    ref = run(True, rank, layers=(5, 4, 4))
+    got = run(True, rank, layers=(5, 4, 4), zero1=True)
+    other = [torch.empty_like(got) for _ in range(2)]
+    dist.all_gather(other, got)
+    assert torch.equal(other[0], other[1]), "fp32 masters differ after gather_state"
+    d = float((got - ref).double().norm() / ref.double().norm())
+    if rank == 0:
+        print("sharded vs replicated update: relative parameter difference %.2e" % d, flush=True)
+    assert d < 1e-4
 
 
 def check(rank, layers):

@@ -94,10 +94,20 @@ class ParamArena:
         self.shadow = (torch.zeros(self.total, device=dev, dtype=torch.bfloat16)
                        if compute_dtype == torch.bfloat16 else None)
         self.fp8 = None  # xggm_amd.fp8.Fp8State when the forward QKV / FFN products run on e4m3 operands
+        # Data parallelism with bf16 on the wire: the weight-gradient GEMMs write MATRIX gradients straight into this
+        # bf16 mirror of the gradient buffer (same offsets), RCCL reduces it in place and the update reads it -- no
+        # fp32 copy of those gradients, no cast before and no copy after the exchange.  Vector gradients (biases,
+        # LayerNorm, embedding tables: accumulated with fp32 atomics) stay in ``grads`` and are cast into their
+        # ranges of the wire when the exchange starts.  ``p.grad`` of a matrix is then only a presence marker.
+        self.wire = None
         # device scalars: per-group step counter + schedule value, global sum of squares
         self.steps = torch.zeros(len(order), device=dev, dtype=torch.int64)
         self.lr_scale = torch.ones(len(order), device=dev, dtype=torch.float32)
         self.sqnorm = torch.zeros(1, device=dev, dtype=torch.float32)
+        # learning rate of each group as the update kernels read it (BertAdam.sync_hyper keeps it equal to
+        # param_groups[i]['lr']: an edit between replays of a captured pass takes effect)
+        self.lr_table = torch.zeros(len(order), device=dev, dtype=torch.float32)
+        self.lr_host = [None] * len(order)
         self.group_index = {g: i for i, g in enumerate(order)}
         self.pending_clip = None  # max_norm registered by clip_grad_norm_, consumed by BertAdam.step
         self.zero1 = None         # dist.ShardedUpdate when the update is sharded over data-parallel ranks
@@ -174,7 +184,15 @@ class ParamArena:
             return buf[o0:o0 + k].view(-1, ps[0].shape[1])
         return buf[o0:o0 + k]
 
-    def grad_view(self, ps):
+    def enable_wire(self):
+        if self.shadow is None:
+            raise RuntimeError("the bf16 wire arena needs bf16 storage")
+        if self.wire is None:
+            self.wire = torch.zeros(self.total, device=self.device, dtype=torch.bfloat16)
+        self.sq_enabled = False
+        return self.wire
+
+    def grad_view(self, ps, wire=False):
         if not isinstance(ps, (list, tuple)):
             ps = [ps]
         o0 = ps[0]._xg[1]
@@ -183,7 +201,7 @@ class ParamArena:
             if p._xg[1] != o0 + k:
                 raise RuntimeError("parameters are not adjacent in the arena")
             k += p.numel()
-        v = self.grads[o0:o0 + k]
+        v = (self.wire if wire else self.grads)[o0:o0 + k]
         return v.view(-1, ps[0].shape[1]) if ps[0].dim() >= 2 else v
 
     # ------------------------------------------------------------------ gradient bookkeeping
@@ -197,6 +215,8 @@ class ParamArena:
         self.pending_clip = None
         self.sq_covered.clear()
         self.sq_clean = False
+        if self.zero1 is not None:
+            self.zero1.reset()
 
     def _publish(self, p):
         o, k = p._xg[1], p._xg[2]
@@ -212,7 +232,8 @@ class ParamArena:
                 raise RuntimeError("fused parameters disagree on having a gradient")
             if not acc:
                 self._publish(p)
-        return self.grad_view(ps), acc
+        # matrices (never "atomic" tensors) go to the wire arena when there is one
+        return self.grad_view(ps, wire=self.wire is not None and not ps[0]._xg[4]), acc
 
     def sq_target(self, ps, like):
         """the norm slots of the weight-gradient GEMM into ``ps`` (adjacent, equally wide parameters), or None when

@@ -36,8 +36,12 @@ def ranges_to_buckets(ranges, bucket_elems=DEFAULT_BUCKET):
 class GradSync:
     """all-reduce (average) slices of a flat gradient buffer across the process group."""
 
-    def __init__(self, flat_grads, group=None, wire_dtype=None, bucket_elems=DEFAULT_BUCKET):
+    def __init__(self, flat_grads, group=None, wire_dtype=None, bucket_elems=DEFAULT_BUCKET, arena=None):
+        """``arena`` with a wire buffer (ParamArena.enable_wire): the exchange runs IN PLACE on ``arena.wire`` -- the
+        matrix gradients are already there (written by the weight-gradient GEMMs), only the vector ranges are cast
+        in -- and nothing is copied back: the norm pass and the update read the wire."""
         self.g = flat_grads
+        self.arena = arena if (arena is not None and getattr(arena, "wire", None) is not None) else None
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # XGGM_DP_FORCE=1: issue the collectives even in a one-rank group (rehearses the RCCL stream / graph
@@ -50,10 +54,51 @@ class GradSync:
         self._wire = None
         self._flight = None
 
+    # ---- in-place exchange on the bf16 wire arena
+    def vec_parts(self, ranges):
+        """the pieces of ``ranges`` that lie in a group's vector region (gradients accumulated in fp32)"""
+        out = []
+        for s, e in ranges:
+            for G in self.arena.groups.values():
+                a, b = max(s, G.vec_start), min(e, G.end)
+                if b > a:
+                    out.append((a, b))
+        return out
+
+    def cast_vectors(self, ranges):
+        a = self.arena
+        for s, e in self.vec_parts(ranges):
+            if a.wire.is_cuda:
+                from . import ops
+                ops.cast_bf16(a.grads[s:e], a.wire[s:e])
+            else:
+                a.wire[s:e].copy_(a.grads[s:e])
+
+    def _begin_inplace(self, ranges):
+        self.cast_vectors(ranges)
+        w = self.arena.wire
+        use_avg = self.backend == "nccl"
+        op = dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM
+        rs = [(s, e) for s, e in ranges if e > s]
+        works = [dist.all_reduce(w[s:e], op=op, group=self.group, async_op=True) for s, e in rs]
+        return ("inplace", rs, works, use_avg)
+
+    def _finish_inplace(self, handle):
+        _, rs, works, use_avg = handle
+        for wk in works:
+            wk.wait()
+        if not use_avg:
+            for s, e in rs:
+                self.arena.wire[s:e].div_(self.world)
+
     def sync(self, ranges):
         """average ``flat_grads[s:e]`` over ranks for every (s, e) in ``ranges``."""
         if self.world == 1 and not self.force:
+            if self.arena is not None:
+                self.cast_vectors(ranges)  # the update reads the wire
             return
+        if self.arena is not None:
+            return self._finish_inplace(self._begin_inplace(ranges))
         buckets = ranges_to_buckets(ranges, self.bucket_elems)
         use_avg = self.backend == "nccl"
         op = dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM
@@ -92,6 +137,11 @@ class GradSync:
 
     # ---- split form: ``begin`` puts the ranges on the wire and returns at once, ``finish`` waits and writes back
     def begin(self, ranges, slot=0):
+        if self.arena is not None and ranges:
+            if self.world == 1 and not self.force:
+                self.cast_vectors(ranges)
+                return None
+            return self._begin_inplace(ranges)
         if (self.world == 1 and not self.force) or not ranges:
             return None
         buckets = ranges_to_buckets(ranges, self.bucket_elems)
@@ -125,6 +175,8 @@ class GradSync:
     def finish(self, handle):
         if handle is None:
             return
+        if handle[0] == "inplace":
+            return self._finish_inplace(handle)
         buckets, wire, works, use_avg = handle
         if wire is not None:  # collectives cover the whole stage buffer, not single buckets
             for w in works:
@@ -136,6 +188,134 @@ class GradSync:
                 self.g[s:e].copy_(wire[i])
             if not use_avg:
                 self.g[s:e].div_(self.world)
+
+
+class ShardedUpdate(GradSync):
+    """ZeRO-1 on the wire arena: the update of the MATRIX ranges is sharded over the data-parallel ranks.
+
+        backward (per stage)   reduce-scatter of the stage's matrix runs: rank r keeps the averaged r-th slice of
+                               every run (in place: the slice of the wire it already holds); all-reduce of the vector
+                               runs (biases, LayerNorm, embedding tables: 12 % of the parameters, updated everywhere)
+        norm                   sum of squares over the own slices -> all-reduce of ONE scalar -> + the vector ranges
+        update                 BertAdam on the own slices (1 / world of p, m, v) and on the vector ranges
+        after the update       all-gather of the bf16 shadow weights of the matrix runs (what the GEMMs read)
+
+    Same bytes on the links as the all-reduce it replaces (reduce-scatter + all-gather), 1 / world of the 30 B per
+    parameter the update streams through HBM -- the step is update-bound at 32 samples per GPU.
+    The fp32 masters and moments of the other ranks' slices go stale: ``gather_state`` refreshes them before a
+    checkpoint.  Runs are contiguous pieces of the gradient buffer whose length divides by the world size (matrices
+    start on 256-element chunks, arena.ALIGN_MAT); the slices of one pass are recorded at the exchange and reused by
+    the norm, the update and the gather."""
+
+    def __init__(self, arena, group=None):
+        if getattr(arena, "wire", None) is None:
+            raise RuntimeError("the sharded update runs on the bf16 wire arena (ParamArena.enable_wire)")
+        super().__init__(arena.grads, group, torch.bfloat16, arena=arena)
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if any(256 % w for w in (self.world,)) and self.world > 1:
+            raise RuntimeError("sharded update: world size %d must divide 256" % self.world)
+        self.runs = []  # matrix runs (start, end) exchanged in this pass, in exchange order
+        self.all_runs = set()  # every run any pass has exchanged (gather_state)
+
+    def reset(self):
+        self.runs = []
+
+    def split(self, ranges):
+        """ranges -> (matrix runs, vector runs): cut at the groups' matrix / vector borders"""
+        mats, vecs = [], []
+        for s, e in ranges:
+            for G in self.arena.groups.values():
+                a, b = max(s, G.start), min(e, G.vec_start)
+                if b > a:
+                    mats.append((a, b))
+                a, b = max(s, G.vec_start), min(e, G.end)
+                if b > a:
+                    vecs.append((a, b))
+        return mats, vecs
+
+    def own(self, run):
+        a, b = run
+        c = (b - a) // self.world
+        if c * self.world != b - a:
+            raise RuntimeError("sharded update: run [%d, %d) does not divide by %d ranks" % (a, b, self.world))
+        return a + self.rank * c, a + (self.rank + 1) * c
+
+    def _begin_inplace(self, ranges):
+        self.cast_vectors(ranges)
+        w = self.arena.wire
+        nccl = self.backend == "nccl"
+        op = dist.ReduceOp.AVG if nccl else dist.ReduceOp.SUM
+        mats, vecs = self.split(ranges)
+        works = []
+        for run in mats:
+            self.runs.append(run)
+            self.all_runs.add(run)
+            a, b = run
+            if nccl:  # in place: the output is this rank's slice of the input
+                o0, o1 = self.own(run)
+                works.append(dist.reduce_scatter_tensor(w[o0:o1], w[a:b], op=op, group=self.group, async_op=True))
+            else:     # gloo has no reduce-scatter: all-reduce, every rank then uses its slice only
+                works.append(dist.all_reduce(w[a:b], op=op, group=self.group, async_op=True))
+        works += [dist.all_reduce(w[s:e], op=op, group=self.group, async_op=True) for s, e in vecs]
+        return ("inplace", mats + vecs, works, nccl)
+
+    def begin(self, ranges, slot=0):
+        if not ranges:
+            return None
+        if self.world == 1 and not self.force:
+            self.cast_vectors(ranges)
+            mats = self.split(ranges)[0]
+            self.runs += mats
+            self.all_runs.update(mats)
+            return None
+        return self._begin_inplace(ranges)
+
+    def sync(self, ranges):
+        self.finish(self.begin(ranges))
+
+    # ---- after the exchange
+    def norm_spans(self, ranges):
+        """(spans summed locally and all-reduced, spans every rank sums itself)"""
+        return [self.own(r) for r in self.runs], self.split(ranges)[1]
+
+    def exchange_norm(self, sq):
+        if self.world > 1 or self.force:
+            dist.all_reduce(sq, op=dist.ReduceOp.SUM, group=self.group)
+
+    def gather(self):
+        """all-gather the bf16 shadow weights of this pass's matrix runs from their owners"""
+        if self.world == 1 and not self.force:
+            return
+        sh = self.arena.shadow
+        works = []
+        for run in self.runs:
+            a, b = run
+            o0, o1 = self.own(run)
+            if self.backend == "nccl":
+                works.append(dist.all_gather_into_tensor(sh[a:b], sh[o0:o1], group=self.group, async_op=True))
+            else:
+                c = (b - a) // self.world
+                works.append(dist.all_gather([sh[a + i * c:a + (i + 1) * c] for i in range(self.world)], sh[o0:o1].clone(),
+                                             group=self.group, async_op=True))
+        for wk in works:
+            wk.wait()
+
+    @torch.no_grad()
+    def gather_state(self):
+        """fp32 masters and BertAdam moments of EVERY matrix range from their owners (before state_dict / a
+        checkpoint), run by run as the passes exchanged them"""
+        if self.world == 1:
+            return
+        for run in sorted(self.all_runs):
+            a, b = run
+            o0, o1 = self.own(run)
+            c = (b - a) // self.world
+            for buf in (self.arena.params, self.arena.m, self.arena.v):
+                if self.backend == "nccl":
+                    dist.all_gather_into_tensor(buf[a:b], buf[o0:o1], group=self.group)
+                else:
+                    dist.all_gather([buf[a + i * c:a + (i + 1) * c] for i in range(self.world)], buf[o0:o1].clone(),
+                                    group=self.group)
 
 
 def stage_ranges(arena, ranges, layout, n_stages):

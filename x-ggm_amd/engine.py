@@ -63,6 +63,41 @@ class CapturedTrainer:
         self.rt.advance()
         return total
 
+    # the update as graphs: one, or -- sharded update -- two with the norm's scalar all-reduce between them and the
+    # all-gather of the weights behind them (collectives run on the live communicator, never inside a capture)
+    def _capture_update(self, pool):
+        z = self.rt.arena.zero1
+        if z is None:
+            gu = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gu, pool=pool, capture_error_mode=self.capture_mode):
+                total = self._update()
+            return (gu,), total
+        from .lxrt.optimization import clip_norm_local, clip_norm_finish
+        arena = self.rt.arena
+        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1, pool=pool, capture_error_mode=self.capture_mode):
+            clip_norm_local(arena)
+        z.exchange_norm(arena.sqnorm)
+        with torch.cuda.graph(g2, pool=pool, capture_error_mode=self.capture_mode):
+            total = clip_norm_finish(arena, self.clip)
+            self.optim.step()
+        z.gather()
+        self.optim.zero_grad()
+        # Runtime.advance (new dropout masks for the next pass) is NOT run here: a capture executes nothing, and the
+        # replay issues it eagerly behind the gather (_replay_update) -- exactly once per trained pass
+        return (g1, g2), total
+
+    def _replay_update(self, gus):
+        if len(gus) == 1:
+            gus[0].replay()
+            return
+        z = self.rt.arena.zero1
+        gus[0].replay()
+        z.exchange_norm(self.rt.arena.sqnorm)
+        gus[1].replay()
+        z.gather()
+        self.rt.advance()
+
     def _stage_ranges(self):
         from .dist import active_ranges, stage_ranges
         return stage_ranges(self.rt.arena, active_ranges(self.rt.arena), self.rt.cut_layout, self.rt.n_stages)
@@ -119,10 +154,13 @@ class CapturedTrainer:
                 ranges = None
                 from .dist import active_ranges
                 ranges = active_ranges(self.rt.arena)
-                g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2, pool=pool, capture_error_mode=self.capture_mode):
-                    total = self._update()
-                self.graphs[kind] = (g1, g2, ranges)
+                if self.rt.arena.zero1 is not None:
+                    # the sharded update records its runs at the exchange: run the one of this pass kind (on whatever the
+                    # buffers hold -- the captured kernels have not run; every rank does the same)
+                    self.rt.arena.zero1.reset()
+                    self.model._grad_sync.sync(ranges)
+                gus, total = self._capture_update(pool)
+                self.graphs[kind] = (g1, gus, ranges)
                 self.outputs[kind] = (loss, logit, total)
             else:
                 # one graph per backward stage: forward + stage 0 | stage 1 | ... | clip + update.  The capture is
@@ -153,10 +191,13 @@ class CapturedTrainer:
                 if final is None:
                     from .dist import active_ranges
                     final = active_ranges(self.rt.arena)
-                gu = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gu, pool=pool, capture_error_mode=self.capture_mode):
-                    total = self._update()
-                self.graphs[kind] = ("staged", graphs, early, final, gu)
+                if self.rt.arena.zero1 is not None:
+                    # the runs of this pass kind, recorded as the real exchange would record them
+                    self.rt.arena.zero1.reset()
+                    for rs in early + [final]:
+                        self.model._grad_sync.sync(rs)
+                gus, total = self._capture_update(pool)
+                self.graphs[kind] = ("staged", graphs, early, final, gus)
                 self.outputs[kind] = (loss, logit, total)
         torch.cuda.synchronize()
 
@@ -170,16 +211,18 @@ class CapturedTrainer:
         if not self.use_graph:
             return self._eager_pass(kind)
         gs = self.graphs[kind]
+        if self.rt.arena.zero1 is not None:
+            self.rt.arena.zero1.reset()  # the runs of this pass are recorded again by its exchanges
         if len(gs) == 1:
             gs[0].replay()
         elif gs[0] != "staged":
             gs[0].replay()
             self.model._grad_sync.sync(gs[2])
-            gs[1].replay()
+            self._replay_update(gs[1])
         else:
             # the exchange of stage k (cast to the wire type, all-reduce, copy back) is queued on a side stream
             # right behind graph k and runs under graph k + 1; the update waits for all of it
-            _, graphs, early, final, gu = gs
+            _, graphs, early, final, gus = gs
             sync = self.model._grad_sync
             main = torch.cuda.current_stream()
             if self._comm is None:
@@ -206,7 +249,7 @@ class CapturedTrainer:
                 prev = ev
             exchange(len(graphs) - 1, prev)
             main.wait_stream(comm)
-            gu.replay()
+            self._replay_update(gus)
         return self.outputs[kind]
 
     def iteration(self, branch):

@@ -53,6 +53,11 @@ def clip_grad_norm_(parameters, max_norm):
     arena = _arena_of_params(params)
     if arena is None:
         raise RuntimeError("clip_grad_norm_: parameters are not arena-managed; run a forward first")
+    if arena.wire is not None:  # data parallel, bf16 wire arena: the (averaged) gradients live there
+        clip_norm_local(arena)
+        if arena.zero1 is not None:
+            arena.zero1.exchange_norm(arena.sqnorm)
+        return clip_norm_finish(arena, max_norm)
     # ranges of the flat gradient buffer the norm pass has to READ: everything of the active groups except the
     # matrices whose weight-gradient GEMM already left its sum of squares in the slot table (arena.sq_target);
     # adjacent ranges are merged
@@ -83,6 +88,34 @@ def clip_grad_norm_(parameters, max_norm):
     ops.sqnorm_multi(arena.grads, spans, arena.sqnorm, None if slot_spans else total, overwrite=True)
     if slot_spans:
         ops.sqnorm_multi(arena.sq_slots, slot_spans, arena.sqnorm, total, overwrite=False, square=False)
+    arena.pending_clip = float(max_norm)
+    return total.view(())
+
+
+def _active_ranges(arena):
+    return [(arena.groups[g].start, arena.groups[g].end)
+            for g in sorted(arena.active_groups(), key=lambda n: arena.groups[n].start)]
+
+
+def clip_norm_local(arena):
+    """wire-arena norm, first half: seed the running sum and add what THIS rank sums alone -- everything without a
+    sharded update, the own slices of the matrix runs with one (their sum is then all-reduced: ShardedUpdate)"""
+    ops.sqnorm_multi(arena.grads, [], arena.sqnorm, None, overwrite=True)
+    z = arena.zero1
+    spans = _active_ranges(arena) if z is None else z.norm_spans(_active_ranges(arena))[0]
+    for a, b in spans:
+        if b > a:
+            ops.sqnorm_bf16(arena.wire[a:b], arena.sqnorm)
+
+
+def clip_norm_finish(arena, max_norm):
+    """second half: the vector ranges every rank holds in full (sharded update only), then the norm"""
+    z = arena.zero1
+    if z is not None:
+        for a, b in z.norm_spans(_active_ranges(arena))[1]:
+            ops.sqnorm_bf16(arena.wire[a:b], arena.sqnorm)
+    total = torch.empty(1, device=arena.grads.device, dtype=torch.float32)
+    ops.sqnorm_multi(arena.grads, [], arena.sqnorm, total, overwrite=False)
     arena.pending_clip = float(max_norm)
     return total.view(())
 
@@ -171,12 +204,41 @@ class BertAdam(Optimizer):
             arena.steps[arena.group_index[gname]] = s
 
     def _hyper_of_group(self, arena, gname):
-        """the optimiser param_group that holds (all) parameters of arena group ``gname``."""
-        first = arena.groups[gname].params[0]
-        for pg in self.param_groups:
-            if any(p is first for p in pg['params']):
-                return pg
-        return None
+        """the optimiser param_group that holds ALL parameters of arena group ``gname`` (one contiguous range, one
+        launch, one set of hyper-parameters).  A param_groups split that cuts through an arena group -- the usual
+        BERT "no decay for bias / LayerNorm" grouping would -- cannot be honoured by a flat update and is refused
+        instead of silently applying the first parameter's settings to the whole range."""
+        cache = getattr(self, "_group_pg", None)
+        if cache is None:
+            cache = self._group_pg = {}
+        if gname not in cache:
+            owner = {}
+            for i, pg in enumerate(self.param_groups):
+                for p in pg['params']:
+                    owner[id(p)] = i
+            idx = {owner.get(id(p)) for p in arena.groups[gname].params}
+            if len(idx) > 1:
+                raise ValueError("BertAdam: the parameters of arena group '%s' are spread over optimiser param_groups %s; "
+                                 "a group is updated as one range with one lr / weight_decay / schedule -- keep its "
+                                 "parameters in one param_group (vqa.vqacpv2.make_optimizer does)" % (gname, sorted(idx, key=str)))
+            cache[gname] = idx.pop()
+        i = cache[gname]
+        return None if i is None else self.param_groups[i]
+
+    def sync_hyper(self):
+        """push ``param_groups[i]['lr']`` to the device table the update kernels read: call after editing a learning
+        rate between replays of a captured pass (an eager ``step()`` does it by itself)"""
+        arena = self._arena()
+        if arena is None:
+            return
+        for g in arena.groups:
+            pg = self._hyper_of_group(arena, g)
+            gi = arena.group_index[g]
+            if pg is not None and arena.lr_host[gi] != float(pg['lr']):
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("BertAdam: a learning rate changed during graph capture; call sync_hyper() before")
+                arena.lr_table[gi] = float(pg['lr'])
+                arena.lr_host[gi] = float(pg['lr'])
 
     def get_lr(self):
         """ref :100-114: the scheduled learning rate of every parameter, in param_groups order; ``[0]`` while some
@@ -225,21 +287,39 @@ class BertAdam(Optimizer):
             todo.append((G, pg, arena.group_index[g]))
         if todo:  # schedule values and step counters of all groups: one launch
             ops.sched_step_multi(arena.steps, arena.lr_scale, [(gi, pg['t_total'], pg['warmup']) for _, pg, gi in todo])
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_hyper()  # the kernels read lr from a device table: edits of param_groups survive graph replay
+        elif any(arena.lr_host[gi] is None for _, _, gi in todo):
+            raise RuntimeError("BertAdam.step is being captured before any eager step: run one pass eagerly first "
+                               "(the learning rates are uploaded to the device outside of captures)")
         f8 = arena.fp8
+        gbuf = arena.wire if arena.wire is not None else arena.grads  # bf16 wire arena: the update reads it directly
+        z = arena.zero1
+        if z is not None and f8 is not None:
+            raise NotImplementedError("sharded update + fp8 forward: the e4m3 weight copies and their scale table "
+                                      "would have to be gathered too")
         for G, pg, gi in todo:
             scale_t = arena.lr_scale[gi:gi + 1]
+            if z is not None:
+                # sharded update: this rank's slice of every matrix run of the group + the whole vector region
+                pieces = [z.own(r) for r in z.runs if r[0] >= G.start and r[1] <= G.vec_start] + [(G.vec_start, G.end)]
+                for a, b in pieces:
+                    if b > a:
+                        sl = slice(a, b)
+                        ops.bertadam_ex(arena.params[sl], gbuf[sl], arena.m[sl], arena.v[sl], arena.shadow[sl], sq, max_norm,
+                                        pg['lr'], scale_t, pg['b1'], pg['b2'], pg['e'], pg['weight_decay'],
+                                        lr_dev=arena.lr_table[gi:gi + 1], elem0=a)
+                continue
             sl = slice(G.start, G.end)
             w8 = f8.adam_w8(G.name) if f8 is not None else None
             if w8 is not None:
                 # fp8 forward: this group's weight operands get their e4m3 copies from the same pass over p, with
                 # the scales the delayed update derives from the maxima earlier steps recorded
                 f8.update_weight_scales(G.name)
-                ops.bertadam_ex(arena.params[sl], arena.grads[sl], arena.m[sl], arena.v[sl], arena.shadow[sl], sq, max_norm,
-                                pg['lr'], scale_t, pg['b1'], pg['b2'], pg['e'], pg['weight_decay'],
-                                w8=(f8.shadow8[sl],) + w8, elem0=G.start)
-                continue
-            ops.bertadam(arena.params[sl], arena.grads[sl], arena.m[sl], arena.v[sl],
-                         None if arena.shadow is None else arena.shadow[sl], sq, max_norm, pg['lr'], scale_t,
-                         pg['b1'], pg['b2'], pg['e'], pg['weight_decay'])
+                w8 = (f8.shadow8[sl],) + w8
+            ops.bertadam_ex(arena.params[sl], gbuf[sl], arena.m[sl], arena.v[sl],
+                            None if arena.shadow is None else arena.shadow[sl], sq, max_norm, pg['lr'], scale_t,
+                            pg['b1'], pg['b2'], pg['e'], pg['weight_decay'], lr_dev=arena.lr_table[gi:gi + 1], w8=w8,
+                            elem0=G.start)
         arena.pending_clip = None
         return loss

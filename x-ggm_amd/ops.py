@@ -133,15 +133,16 @@ def linear_dgrad(dy, w, residual=None, gelu_aux=None):
 
 
 def linear_wgrad(dy, x, gw, accumulate):
-    """gw[N,K] (fp32) (+)= dy[M,N]^T @ x[M,K]."""
+    """gw[N,K] (+)= dy[M,N]^T @ x[M,K]; gw fp32, or bf16 (the data-parallel wire arena: the gradient is born in the
+    type it crosses the links in)."""
     M, N, dy_rs = _rows(_chk(dy))
     M2, K, x_rs = _rows(_chk(x))
     if M2 != M or x.dtype != dy.dtype:
         raise RuntimeError("linear_wgrad: %s vs %s" % (tuple(dy.shape), tuple(x.shape)))
-    _c(gw, F32, "weight grad")
-    assert tuple(gw.shape) == (N, K)
+    _c(gw)
+    assert tuple(gw.shape) == (N, K) and (gw.dtype == F32 or gw.dtype == dy.dtype)
     # A(m=n, k=m') = dy[m', n]: row index contiguous; B(k=m', n=k) = x[m', k]
-    gemm_raw(dy.dtype, dy, x, gw, N, K, M, 1, dy_rs, 1, x_rs, K, c_f32=True, accumulate=accumulate)
+    gemm_raw(dy.dtype, dy, x, gw, N, K, M, 1, dy_rs, 1, x_rs, K, c_f32=gw.dtype == F32, accumulate=accumulate)
 
 
 def _ws(nbytes, device):
@@ -271,8 +272,9 @@ def p_wgrad(dy, x, gw, accumulate, sqsum=None):
     squares of the stored gradient per 64 x 64 block (tuned bf16 kernels only), or None."""
     M, N, dy_rs = _rows(_chk(dy))
     M2, K, x_rs = _rows(_chk(x))
-    assert M2 == M and x.dtype == dy.dtype and tuple(gw.shape) == (N, K) and gw.dtype == F32 and gw.is_contiguous()
-    p = _problem(dy, x, gw, N, K, M, 1, dy_rs, 1, x_rs, K, c_f32=True, accumulate=accumulate)
+    assert M2 == M and x.dtype == dy.dtype and tuple(gw.shape) == (N, K) and gw.is_contiguous()
+    assert gw.dtype == F32 or gw.dtype == dy.dtype  # bf16: the data-parallel wire arena
+    p = _problem(dy, x, gw, N, K, M, 1, dy_rs, 1, x_rs, K, c_f32=gw.dtype == F32, accumulate=accumulate)
     if sqsum is not None:
         _c(sqsum, F32, "sqsum slots")
         assert sqsum.numel() == ((N + 63) // 64) * ((K + 63) // 64)
@@ -995,7 +997,8 @@ def cast_from_f32(x, dt):
 def cast_bf16(x, out):
     _c(x, F32), _c(out, BF16)
     assert x.numel() == out.numel()
-    call("xggm_cast_f32_to_bf16", ptr(x), ptr(out), x.numel(), stream())
+    if x.numel():
+        call("xggm_cast_f32_to_bf16", ptr(x), ptr(out), x.numel(), stream())
 
 
 def dropout_mask(n, p, rng, sid, device):

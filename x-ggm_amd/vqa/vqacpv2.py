@@ -81,15 +81,23 @@ def enable_data_parallel(model, group=None, wire_dtype=None, overlap=None, zero1
     if rank:
         # seed word of the device-resident {seed, offset} pair; saved / restored with the training state
         rt.rng[0] = (int(rt.rng[0].item()) + rank * 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF
-    gs = GradSync(rt.arena.grads, group, wire_dtype)
+    inplace = wire_dtype == torch.bfloat16 and rt.arena.shadow is not None and os.environ.get("XGGM_DP_WIRE_ARENA", "1") != "0"
+    if inplace:
+        # bf16 on the wire + bf16 storage: matrix gradients are BORN in the wire arena (weight-gradient GEMM epilogue),
+        # reduced in place and read by the update: no cast before, no copy after the exchange
+        rt.arena.enable_wire()
+    if zero1 and not inplace:
+        raise RuntimeError("the sharded update needs the bf16 wire arena (bf16 storage, wire_dtype=torch.bfloat16)")
+    if zero1:
+        from ..dist import ShardedUpdate
+        gs = rt.arena.zero1 = ShardedUpdate(rt.arena, group)
+    else:
+        gs = GradSync(rt.arena.grads, group, wire_dtype, arena=rt.arena if inplace else None)
     object.__setattr__(model, "_grad_sync", gs)
     rt.arena.sq_enabled = False  # the clip norm is that of the AVERAGED gradients: read them after the exchange
     if overlap is None:
         overlap = os.environ.get("XGGM_DP_OVERLAP", "1") != "0"
     rt.cut_enabled = bool(overlap)
-    if zero1 and (gs.world > 1 or gs.force):
-        from ..dist import ShardedUpdate
-        rt.arena.zero1 = ShardedUpdate(rt.arena, group)
     return model
 
 
@@ -156,6 +164,9 @@ def clip_and_step(model, optim, clip=5.0):
     (src/vqa/vqacpv2.py:175-177), fused: one norm reduction, one update pass."""
     total = clip_grad_norm_(model.parameters(), clip)
     optim.step()
+    z = runtime_of(model).arena.zero1
+    if z is not None:
+        z.gather()  # sharded update: the other ranks' slices of the bf16 weights
     optim.zero_grad()
     return total
 
