@@ -446,9 +446,11 @@ int xggm_sqnorm_f32(const float* g, int64_t n, float* out, float* ws, xggm_strea
  * multiples of 4) in two launches, partials added in (range, slice) order: *out = (overwrite ? 0 : *out) + sum;
  * *norm (or NULL) = sqrt(*out) -- the total norm nn.utils.clip_grad_norm_ returns.  n == 0 only seeds / finishes.
  * square == 0 sums the VALUES instead of their squares: the gradient-norm slots of the weight-gradient GEMMs
- * (xggm_gemm_problem.sqsum) already hold sums of squares and are added to the running sum by a second call. */
+ * (xggm_gemm_problem.sqsum) already hold sums of squares and are added to the running sum by a second call.
+ * mul: the new *out is multiplied by it before the root (1; 1 / world^2 turns the norm of SUMMED data-parallel
+ * gradients into the norm of their average). */
 int xggm_sqnorm_multi_f32(const float* base, const int64_t* offsets, const int64_t* lengths, int n, float* out, float* norm,
-                          float* ws, int overwrite, int square, xggm_stream_t stream);
+                          float* ws, int overwrite, int square, float mul, xggm_stream_t stream);
 /* BertAdam.step (src/lxrt/optimization.py:159-193) fused with the clip scale
  * min(1, max_norm/(sqrt(*sqnorm)+1e-6)) and the bf16 shadow-weight write. */
 int xggm_bertadam_f32(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, const float* sqnorm,
@@ -482,6 +484,8 @@ typedef struct xggm_adam_args {
     const float* w8_qscale;
     float* w8_amax;
     int64_t elem0;
+    float g_scale; /* > 0: every gradient is multiplied by it (1 / world: the exchange SUMS over the data-parallel ranks
+                      and the average is taken here); <= 0 reads as 1 */
 } xggm_adam_args;
 int xggm_bertadam_ex(const xggm_adam_args* args, xggm_stream_t stream);
 /* *out += sum g^2 of a flat bf16 range (the wire arena), same fixed summation order as xggm_sqnorm_f32 */
@@ -495,6 +499,8 @@ int xggm_sched_step_multi(int64_t* steps, float* lr_scale, const int* index, con
 
 /* out = in with the diagonal of every [N, N] matrix zeroed: adj_true.triu(1) + adj_true.tril(-1), src/vqa/vqacpv2.py:188 */
 int xggm_zero_diag_f32(const float* in, float* out, int B, int N, xggm_stream_t stream);
+/* out[i] = (1 - mask[i]) * -10000: additive attention mask from the int64 token mask, src/lxrt/modeling.py:919-928 */
+int xggm_additive_mask(const int64_t* mask, float* out, int64_t n, xggm_stream_t stream);
 /* *out = *a + *b + *c + *d (NULL terms skipped): the sum of the loss terms of a pass, src/vqa/vqacpv2.py:220-221 */
 int xggm_add_scalars_f32(const float* a, const float* b, const float* c, const float* d, float* out, xggm_stream_t stream);
 /* zero up to 16 element ranges [offset[i], offset[i] + length[i]) of one fp32 buffer in ONE launch: the

@@ -178,8 +178,8 @@ def _sharded_worker(rank, world, port, q):
         a.m = torch.full((n,), 10.0 * (rank + 1))
         a.v = torch.full((n,), 100.0 * (rank + 1))
         z = ShardedUpdate(a)
-        ok = z.world == world and z.rank == rank
-        mean = (base * (sum(range(1, world + 1)) / world))
+        ok = z.world == world and z.rank == rank and a.grad_scale == 1.0 / world
+        mean = base * sum(range(1, world + 1))  # the exchange SUMS; the consumers apply arena.grad_scale = 1 / world
         # two "stages": part of g0's matrices first, the rest + everything else second
         st0, st1 = [(0, 512)], [(512, 1200), (1280, 1800)]
         h0 = z.begin(st0)
@@ -221,10 +221,13 @@ def _sharded_worker(rank, world, port, q):
         ok &= z.runs == []
         # the plain in-place exchange (no sharding) on the same arena
         a.wire = (base * (rank + 1)).to(torch.bfloat16)
+        a.wire[1200:1280] = 0  # the alignment gap between two groups: never written, zeros on every rank
+        a.wire[1800:] = 7.0
         g = GradSync(a.grads, wire_dtype=torch.bfloat16, arena=a)
-        g.sync([(0, 1200), (1280, 1800)])
+        g.sync([(0, 1200), (1280, 1800)])  # one collective: the two ranges merge across the gap
+        ok &= g.merged([(0, 1200), (1280, 1800), (4000, 4100)]) == [(0, 1800), (4000, 4100)]
         ok &= bool(((a.wire[:1200].float() - mean[:1200]).abs() <= 8e-3 * mean[:1200].abs() + 1e-6).all())
-        ok &= torch.equal(a.wire[1200:1280], (base * (rank + 1)).to(torch.bfloat16)[1200:1280])
+        ok &= bool((a.wire[1200:1280] == 0).all()) and bool((a.wire[1800:] == 7.0).all())
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

@@ -29,9 +29,43 @@ def _align(n, a=ALIGN):
     return (n + a - 1) // a * a
 
 
+def region_of(name, pair_cut, x_mid):
+    """forward region of an encoder parameter, as the data-parallel backward stages see it (LXRTEncoder.forward cuts
+    the autograd graph between them): 0 = embeddings and visn_fc; 1 = layer pairs below ``pair_cut``; 2 = the other
+    single-modality layers; 3 = cross layers below ``x_mid``; 4 = the remaining cross layers and the pooler."""
+    import re
+    m = re.search(r"\.x_layers\.(\d+)\.", name)
+    if m:
+        return 4 if (x_mid is not None and int(m.group(1)) >= x_mid) else 3
+    m = re.search(r"\.(?:layer|r_layers)\.(\d+)\.", name)
+    if m:
+        return 2 if (pair_cut is None or int(m.group(1)) >= pair_cut) else 1
+    if ".pooler." in name:
+        return 4
+    return 0
+
+
+def encoder_cuts(names):
+    """(pair_cut, x_mid) of the encoder whose parameter names are given: the rule of LXRTEncoder.forward"""
+    import re
+
+    def count(tag):
+        idx = [int(m.group(1)) for n in names for m in [re.search(r"\.%s\.(\d+)\." % tag, n)] if m]
+        return max(idx) + 1 if idx else 0
+
+    n_pair = min(count("layer"), count("r_layers"))
+    nx = count("x_layers")
+    return (2 if n_pair >= 4 else None), (nx - 2 if nx >= 4 else None)
+
+
 def layout(named, group_of, model=None):
     """offsets of every parameter in the flat buffers.  ``named``: [(name, p)] with p.dim() / p.numel() / p.shape.
-    -> (group order, {group: Group}, {name: (offset, numel, group, atomic)}, total elements)"""
+    -> (group order, {group: Group}, {name: (offset, numel, group, atomic)}, total elements).
+    Inside a group the matrices are laid out by DESCENDING backward-stage region (stable within a region), the
+    vectors behind them: the gradients that become final together in a staged data-parallel backward are then ONE
+    contiguous run of the buffer (one collective per stage instead of one per scattered piece), and the region that
+    is final last sits next to the vector region, which is final last too."""
+    pair_cut, x_mid = encoder_cuts([n for n, _ in named])
     order = []
     for n, p in named:
         g = group_of(n, model)
@@ -43,10 +77,11 @@ def layout(named, group_of, model=None):
         G = groups[gname]
         G.start = off = _align(off, ALIGN_MAT)
         members = [(n, p) for n, p in named if group_of(n, model) == gname]
-        for n, p in members:
-            if not is_atomic(n, p):
-                info[n] = (off, p.numel(), gname, False)
-                off = _align(off + p.numel(), ALIGN_MAT)
+        mats = [(n, p) for n, p in members if not is_atomic(n, p)]
+        mats.sort(key=lambda t: -region_of(t[0], pair_cut, x_mid))  # stable: modules keep their parameter order
+        for n, p in mats:
+            info[n] = (off, p.numel(), gname, False)
+            off = _align(off + p.numel(), ALIGN_MAT)
         G.vec_start = off
         for n, p in members:
             if is_atomic(n, p):
@@ -100,6 +135,7 @@ class ParamArena:
         # LayerNorm, embedding tables: accumulated with fp32 atomics) stay in ``grads`` and are cast into their
         # ranges of the wire when the exchange starts.  ``p.grad`` of a matrix is then only a presence marker.
         self.wire = None
+        self.grad_scale = 1.0  # 1 / world when the wire holds SUMS over the data-parallel ranks
         # device scalars: per-group step counter + schedule value, global sum of squares
         self.steps = torch.zeros(len(order), device=dev, dtype=torch.int64)
         self.lr_scale = torch.ones(len(order), device=dev, dtype=torch.float32)

@@ -117,6 +117,11 @@ __global__ __launch_bounds__(NT) void zero_diag_kernel(const float* __restrict__
         out[i] = (e / N == e % N) ? 0.f : in[i];
     }
 }
+// (1 - mask) * -10000: the additive attention mask of LXRTModel.forward (src/lxrt/modeling.py:919-928)
+__global__ __launch_bounds__(NT) void additive_mask_kernel(const int64_t* __restrict__ m, float* out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT)
+        out[i] = (1.0f - (float)m[i]) * -10000.0f;
+}
 __global__ void add_scalars_kernel(const float* a, const float* b, const float* c, const float* d, float* out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *out = (a ? *a : 0.f) + (b ? *b : 0.f) + (c ? *c : 0.f) + (d ? *d : 0.f);
 }
@@ -127,6 +132,12 @@ extern "C" int xggm_zero_diag_f32(const float* in, float* out, int B, int N, hip
     const int64_t total = (int64_t)B * N * N;
     hipLaunchKernelGGL(zero_diag_kernel, dim3(grid1d(total)), dim3(NT), 0, st, in, out, total, N);
     return xggm_check_launch("xggm_zero_diag_f32");
+}
+
+extern "C" int xggm_additive_mask(const int64_t* mask, float* out, int64_t n, hipStream_t st) {
+    XGGM_REQUIRE(mask && out && n > 0, "xggm_additive_mask: bad arguments");
+    hipLaunchKernelGGL(additive_mask_kernel, dim3(grid1d(n)), dim3(NT), 0, st, mask, out, n);
+    return xggm_check_launch("xggm_additive_mask");
 }
 
 extern "C" int xggm_add_scalars_f32(const float* a, const float* b, const float* c, const float* d, float* out, hipStream_t st) {

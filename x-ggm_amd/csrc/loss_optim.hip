@@ -229,12 +229,12 @@ __global__ __launch_bounds__(NT) void sqnorm_multi_kernel(const float* __restric
     if (threadIdx.x == 0) ws[blockIdx.x] = acc;
 }
 __global__ __launch_bounds__(NT) void sqnorm_multi_finish_kernel(const float* __restrict__ ws, int nblk, float* out, float* norm,
-                                                                 int overwrite) {
+                                                                 int overwrite, float mul) {
     float t = 0.f;
     for (int b = threadIdx.x; b < nblk; b += NT) t += ws[b];
     t = block_sum(t);
     if (threadIdx.x == 0) {
-        const float s = (overwrite ? 0.f : *out) + t;
+        const float s = ((overwrite ? 0.f : *out) + t) * mul;
         *out = s;
         if (norm) *norm = sqrtf(s);
     }
@@ -281,6 +281,7 @@ struct AdamArgs {
     const float* w8_qscale;
     float* w8_amax;
     int64_t elem0;              // arena offset of p[0] (multiple of 256 with shadow8)
+    float g_scale;              // gradients are SUMS over data-parallel ranks: 1 / world (1 otherwise)
 };
 
 // One float4 of each of p, g, m, v per step; UNR independent float4 quadruples per thread and
@@ -293,6 +294,7 @@ __global__ __launch_bounds__(NT) void bertadam_kernel(AdamArgs a) {
         const float total = sqrtf(*a.sqnorm);
         coef = fminf(a.max_norm / (total + 1e-6f), 1.f);  // torch.nn.utils.clip_grad_norm_
     }
+    coef *= a.g_scale;
     const float lr = (a.lr_dev ? *a.lr_dev : a.lr) * (a.lr_scale ? *a.lr_scale : 1.f);
     const int64_t n4 = a.n >> 2;
     typedef float __attribute__((ext_vector_type(4))) f4;
@@ -560,12 +562,12 @@ extern "C" int xggm_bertadam_f32(float* p, const float* g, float* m, float* v, v
                  "xggm_bertadam_f32: pointers must be 16-byte aligned");
     XGGM_REQUIRE(!shadow_bf16 || reinterpret_cast<uintptr_t>(shadow_bf16) % 8 == 0, "xggm_bertadam_f32: shadow misaligned");
     AdamArgs a{p, g, m, v, (bf16*)shadow_bf16, n, sqnorm, max_norm, lr, nullptr, lr_scale, b1, b2, eps, weight_decay,
-               nullptr, nullptr, nullptr, nullptr, 0};
+               nullptr, nullptr, nullptr, nullptr, 0, 1.f};
     return launch_adam(a, false, st);
 }
 
 extern "C" int xggm_sqnorm_multi_f32(const float* base, const int64_t* offsets, const int64_t* lengths, int n, float* out,
-                                     float* norm, float* ws, int overwrite, int square, hipStream_t st) {
+                                     float* norm, float* ws, int overwrite, int square, float mul, hipStream_t st) {
     XGGM_REQUIRE(base && offsets && lengths && out && ws && n >= 0 && n <= MAX_SPANS,
                  "xggm_sqnorm_multi_f32: bad arguments (n = %d, at most %d ranges)", n, MAX_SPANS);
     XGGM_REQUIRE(reinterpret_cast<uintptr_t>(base) % 16 == 0, "xggm_sqnorm_multi_f32: base must be 16-byte aligned");
@@ -592,7 +594,7 @@ extern "C" int xggm_sqnorm_multi_f32(const float* base, const int64_t* offsets, 
         if (square) hipLaunchKernelGGL(sqnorm_multi_kernel<true>, dim3(nblk), dim3(NT), 0, st, base, sp, ws);
         else hipLaunchKernelGGL(sqnorm_multi_kernel<false>, dim3(nblk), dim3(NT), 0, st, base, sp, ws);
     }
-    hipLaunchKernelGGL(sqnorm_multi_finish_kernel, dim3(1), dim3(NT), 0, st, ws, nblk, out, norm, overwrite);
+    hipLaunchKernelGGL(sqnorm_multi_finish_kernel, dim3(1), dim3(NT), 0, st, ws, nblk, out, norm, overwrite, mul);
     return xggm_check_launch("xggm_sqnorm_multi_f32");
 }
 
@@ -607,7 +609,8 @@ extern "C" int xggm_bertadam_ex(const xggm_adam_args* x, hipStream_t st) {
                  "xggm_bertadam_ex: the e4m3 copy needs the chunk table, the scale table and a range that starts on a "
                  "256-element chunk of the arena");
     AdamArgs a{x->p, x->g, x->m, x->v, (bf16*)x->shadow_bf16, x->n, x->sqnorm, x->max_norm, x->lr, x->lr_dev, x->lr_scale,
-               x->b1, x->b2, x->eps, x->weight_decay, (unsigned char*)x->shadow8, x->w8_id, x->w8_qscale, x->w8_amax, x->elem0};
+               x->b1, x->b2, x->eps, x->weight_decay, (unsigned char*)x->shadow8, x->w8_id, x->w8_qscale, x->w8_amax, x->elem0,
+               x->g_scale > 0.f ? x->g_scale : 1.f};
     return launch_adam(a, x->g_bf16 != 0, st);
 }
 

@@ -43,6 +43,8 @@ class GradSync:
         self.g = flat_grads
         self.arena = arena if (arena is not None and getattr(arena, "wire", None) is not None) else None
         self.group = group
+        if self.arena is not None:
+            self.arena.grad_scale = 1.0 / (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # XGGM_DP_FORCE=1: issue the collectives even in a one-rank group (rehearses the RCCL stream / graph
         # interplay on a single GPU: the reduction itself is then the identity)
@@ -74,22 +76,30 @@ class GradSync:
             else:
                 a.wire[s:e].copy_(a.grads[s:e])
 
+    @staticmethod
+    def merged(ranges):
+        """touching ranges as one -- also across the < 256-element alignment gap between two arena groups, which no
+        kernel ever writes (zeros on every rank): fewer, larger collectives"""
+        out = []
+        for s, e in sorted(r for r in ranges if r[1] > r[0]):
+            if out and 0 <= s - out[-1][1] < 256:
+                out[-1] = (out[-1][0], e)
+            else:
+                out.append((s, e))
+        return out
+
     def _begin_inplace(self, ranges):
+        # SUM, not AVG: the norm pass and the update take the average (``arena.grad_scale`` = 1 / world) on the way
+        # in.  Same bytes on the links and no pre-multiply kernel (on a one-rank group RCCL then launches nothing).
         self.cast_vectors(ranges)
         w = self.arena.wire
-        use_avg = self.backend == "nccl"
-        op = dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM
-        rs = [(s, e) for s, e in ranges if e > s]
-        works = [dist.all_reduce(w[s:e], op=op, group=self.group, async_op=True) for s, e in rs]
-        return ("inplace", rs, works, use_avg)
+        rs = self.merged(ranges)
+        works = [dist.all_reduce(w[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for s, e in rs]
+        return ("inplace", rs, works, True)
 
     def _finish_inplace(self, handle):
-        _, rs, works, use_avg = handle
-        for wk in works:
+        for wk in handle[2]:
             wk.wait()
-        if not use_avg:
-            for s, e in rs:
-                self.arena.wire[s:e].div_(self.world)
 
     def sync(self, ranges):
         """average ``flat_grads[s:e]`` over ranks for every (s, e) in ``ranges``."""
@@ -244,7 +254,7 @@ class ShardedUpdate(GradSync):
         self.cast_vectors(ranges)
         w = self.arena.wire
         nccl = self.backend == "nccl"
-        op = dist.ReduceOp.AVG if nccl else dist.ReduceOp.SUM
+        op = dist.ReduceOp.SUM  # the average is taken by the norm pass and the update (arena.grad_scale)
         mats, vecs = self.split(ranges)
         works = []
         for run in mats:
@@ -344,16 +354,10 @@ def stage_ranges(arena, ranges, layout, n_stages):
     if len(borders) + 1 != n_stages:  # the forward recorded other cuts than the layout predicts: no split
         return [[] for _ in range(last)] + [list(ranges)]
 
+    from .arena import region_of
+
     def region(name):
-        m = re.search(r"\.x_layers\.(\d+)\.", name)
-        if m:
-            return 4 if (x_mid is not None and int(m.group(1)) >= x_mid) else 3
-        m = re.search(r"\.(?:layer|r_layers)\.(\d+)\.", name)
-        if m:
-            return 2 if (pair_cut is None or int(m.group(1)) >= pair_cut) else 1
-        if ".pooler." in name:
-            return 4
-        return 0  # embeddings, visn_fc
+        return region_of(name, pair_cut, x_mid)
 
     def stage_of_region(r):
         return sum(1 for b in borders if b > r)  # cuts after the region = stages that run before it is final

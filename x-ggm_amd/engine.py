@@ -22,6 +22,22 @@ from .vqa.vqacpv2 import (forward_backward_plain, forward_backward_ggm, clip_and
                           BCEWithLogitsLoss)
 
 
+class _quiet_gc:
+    """no garbage collection while a stream is being captured: a finalizer that runs in the middle of a capture
+    (on whatever thread allocates next, the autograd thread included) may free pinned host memory or destroy
+    events -- the caching host allocator then queries an event, which HIP refuses during a global-mode capture,
+    and the process aborts.  Collect first, then keep the collector off until the capture has ended."""
+
+    def __enter__(self):
+        gc.collect()
+        self.was = gc.isenabled()
+        gc.disable()
+
+    def __exit__(self, *a):
+        if self.was:
+            gc.enable()
+
+
 class CapturedTrainer:
     def __init__(self, model, optim, batch, sigma=1.0, order="vqa", clip=5.0, use_graph=True, warmup_iters=2):
         """``batch``: dict of DEVICE tensors feats, boxes, input_ids, input_mask, segment_ids,
@@ -134,6 +150,11 @@ class CapturedTrainer:
             import torch.distributed as dist
             dist.barrier()
             torch.cuda.synchronize()
+        with _quiet_gc():
+            self._capture_kinds()
+        torch.cuda.synchronize()
+
+    def _capture_kinds(self):
         for kind in ("plain", "rel", "node"):
             # one memory pool per pass kind (shared by the graphs of that kind only): with a pool shared across kinds
             # the outputs of one kind (loss, logits, norm) can land where an earlier-captured kind keeps its
@@ -293,7 +314,7 @@ class CapturedPredictor:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with _quiet_gc(), torch.cuda.graph(self.graph):
                 self.logit, self.label = self._forward()
             model.train(was_training)
 

@@ -467,7 +467,11 @@ class LXRTModel(BertPreTrainedModel):
         if token_type_ids is None:
             token_type_ids = torch.zeros_like(input_ids)
         # additive masks (1 - m) * -10000, [B,1,1,S] as in the reference (:919-939)
-        extended_attention_mask = (1.0 - attention_mask.unsqueeze(1).unsqueeze(2).to(torch.float32)) * -10000.0
+        if attention_mask.is_cuda and attention_mask.dtype == torch.int64 and attention_mask.is_contiguous():
+            # one kernel for the reference's cast / subtract / multiply
+            extended_attention_mask = ops.additive_mask(attention_mask).unsqueeze(1).unsqueeze(2)
+        else:
+            extended_attention_mask = (1.0 - attention_mask.unsqueeze(1).unsqueeze(2).to(torch.float32)) * -10000.0
         if visual_attention_mask is not None:
             extended_visual_attention_mask = (1.0 - visual_attention_mask.unsqueeze(1).unsqueeze(2).to(
                 torch.float32)) * -10000.0

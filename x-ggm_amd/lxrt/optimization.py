@@ -115,7 +115,8 @@ def clip_norm_finish(arena, max_norm):
         for a, b in z.norm_spans(_active_ranges(arena))[1]:
             ops.sqnorm_bf16(arena.wire[a:b], arena.sqnorm)
     total = torch.empty(1, device=arena.grads.device, dtype=torch.float32)
-    ops.sqnorm_multi(arena.grads, [], arena.sqnorm, total, overwrite=False)
+    # the wire holds sums over the ranks: |mean|^2 = |sum|^2 / world^2
+    ops.sqnorm_multi(arena.grads, [], arena.sqnorm, total, overwrite=False, mul=arena.grad_scale ** 2)
     arena.pending_clip = float(max_norm)
     return total.view(())
 
@@ -294,6 +295,7 @@ class BertAdam(Optimizer):
                                "(the learning rates are uploaded to the device outside of captures)")
         f8 = arena.fp8
         gbuf = arena.wire if arena.wire is not None else arena.grads  # bf16 wire arena: the update reads it directly
+        gscale = arena.grad_scale if arena.wire is not None else 1.0     # ... and holds sums over the ranks
         z = arena.zero1
         if z is not None and f8 is not None:
             raise NotImplementedError("sharded update + fp8 forward: the e4m3 weight copies and their scale table "
@@ -308,7 +310,7 @@ class BertAdam(Optimizer):
                         sl = slice(a, b)
                         ops.bertadam_ex(arena.params[sl], gbuf[sl], arena.m[sl], arena.v[sl], arena.shadow[sl], sq, max_norm,
                                         pg['lr'], scale_t, pg['b1'], pg['b2'], pg['e'], pg['weight_decay'],
-                                        lr_dev=arena.lr_table[gi:gi + 1], elem0=a)
+                                        lr_dev=arena.lr_table[gi:gi + 1], elem0=a, g_scale=gscale)
                 continue
             sl = slice(G.start, G.end)
             w8 = f8.adam_w8(G.name) if f8 is not None else None
@@ -320,6 +322,6 @@ class BertAdam(Optimizer):
             ops.bertadam_ex(arena.params[sl], gbuf[sl], arena.m[sl], arena.v[sl],
                             None if arena.shadow is None else arena.shadow[sl], sq, max_norm, pg['lr'], scale_t,
                             pg['b1'], pg['b2'], pg['e'], pg['weight_decay'], lr_dev=arena.lr_table[gi:gi + 1], w8=w8,
-                            elem0=G.start)
+                            elem0=G.start, g_scale=gscale)
         arena.pending_clip = None
         return loss

@@ -844,7 +844,7 @@ def sqnorm(g, out):
     call("xggm_sqnorm_f32", ptr(g), g.numel(), ptr(out), ptr(ws), stream())
 
 
-def sqnorm_multi(buf, spans, out, norm=None, overwrite=True, square=True):
+def sqnorm_multi(buf, spans, out, norm=None, overwrite=True, square=True, mul=1.0):
     """out (1 fp32) = [out +] sum over the (start, end) element ranges ``spans`` of buf^2 (``square`` False: of buf),
     fixed summation order; ``norm`` (1 fp32 or None) = sqrt(out).  Any number of ranges (16 per launch pair; none:
     only seeds / finishes)."""
@@ -861,7 +861,15 @@ def sqnorm_multi(buf, spans, out, norm=None, overwrite=True, square=True):
         lens = (_ct.c_int64 * max(len(ch), 1))(*[e - s for s, e in ch])
         last = ci == len(chunks) - 1
         call("xggm_sqnorm_multi_f32", ptr(buf), _ct.cast(offs, _ct.c_void_p), _ct.cast(lens, _ct.c_void_p), len(ch), ptr(out),
-             ptr(norm) if last else None, ptr(ws), int(overwrite and ci == 0), int(square), stream())
+             ptr(norm) if last else None, ptr(ws), int(overwrite and ci == 0), int(square), float(mul) if last else 1.0, stream())
+
+
+def additive_mask(mask):
+    """(1 - mask) * -10000 as fp32, for an int64 token mask [B, S]"""
+    _c(mask, torch.int64, "attention mask")
+    out = torch.empty(mask.shape, device=mask.device, dtype=F32)
+    call("xggm_additive_mask", ptr(mask), ptr(out), mask.numel(), stream())
+    return out
 
 
 def zero_diag(adj):
@@ -902,10 +910,10 @@ class AdamArgs(_ct.Structure):
                 ("lr", _ct.c_float), ("lr_dev", _ct.c_void_p), ("lr_scale", _ct.c_void_p),
                 ("b1", _ct.c_float), ("b2", _ct.c_float), ("eps", _ct.c_float), ("weight_decay", _ct.c_float),
                 ("g_bf16", _ct.c_int), ("shadow8", _ct.c_void_p), ("w8_id", _ct.c_void_p), ("w8_qscale", _ct.c_void_p),
-                ("w8_amax", _ct.c_void_p), ("elem0", _ct.c_int64)]
+                ("w8_amax", _ct.c_void_p), ("elem0", _ct.c_int64), ("g_scale", _ct.c_float)]
 
 
-def bertadam_ex(p, g, m, v, shadow, sqn, max_norm, lr, lr_scale, b1, b2, eps, wd, lr_dev=None, w8=None, elem0=0):
+def bertadam_ex(p, g, m, v, shadow, sqn, max_norm, lr, lr_scale, b1, b2, eps, wd, lr_dev=None, w8=None, elem0=0, g_scale=1.0):
     """the update with device-resident lr (``lr_dev``), bf16 gradients (``g.dtype``) and/or the e4m3 weight copy
     ``w8`` = (shadow8 slice, id table, qscale table, amax table); ``elem0``: arena offset of p[0]."""
     for t in (p, m, v):
@@ -915,7 +923,7 @@ def bertadam_ex(p, g, m, v, shadow, sqn, max_norm, lr, lr_scale, b1, b2, eps, wd
     assert g.numel() == p.numel() and g.dtype in (F32, BF16)
     a = AdamArgs(ptr(p), ptr(g), ptr(m), ptr(v), ptr(shadow), p.numel(), ptr(sqn), float(max_norm), float(lr), ptr(lr_dev),
                  ptr(lr_scale), float(b1), float(b2), float(eps), float(wd), int(g.dtype == BF16), None, None, None, None,
-                 int(elem0))
+                 int(elem0), float(g_scale))
     if w8 is not None:
         s8, ids, q, amax = w8
         assert s8.numel() == p.numel() and s8.element_size() == 1 and ids.dtype == torch.int16
