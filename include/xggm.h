@@ -147,7 +147,7 @@ int xggm_fp8_scale_update(float* amax, float* hist, float* qscale, float* dscale
  * step's scale without another pass over x. */
 int xggm_quantize_fp8e4m3_f32(const void* x, void* y, int64_t n, const float* qscale, float* amax, xggm_stream_t stream);
 int xggm_quantize_fp8e4m3_bf16(const void* x, void* y, int64_t n, const float* qscale, float* amax, xggm_stream_t stream);
-/* HOST: tile of grouped launches (0 heuristic, 1: 64x64, 2: 128x64, 3: 128x128) */
+/* HOST: tile of grouped launches (0 heuristic, 1: 64x64, 2: 128x64, 3: 128x128, 4: 128x128 on 8 waves) */
 int xggm_gemm_set_group_tile(int v);
 /* HOST: 1 = run bf16 GEMMs on the generic 64x64 kernel, 0 = tuned kernels (default); A/B tests */
 int xggm_gemm_set_generic(int on);

@@ -121,7 +121,7 @@ def test_linear_backward_padded_odd_width(ops, M, N, K):
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("group_tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("group_tile", [0, 1, 2, 3, 4])
 def test_grouped_gemm(ops, dt, group_tile):
     """forward (two modalities) + dgrad + wgrad in ONE launch == the four products done alone"""
     from xggm_amd import _lib
@@ -480,6 +480,24 @@ def test_aggregate(ops, dt, N):
     acc = torch.zeros(1, device=DEV)
     ops.agg_dot(adj.to(DEV), x, dh, acc)
     assert abs(float(acc) - float(((a @ xr) * dhr).sum())) < 1e-3 * float(((a @ xr) * dhr).abs().sum())
+    # a ragged last column block, a batch that fills whole XCD groups (the bf16 kernel deals samples to XCDs in eights),
+    # accumulation into an existing output
+    for B2, H2 in ((16, 96), (9, 200)):
+        x2, x2r = rnd((B2, N, H2), dt, 5)
+        adj2 = torch.randn(B2, N, N, generator=torch.Generator().manual_seed(6))
+        got = ops.aggregate(adj2.to(DEV), x2)
+        assert rel_err(got, adj2.double() @ x2r) < tol(dt)
+        base, baser = rnd((B2, N, H2), dt, 7)
+        ops.aggregate(adj2.to(DEV), x2, mode=ops.AGG_TRANSPOSE, out=base)
+        assert rel_err(base, baser + adj2.double().transpose(1, 2) @ x2r) < tol(dt)
+    if dt == torch.bfloat16:
+        # the adjacency is NOT rounded to bf16 (hi + lo split): a matrix whose entries need > 8 mantissa bits
+        adj3 = (1.0 + torch.arange(N * N, dtype=torch.float32).reshape(1, N, N) / 4096.0).repeat(2, 1, 1)
+        x3, x3r = rnd((2, N, H), dt, 8)
+        got = ops.aggregate(adj3.to(DEV), x3).double().cpu()
+        want = adj3.double() @ x3r
+        rounded = adj3.to(torch.bfloat16).double() @ x3r
+        assert rel_err(got, want) < 4e-3 and rel_err(got, want) < 0.5 * rel_err(rounded, want) + 3e-3
 
 
 @pytest.mark.parametrize("N", [36, 64, 7])
@@ -772,7 +790,7 @@ def test_layernorm_forward_sums_split_k_partials(ops):
         ops.p_fwd_splitk(x, w, 5)
 
 
-@pytest.mark.parametrize("group_tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("group_tile", [0, 1, 2, 3, 4])
 def test_wgrad_norm_slots(ops, group_tile):
     """xggm_gemm_problem.sqsum: every 64 x 64 block of the stored fp32 weight gradient leaves its sum of squares in
     its slot -- for every tile size of the grouped kernels (a 128-wide tile writes 2 or 4 slots), with ``accumulate``

@@ -79,15 +79,21 @@ def check_sharded(rank):
             print("sharded update overlap=%s graphs=%s: bf16 weights identical on both ranks: %s" % (overlap, use_graph, same),
                   flush=True)
         assert same
-    ref = run(True, rank, layers=(5, 4, 4))
-    got = run(True, rank, layers=(5, 4, 4), zero1=True)
-    other = [torch.empty_like(got) for _ in range(2)]
-    dist.all_gather(other, got)
-    assert torch.equal(other[0], other[1]), "fp32 masters differ after gather_state"
-    d = float((got - ref).double().norm() / ref.double().norm())
-    if rank == 0:
-        print("sharded vs replicated update: relative parameter difference %.2e" % d, flush=True)
-    assert d < 1e-4
+    # One iteration: the two runs differ only in the order the clip norm is summed in (an ulp of the coefficient).
+    # Three iterations: that ulp has been through bf16 roundings and BertAdam's sign-like first steps (m / sqrt(v) is
+    # +-3.16 whatever |g| is), so single elements move by ~lr; the bound only says "same training", as it would for
+    # any two orders of a floating-point sum.
+    for iters, bound in ((("rel",), 1e-5), (("rel", "node", "rel"), 5e-3)):
+        ref = run(True, rank, layers=(5, 4, 4), iters=iters)
+        got = run(True, rank, layers=(5, 4, 4), zero1=True, iters=iters)
+        other = [torch.empty_like(got) for _ in range(2)]
+        dist.all_gather(other, got)
+        assert torch.equal(other[0], other[1]), "fp32 masters differ after gather_state"
+        d = float((got - ref).double().norm() / ref.double().norm())
+        if rank == 0:
+            print("sharded vs replicated update, %d iteration(s): relative parameter difference %.2e" % (len(iters), d),
+                  flush=True)
+        assert d < bound
 
 
 def check(rank, layers):

@@ -48,6 +48,9 @@ struct MSeg {
 struct MGroup {
     MSeg s[2];
     int start1;
+#ifdef XGGM_STAMP
+    long long* stamp;
+#endif
 };
 
 __device__ __forceinline__ int rup(int x, int m) { return (x + m - 1) / m * m; }
@@ -93,6 +96,17 @@ __device__ __forceinline__ bf16x8_t frag_tr(const bf16* lds, int ld, int k0, int
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 
+#ifdef XGGM_STAMP
+// instrumented build (make stamp, tools/attn_stamps.py): 16 cycle-counter slots per workgroup
+long long* g_attn_stamp = nullptr;
+#define ASTAMP(p, slot)                                                                                      \
+    do {                                                                                                     \
+        if ((p) && threadIdx.x == 0) (p)[(int64_t)blockIdx.x * 16 + (slot)] = __builtin_readcyclecounter();  \
+    } while (0)
+#else
+#define ASTAMP(p, slot)
+#endif
+
 // S = scale * Q K^T + mask  ->  Sf (fp32, row stride lds_s), tiles shared round-robin by the waves
 __device__ __forceinline__ void scores(const MArgs& a, const bf16* Qs, const bf16* Ks, float* Sf, int lds_s, int b, int tid) {
     const int lane = tid & 63, wid = tid >> 6, fr = lane & 15, fq = lane >> 4;
@@ -129,6 +143,17 @@ struct Drop {
     __device__ __forceinline__ float scale(int i, int j, int Sk) const {
         return p > 0.f ? dropout_scale(p, ik, seed, off, sid, base + (uint64_t)i * Sk + j) : 1.f;
     }
+    // keep-scales of (i, j0 .. j0 + 3): one Philox call when the four element indices share it
+    __device__ __forceinline__ void scale4(int i, int j0, int Sk, float (&s)[4]) const {
+        if (p <= 0.f) {
+            s[0] = s[1] = s[2] = s[3] = 1.f;
+        } else if ((Sk & 3) == 0) {
+            dropout_scale4(p, ik, seed, off, sid, base + (uint64_t)i * Sk + j0, s);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] = dropout_scale(p, ik, seed, off, sid, base + (uint64_t)i * Sk + j0 + e);
+        }
+    }
 };
 
 // row softmax of Sf in place (fp32).  wave w owns rows w, w+4, ...
@@ -142,6 +167,37 @@ __device__ __forceinline__ void softmax_rows(const MArgs& a, float* Sf, int lds_
         if (lane < a.Sk) Sf[i * lds_s + lane] = e / sum;
     }
 }
+
+// ---- row phase: EIGHT lanes per score row, no wave-wide shuffles -------------------------------------------------
+// The first version gave every row to a whole wave (wave_max / wave_sum = 12 ds_bpermute round trips per row, then a
+// second pass over all elements for dropout + bf16): in-kernel stamps put 66 % of the forward and 58 % of the
+// backward there.  Here lane 8 r + part owns the column groups part and part + 8 (four consecutive columns each, 8
+// values, kept in registers) of row r: maximum and sum are finished with three DPP moves (quad permutes, half-row mirror), one
+// Philox call serves the four dropout decisions of a group (their element indices share idx >> 2 when Sk % 4 == 0),
+// and the probabilities leave as 8-byte bf16 stores.  Rows / columns outside the problem are written as zeros.
+__device__ __forceinline__ float quad_xor1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_xor2(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+}
+// lanes i <-> 7 - i of every group of eight (DPP row_half_mirror): after the two quad steps each quad holds its own
+// result, so the mirrored lane supplies the other quad's
+__device__ __forceinline__ float half_mirror(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_max(float v) {  // over the ROW_L = 8 lanes of a row
+    v = fmaxf(v, quad_xor1(v));
+    v = fmaxf(v, quad_xor2(v));
+    return fmaxf(v, half_mirror(v));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+    v += quad_xor1(v);
+    v += quad_xor2(v);
+    return v + half_mirror(v);
+}
+constexpr int ROW_L = 8;  // lanes per score row
+constexpr int ROW_G = 2;  // column groups per lane: 8 lanes x 2 groups x 4 columns = 64 keys
 
 __global__ __launch_bounds__(NT) void attn_fwd_mfma_kernel(MGroup G) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -160,6 +216,10 @@ __global__ __launch_bounds__(NT) void attn_fwd_mfma_kernel(MGroup G) {
     bf16* Vs = Ks + RK * LDT;
     bf16* Pb = Vs + RK * LDT;                                    // [RQ][LDP] bf16 probabilities (dropout folded in)
     float* Sf = reinterpret_cast<float*>(Pb + RQ * LDP);         // [RQ][lds_s]
+#ifdef XGGM_STAMP
+    long long* stp = G.stamp;
+#endif
+    ASTAMP(stp, 0);
     {
         const TileRegs tq_ = tile_fetch(a.q + (int64_t)b * Sq * a.q_rs + h * D, a.q_rs, Sq, tid);
         const TileRegs tk_ = tile_fetch(a.k + (int64_t)b * Sk * a.k_rs + h * D, a.k_rs, Sk, tid);
@@ -169,20 +229,55 @@ __global__ __launch_bounds__(NT) void attn_fwd_mfma_kernel(MGroup G) {
         tile_commit(Vs, tv_, Sk, RK, tid);
     }
     __syncthreads();
+    ASTAMP(stp, 1);
     scores(a, Qs, Ks, Sf, lds_s, b, tid);
     __syncthreads();
-    softmax_rows(a, Sf, lds_s, tid);
-    __syncthreads();
+    ASTAMP(stp, 2);
+    ASTAMP(stp, 3);
     {
+        // softmax + dropout + bf16 operand copy of the probabilities, eight lanes per row (see above)
         const Drop dr(a, b, h);
-        for (int e = tid; e < RQ * RK; e += NT) {  // bf16 operand copy, zero outside [Sq) x [Sk)
-            const int i = e / RK, j = e % RK;
-            float v = 0.f;
-            if (i < Sq && j < Sk) v = Sf[i * lds_s + j] * dr.scale(i, j, Sk);
-            Pb[i * LDP + j] = __float2bfloat16(v);
+        const int row = tid / ROW_L, part = tid % ROW_L, NG = RK >> 2;
+        if (row < RQ) {
+            float v[ROW_G][4];
+            float m = -INFINITY;
+#pragma unroll
+            for (int gi = 0; gi < ROW_G; ++gi) {
+                const int j0 = 4 * (part + ROW_L * gi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool in = row < Sq && j0 + e < Sk;
+                    v[gi][e] = in ? Sf[row * lds_s + j0 + e] : -INFINITY;
+                    m = fmaxf(m, v[gi][e]);
+                }
+            }
+            m = quad_max(m);
+            float sum = 0.f;
+#pragma unroll
+            for (int gi = 0; gi < ROW_G; ++gi)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[gi][e] = v[gi][e] > -INFINITY ? __expf(v[gi][e] - m) : 0.f;
+                    sum += v[gi][e];
+                }
+            sum = quad_sum(sum);
+            const float inv = sum > 0.f ? 1.f / sum : 0.f;
+#pragma unroll
+            for (int gi = 0; gi < ROW_G; ++gi) {
+                const int g = part + ROW_L * gi, j0 = 4 * g;
+                if (g < NG) {
+                    float ds[4] = {1.f, 1.f, 1.f, 1.f};
+                    if (row < Sq && j0 < Sk) dr.scale4(row, j0, Sk, ds);
+                    short4_t pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk[e] = __builtin_bit_cast(short, __float2bfloat16(v[gi][e] * inv * ds[e]));
+                    *reinterpret_cast<short4_t*>(Pb + row * LDP + j0) = pk;
+                }
+            }
         }
     }
     __syncthreads();
+    ASTAMP(stp, 4);
     // O = P V : tiles (ti, tc), k = j over RK.  The tiles go back through LDS (the Q image is dead since the scores)
     // so that the context leaves as whole 16-byte row pieces -- 128 contiguous bytes per (row, head) -- instead of
     // 2-byte stores at a row stride, and, for the fp8 forward, as e4m3 next to it in the same pass.
@@ -197,6 +292,7 @@ __global__ __launch_bounds__(NT) void attn_fwd_mfma_kernel(MGroup G) {
         for (int r = 0; r < 4; ++r) Os[(ti * 16 + fq * 4 + r) * LDT + tc * 16 + fr] = __float2bfloat16(acc[r]);
     }
     __syncthreads();
+    ASTAMP(stp, 5);
     const Q8 qs(sg.out8 ? sg.qscale : nullptr);
     const float q8 = qs.q;
     float amax8 = 0.f;
@@ -215,6 +311,7 @@ __global__ __launch_bounds__(NT) void attn_fwd_mfma_kernel(MGroup G) {
             *reinterpret_cast<int2*>(sg.out8 + o) = make_int2(pack4_e4m3(f[0], f[1], f[2], f[3], q8), pack4_e4m3(f[4], f[5], f[6], f[7], q8));
         }
     }
+    ASTAMP(stp, 6);
     if (sg.out8 && sg.amax) {
         __shared__ float red8[NT / 64];
         const float wv = wave_max(amax8);
@@ -274,6 +371,10 @@ __global__ __launch_bounds__(NT) void attn_bwd_mfma_kernel(MGroup G) {
     bf16* Pdb = dSb + RQ * LDP;   // [RQ][LDP] bf16: P with dropout folded in
     float* Sf = reinterpret_cast<float*>(Pdb + RQ * LDP);  // [R16][lds_s]: S then P
     float* dPf = Sf + R16 * lds_s;
+#ifdef XGGM_STAMP
+    long long* stp = G.stamp;
+#endif
+    ASTAMP(stp, 0);
     {
         const TileRegs tq_ = tile_fetch(a.q + (int64_t)b * Sq * a.q_rs + h * D, a.q_rs, Sq, tid);
         const TileRegs tk_ = tile_fetch(a.k + (int64_t)b * Sk * a.k_rs + h * D, a.k_rs, Sk, tid);
@@ -285,6 +386,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_mfma_kernel(MGroup G) {
         tile_commit(dOs, to_, Sq, RQ, tid);
     }
     __syncthreads();
+    ASTAMP(stp, 1);
     scores(a, Qs, Ks, Sf, lds_s, b, tid);
     // dP = dO V^T (both operands read by rows: the reduction index is the feature)
     {
@@ -304,22 +406,70 @@ __global__ __launch_bounds__(NT) void attn_bwd_mfma_kernel(MGroup G) {
         }
     }
     __syncthreads();
-    softmax_rows(a, Sf, lds_s, tid);
-    __syncthreads();
-    // dS = P (dP D - rowsum(dP D P)) scale;  Pd = P D.  Rows/columns outside the problem are zero.
-    const Drop dr(a, b, h);
-    for (int i = wid; i < RQ; i += NT / 64) {
-        const bool in = i < Sq && lane < Sk;
-        const float pv = in ? Sf[i * lds_s + lane] : 0.f;
-        const float dm = in ? dr.scale(i, lane, Sk) : 1.f;
-        const float dp = in ? dPf[i * lds_s + lane] * dm : 0.f;
-        const float rs = wave_sum(pv * dp);
-        if (lane < RK) {
-            dSb[i * LDP + lane] = __float2bfloat16(in ? pv * (dp - rs) * a.scale : 0.f);
-            Pdb[i * LDP + lane] = __float2bfloat16(in ? pv * dm : 0.f);
+    ASTAMP(stp, 2);
+    ASTAMP(stp, 3);
+    // softmax recomputed, then dS = P (dP D - rowsum(dP D P)) scale and Pd = P D, eight lanes per row (see the forward
+    // kernel).  Rows / columns outside the problem are zero.
+    {
+        const Drop dr(a, b, h);
+        const int row = tid / ROW_L, part = tid % ROW_L, NG = RK >> 2;
+        if (row < RQ) {
+            float v[ROW_G][4], dp[ROW_G][4], dm[ROW_G][4];
+            float m = -INFINITY;
+#pragma unroll
+            for (int gi = 0; gi < ROW_G; ++gi) {
+                const int j0 = 4 * (part + ROW_L * gi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool in = row < Sq && j0 + e < Sk;
+                    v[gi][e] = in ? Sf[row * lds_s + j0 + e] : -INFINITY;
+                    dp[gi][e] = in ? dPf[row * lds_s + j0 + e] : 0.f;
+                    m = fmaxf(m, v[gi][e]);
+                }
+            }
+            m = quad_max(m);
+            float sum = 0.f;
+#pragma unroll
+            for (int gi = 0; gi < ROW_G; ++gi)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[gi][e] = v[gi][e] > -INFINITY ? __expf(v[gi][e] - m) : 0.f;
+                    sum += v[gi][e];
+                }
+            sum = quad_sum(sum);
+            const float inv = sum > 0.f ? 1.f / sum : 0.f;
+            float rs = 0.f;
+#pragma unroll
+            for (int gi = 0; gi < ROW_G; ++gi) {
+                const int j0 = 4 * (part + ROW_L * gi);
+                dm[gi][0] = dm[gi][1] = dm[gi][2] = dm[gi][3] = 1.f;
+                if (row < Sq && j0 < Sk) dr.scale4(row, j0, Sk, dm[gi]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[gi][e] *= inv;          // P
+                    dp[gi][e] *= dm[gi][e];   // dP D
+                    rs += v[gi][e] * dp[gi][e];
+                }
+            }
+            rs = quad_sum(rs);
+#pragma unroll
+            for (int gi = 0; gi < ROW_G; ++gi) {
+                const int g = part + ROW_L * gi, j0 = 4 * g;
+                if (g < NG) {
+                    short4_t ks, kp;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        ks[e] = __builtin_bit_cast(short, __float2bfloat16(v[gi][e] * (dp[gi][e] - rs) * a.scale));
+                        kp[e] = __builtin_bit_cast(short, __float2bfloat16(v[gi][e] * dm[gi][e]));
+                    }
+                    *reinterpret_cast<short4_t*>(dSb + row * LDP + j0) = ks;
+                    *reinterpret_cast<short4_t*>(Pdb + row * LDP + j0) = kp;
+                }
+            }
         }
     }
     __syncthreads();
+    ASTAMP(stp, 4);
     const int tq = rup(Sq, 16) / 16, tk = rup(Sk, 16) / 16;
     // 4 column tiles each for dQ (tq row tiles), dK and dV (tk row tiles): one list shared by the waves
     const int n_dq = tq * 4, n_dk = tk * 4;
@@ -342,6 +492,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_mfma_kernel(MGroup G) {
             store_grad_tile(acc, dv + h * D, dv_rs, b * Sk, Sk, tj * 16, tc * 16, dbv ? csum[2] : nullptr, lane);
         }
     }
+    ASTAMP(stp, 5);
     if (dbq || dbk) {
         __syncthreads();
         const int t = threadIdx.x;
@@ -391,6 +542,9 @@ int xggm_attn_fwd_mfma_group(const xggm_attn_problem* probs, int n, const uint64
         G.s[1] = G.s[0];
         G.start1 = total;
     }
+#ifdef XGGM_STAMP
+    G.stamp = g_attn_stamp;
+#endif
     allow_big_lds(attn_fwd_mfma_kernel, lds);
     hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(total), dim3(NT), lds, st, G);
     return xggm_check_launch("xggm_attn_fwd(mfma)");
@@ -414,7 +568,17 @@ int xggm_attn_bwd_mfma_group(const xggm_attn_problem* probs, int n, const uint64
         G.s[1] = G.s[0];
         G.start1 = total;
     }
+#ifdef XGGM_STAMP
+    G.stamp = g_attn_stamp;
+#endif
     allow_big_lds(attn_bwd_mfma_kernel, lds);
     hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(total), dim3(NT), lds, st, G);
     return xggm_check_launch("xggm_attn_bwd(mfma)");
 }
+
+#ifdef XGGM_STAMP
+extern "C" int xggm_attn_set_stamp(long long* buf) {
+    g_attn_stamp = buf;
+    return XGGM_OK;
+}
+#endif

@@ -264,10 +264,10 @@ template <typename T> __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs
 typedef __attribute__((ext_vector_type(4))) short short4_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 
-template <int R, bool KMAJ> struct OpLds {
+template <int R, bool KMAJ, int NTH = NT> struct OpLds {
     static constexpr int LD = KMAJ ? 64 : (R + 16);  // elements per LDS row
     static constexpr int ELEMS = KMAJ ? R * 64 : 64 * (R + 16);
-    static constexpr int NCH = R / 32;  // 16-byte chunks per thread per k-tile
+    static constexpr int NCH = R * 8 / NTH;  // 16-byte chunks per thread per k-tile (R rows x 8 chunks over NTH threads)
 };
 
 // Branch-free tile load through a buffer descriptor: the hardware range check returns zeros for
@@ -297,12 +297,12 @@ __device__ __forceinline__ OpSrc make_src(const bf16* base, int64_t bytes, int64
     return s;
 }
 
-template <int R, bool KMAJ, int ES = 2>  // ES: bytes per element (2 = bf16; 1 = fp8, k-major operands only)
-__device__ __forceinline__ void fast_load(short8_t (&reg)[R / 32], const OpSrc& src, int r0, int k0, int Rtot, int K, int tid) {
+template <int R, bool KMAJ, int ES = 2, int NTH = NT>  // ES: bytes per element (2 = bf16; 1 = fp8, k-major operands only)
+__device__ __forceinline__ void fast_load(short8_t (&reg)[R * 8 / NTH], const OpSrc& src, int r0, int k0, int Rtot, int K, int tid) {
     static_assert(ES == 2 || KMAJ, "fp8 operands are k-contiguous");
 #pragma unroll
-    for (int i = 0; i < R / 32; ++i) {
-        const int c = tid + NT * i;
+    for (int i = 0; i < R * 8 / NTH; ++i) {
+        const int c = tid + NTH * i;
         int off;
         if (KMAJ) {
             const int row = min(r0 + (c >> 3), Rtot - 1), kc = k0 + (c & 7) * (16 / ES);
@@ -315,11 +315,11 @@ __device__ __forceinline__ void fast_load(short8_t (&reg)[R / 32], const OpSrc& 
     }
 }
 
-template <int R, bool KMAJ>
-__device__ __forceinline__ void fast_store(bf16* lds, const short8_t (&reg)[R / 32], int tid, int k0, int K, int tail) {
+template <int R, bool KMAJ, int NTH = NT>
+__device__ __forceinline__ void fast_store(bf16* lds, const short8_t (&reg)[R * 8 / NTH], int tid, int k0, int K, int tail) {
 #pragma unroll
-    for (int i = 0; i < R / 32; ++i) {
-        const int c = tid + NT * i;
+    for (int i = 0; i < R * 8 / NTH; ++i) {
+        const int c = tid + NTH * i;
         if (KMAJ) {
             const int row = c >> 3, kc = c & 7;
             short8_t v = reg[i];
@@ -384,9 +384,11 @@ __device__ __forceinline__ void lds_barrier() {
 // 16/32-byte vectors along the row (full lines instead of 64 scattered 2-byte stores per lane), in a
 // rolled loop -- a fully unrolled per-element epilogue with its activation switch made the code
 // object ~100 KB and the instruction fetch of that was most of the kernel's fixed cost.
-template <int BM, int BN, int TM, int TN>
+template <int BM, int BN, int TM, int TN, int W = 4>
 __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, const float4_t (&acc)[TM][TN], int m0, int n0, int bz,
                                              float* stage, int wm, int wn) {
+    constexpr int NT = 64 * W;             // threads of this workgroup (shadows the file-wide 256)
+    constexpr int WMH = W / 4;             // waves along M inside one half tile (W / 2 waves along M in all)
     constexpr int LDS_LD = BN + 4;
     constexpr int CPR = BN / 8;           // 8-element chunks per row
     constexpr int HALF = BM / 2;
@@ -420,12 +422,13 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, const float4_
     float amax8 = 0.f;
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {
-        if ((wid >> 1) == h) {
+        if ((wid >> 1) / WMH == h) {
+            const int hr = ((wid >> 1) % WMH) * (HALF / WMH);  // this wave's first row inside the half tile
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    *reinterpret_cast<float4_t*>(stage + (i * 16 + fr) * LDS_LD + wn + j * 16 + fq * 4) = acc[i][j];
+                    *reinterpret_cast<float4_t*>(stage + (hr + i * 16 + fr) * LDS_LD + wn + j * 16 + fq * 4) = acc[i][j];
         }
         lds_barrier();  // LDS only: global stores of the previous half stay in flight
         if (h == 0) STAMP(g, 7);
@@ -586,7 +589,9 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, const float4_
         if (lane == 0) stage[wid] = wv;
         lds_barrier();
         if (tid == 0) {
-            const float bm = fmaxf(fmaxf(stage[0], stage[1]), fmaxf(stage[2], stage[3]));
+            float bm = stage[0];
+#pragma unroll
+            for (int w = 1; w < W; ++w) bm = fmaxf(bm, stage[w]);
             if (bm > qs.thr) atomic_max_nonneg(g.c8_amax, bm);
         }
         lds_barrier();
@@ -601,16 +606,20 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, const float4_
 #pragma unroll
             for (int c = 0; c < CS; ++c) {
                 const float v = wave_sum(cs == c ? sq_acc[r] : 0.f);
-                if (lane == 0) stage[(r * CS + c) * 4 + wid] = v;
+                if (lane == 0) stage[(r * CS + c) * W + wid] = v;
             }
         lds_barrier();
         if (tid < RS * CS) {
             const int r = tid / CS, c = tid % CS;
             const int row = m0 + r * 64, cl = n0 + c * 64;
             const int64_t sc = (g.N + 63) / 64, sr = (g.M + 63) / 64;
-            if (row < g.M && cl < g.N)
-                g.sqsum[(int64_t)bz * sr * sc + (int64_t)(row / 64) * sc + cl / 64] =
-                    (stage[tid * 4] + stage[tid * 4 + 1]) + (stage[tid * 4 + 2] + stage[tid * 4 + 3]);
+            if (row < g.M && cl < g.N) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < W; w += 4)  // fixed order
+                    t += (stage[tid * W + w] + stage[tid * W + w + 1]) + (stage[tid * W + w + 2] + stage[tid * W + w + 3]);
+                g.sqsum[(int64_t)bz * sr * sc + (int64_t)(row / 64) * sc + cl / 64] = t;
+            }
         }
     }
 }
@@ -619,22 +628,27 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, const float4_
 // row, so loads, LDS image, swizzle and fragment reads are the bf16 ones byte for byte; a lane's 16-byte fragment
 // feeds two v_mfma_f32_16x16x32_fp8_fp8 (8 bytes each).  Which 8 k-indices a lane supplies does not matter to a
 // reduction as long as A and B agree, and both go through the same mapping.
-template <int BM, int BN, bool AK, bool BKM, int D, bool F8 = false>
+// W = waves per workgroup: 4 (2 x 2) or 8 (4 along M x 2 along N; two waves per SIMD inside ONE workgroup: one wave's
+// LDS phase runs under the other's MFMAs even when a CU holds a single tile, and a 128 x 128 tile moves a third
+// fewer LDS bytes per flop than two 128 x 64 tiles -- the k-loop is bound by the LDS write path)
+template <int BM, int BN, bool AK, bool BKM, int D, bool F8 = false, int W = 4>
 __device__ __forceinline__ void gemm_kloop(const GemmArgs& g, int tile_m, int tile_n, int bz, bf16* fsm,
-                                           float4_t (&acc)[BM / 32][BN / 32]) {
+                                           float4_t (&acc)[BM / (8 * W)][BN / 32]) {
     static_assert(!F8 || (AK && BKM), "fp8 operands are k-contiguous");
+    constexpr int NT = 64 * W;  // threads of this workgroup (shadows the file-wide 256)
     constexpr int ES = F8 ? 1 : 2, KT = 128 / ES;  // bytes per element, elements per k-tile
     // D = prefetch depth: D k-tiles of both operands are in flight in registers while one tile
     // is consumed from LDS.  These GEMMs are skinny (one k-chain per CU), so the k-loop would
     // otherwise run at one L2/HBM round trip per iteration.
-    typedef OpLds<BM, AK> LA;
-    typedef OpLds<BN, BKM> LB;
-    constexpr int TM = BM / 32, TN = BN / 32;  // 16x16 tiles per wave (wave tile = BM/2 x BN/2)
+    typedef OpLds<BM, AK, NT> LA;
+    typedef OpLds<BN, BKM, NT> LB;
+    constexpr int WM = W / 2;                        // waves along M (2 along N)
+    constexpr int TM = BM / (16 * WM), TN = BN / 32;  // 16x16 tiles per wave (wave tile = BM/WM x BN/2)
     constexpr int STAGE = LA::ELEMS + LB::ELEMS;  // LDS buffer s: A at s*STAGE, B at s*STAGE + LA::ELEMS
     constexpr int UNR = (D % 2 == 0) ? D : 2 * D;  // unroll so that stage (t % D) and buffer (t & 1) are static
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = (wid >> 1) * (BM / 2), wn = (wid & 1) * (BN / 2);
+    const int wm = (wid >> 1) * (BM / WM), wn = (wid & 1) * (BN / 2);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     STAMP(g, 0);
     STAMP_HW(g);
@@ -656,11 +670,11 @@ __device__ __forceinline__ void gemm_kloop(const GemmArgs& g, int tile_m, int ti
     const int nk = ((g.K + KT - 1) / KT + UNR - 1) / UNR * UNR;
 #pragma unroll
     for (int s = 0; s < D; ++s) {
-        fast_load<BM, AK, ES>(ra[s], sa, m0, s * KT, g.a_rows, g.K, tid);
-        fast_load<BN, BKM, ES>(rb[s], sb, n0, s * KT, g.b_rows, g.K, tid);
+        fast_load<BM, AK, ES, NT>(ra[s], sa, m0, s * KT, g.a_rows, g.K, tid);
+        fast_load<BN, BKM, ES, NT>(rb[s], sb, n0, s * KT, g.b_rows, g.K, tid);
     }
-    fast_store<BM, AK>(fsm, ra[0], tid, 0, g.K, F8 ? 0 : g.a_tail);
-    fast_store<BN, BKM>(fsm + LA::ELEMS, rb[0], tid, 0, g.K, F8 ? 0 : g.b_tail);
+    fast_store<BM, AK, NT>(fsm, ra[0], tid, 0, g.K, F8 ? 0 : g.a_tail);
+    fast_store<BN, BKM, NT>(fsm + LA::ELEMS, rb[0], tid, 0, g.K, F8 ? 0 : g.b_tail);
     lds_barrier();
     STAMP(g, 1);
     for (int t0 = 0; t0 < nk; t0 += UNR) {
@@ -671,8 +685,13 @@ __device__ __forceinline__ void gemm_kloop(const GemmArgs& g, int tile_m, int ti
             const bf16* Bc = Ac + LA::ELEMS;
             bf16* An = fsm + ((u + 1) & 1) * STAGE;
             // stage (t % D) was copied to LDS one step ago: refill it with tile t + D
-            fast_load<BM, AK, ES>(ra[u % D], sa, m0, (t + D) * KT, g.a_rows, g.K, tid);
-            fast_load<BN, BKM, ES>(rb[u % D], sb, n0, (t + D) * KT, g.b_rows, g.K, tid);
+            fast_load<BM, AK, ES, NT>(ra[u % D], sa, m0, (t + D) * KT, g.a_rows, g.K, tid);
+            fast_load<BN, BKM, ES, NT>(rb[u % D], sb, n0, (t + D) * KT, g.b_rows, g.K, tid);
+            // (W == 8, measured and not kept: queueing the iteration's LDS writes ahead of its MFMAs -- slower, the
+            // wave stalls on the prefetch's vmcnt in front of the matrix work, 14.97 -> 17.2 k cycles per 128 x 128 x 768
+            // tile; running the two wave groups half an iteration apart with a barrier per half -- slower still,
+            // 22.2 k: the iteration is a LATENCY chain (barrier, fragment reads, dependent MFMAs, writes), not an LDS
+            // throughput limit, and a second barrier lengthens it.)
 #pragma unroll
             for (int ks = 0; ks < 64; ks += 32) {
                 bf16x8_t a[TM], b[TN];
@@ -695,8 +714,8 @@ __device__ __forceinline__ void gemm_kloop(const GemmArgs& g, int tile_m, int ti
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
                         }
             }
-            fast_store<BM, AK>(An, ra[(u + 1) % D], tid, (t + 1) * KT, g.K, F8 ? 0 : g.a_tail);
-            fast_store<BN, BKM>(An + LA::ELEMS, rb[(u + 1) % D], tid, (t + 1) * KT, g.K, F8 ? 0 : g.b_tail);
+            fast_store<BM, AK, NT>(An, ra[(u + 1) % D], tid, (t + 1) * KT, g.K, F8 ? 0 : g.a_tail);
+            fast_store<BN, BKM, NT>(An + LA::ELEMS, rb[(u + 1) % D], tid, (t + 1) * KT, g.K, F8 ? 0 : g.b_tail);
             lds_barrier();
         }
     }
@@ -705,12 +724,12 @@ __device__ __forceinline__ void gemm_kloop(const GemmArgs& g, int tile_m, int ti
 }
 
 // epilogue of one tile (shared by every operand-layout variant of the k-loop: ONE copy of its code per kernel)
-template <int BM, int BN>
+template <int BM, int BN, int W = 4>
 __device__ __forceinline__ void gemm_finish(const GemmArgs& g, int tile_m, int tile_n, int bz, bf16* fsm,
-                                            const float4_t (&acc)[BM / 32][BN / 32]) {
-    constexpr int TM = BM / 32, TN = BN / 32;
+                                            const float4_t (&acc)[BM / (8 * W)][BN / 32]) {
+    constexpr int TM = BM / (8 * W), TN = BN / 32;
     const int wid = threadIdx.x >> 6;
-    const int wm = (wid >> 1) * (BM / 2), wn = (wid & 1) * (BN / 2);
+    const int wm = (wid >> 1) * (BM / (W / 2)), wn = (wid & 1) * (BN / 2);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     if (ABLATE(g, 2)) {
         float keep = 0.f;
@@ -721,7 +740,7 @@ __device__ __forceinline__ void gemm_finish(const GemmArgs& g, int tile_m, int t
         if (keep == 123.456f) reinterpret_cast<float*>(g.C)[threadIdx.x] = keep;
         return;
     }
-    epilogue_staged<BM, BN, TM, TN>(g, acc, m0, n0, bz, reinterpret_cast<float*>(fsm), wm, wn);
+    epilogue_staged<BM, BN, TM, TN, W>(g, acc, m0, n0, bz, reinterpret_cast<float*>(fsm), wm, wn);
     STAMP(g, 4);
 }
 
@@ -830,7 +849,8 @@ struct GroupArgs {
     int nprob;
 };
 
-template <int BM, int BN> __global__ __launch_bounds__(NT, (min_waves<BM, BN>())) void gemm_grouped_kernel(GroupArgs ga) {
+template <int BM, int BN, int W = 4>
+__global__ __launch_bounds__(64 * W, (W == 8 ? 2 : min_waves<BM, BN>())) void gemm_grouped_kernel(GroupArgs ga) {
     extern __shared__ __attribute__((aligned(16))) bf16 fsm[];
     // Which problem, and which tile of it.  Inside each problem the tiles get the XCD-aware order:
     // blocks are dealt to XCDs by id % 8, so the problem's blocks of one residue class take one
@@ -857,18 +877,18 @@ template <int BM, int BN> __global__ __launch_bounds__(NT, (min_waves<BM, BN>())
         tile_n = lt - tile_m * gx;
     }
     constexpr int DK = (BM * BN <= 64 * 64) ? 4 : 2;  // prefetch depth when an operand is k-major
-    float4_t acc[BM / 32][BN / 32];
+    float4_t acc[BM / (8 * W)][BN / 32];
     if (g.a_mode == 1) {
-        if (g.b_mode == 1) gemm_kloop<BM, BN, true, true, DK>(g, tile_m, tile_n, bz, fsm, acc);
-        else gemm_kloop<BM, BN, true, false, DK>(g, tile_m, tile_n, bz, fsm, acc);
+        if (g.b_mode == 1) gemm_kloop<BM, BN, true, true, DK, false, W>(g, tile_m, tile_n, bz, fsm, acc);
+        else gemm_kloop<BM, BN, true, false, DK, false, W>(g, tile_m, tile_n, bz, fsm, acc);
     } else {
-        if (g.b_mode == 1) gemm_kloop<BM, BN, false, true, DK>(g, tile_m, tile_n, bz, fsm, acc);
-        else gemm_kloop<BM, BN, false, false, 2>(g, tile_m, tile_n, bz, fsm, acc);
+        if (g.b_mode == 1) gemm_kloop<BM, BN, false, true, DK, false, W>(g, tile_m, tile_n, bz, fsm, acc);
+        else gemm_kloop<BM, BN, false, false, 2, false, W>(g, tile_m, tile_n, bz, fsm, acc);
     }
-    gemm_finish<BM, BN>(g, tile_m, tile_n, bz, fsm, acc);
+    gemm_finish<BM, BN, W>(g, tile_m, tile_n, bz, fsm, acc);
 }
 
-template <int BM, int BN> int launch_grouped_tile(GroupArgs& ga, hipStream_t stream) {
+template <int BM, int BN, int W = 4> int launch_grouped_tile(GroupArgs& ga, hipStream_t stream) {
     int total = 0;
     for (int i = 0; i < ga.nprob; ++i) {
         ga.tile_start[i] = total;
@@ -885,11 +905,11 @@ template <int BM, int BN> int launch_grouped_tile(GroupArgs& ga, hipStream_t str
     constexpr size_t lds_max = 2 * sizeof(bf16) * (OpLds<BM, false>::ELEMS + OpLds<BN, false>::ELEMS);
     static bool attr_set = false;
     if (lds_max > 48 * 1024 && !attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_grouped_kernel<BM, BN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_grouped_kernel<BM, BN, W>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_grouped_kernel<BM, BN>), dim3(total), dim3(NT), lds, stream, ga);
+    hipLaunchKernelGGL((gemm_grouped_kernel<BM, BN, W>), dim3(total), dim3(64 * W), lds, stream, ga);
     return xggm_check_launch("xggm_gemm_grouped");
 }
 
@@ -1192,7 +1212,23 @@ template <typename T> int grouped(const xggm_gemm_problem* probs, int n, hipStre
             if (int e = launch<T>(from_problem(probs[i]), probs[i].batch, stream)) return e;
         return XGGM_OK;
     }
-    const int v = pick_group_tile(ga, n, 64);
+    int v = pick_group_tile(ga, n, 64);
+    if (g_group_tile == 0 && sizeof(T) == 2) {
+        // 128 x 128 on eight waves (two per SIMD inside one workgroup, a third fewer LDS bytes per flop than two
+        // 128 x 64 tiles): measured faster exactly where one round of such tiles covers the chip and the k-loop is
+        // long enough to matter -- the fused QKV forward pair, 17.6 -> 15.5 us; slower where the tiles need a second
+        // round (FFN forward, 336 tiles) or leave most CUs idle (tools/gemm_phase_report.py)
+        int64_t t128 = 0;
+        bool kmaj = true;
+        int nkmin = 1 << 30;
+        for (int i = 0; i < n; ++i) {
+            t128 += (int64_t)ceil_div(ga.p[i].M, 128) * ceil_div(ga.p[i].N, 128) * ga.p[i].batch;
+            kmaj = kmaj && ga.p[i].a_mode == 1 && ga.p[i].b_mode == 1;
+            nkmin = std::min(nkmin, ceil_div(ga.p[i].K, 64));
+        }
+        if (kmaj && t128 > 200 && t128 <= 256 && nkmin >= 12) v = 4;
+    }
+    if (v == 4) return launch_grouped_tile<128, 128, 8>(ga, stream);
     if (v == 3) return launch_grouped_tile<128, 128>(ga, stream);
     if (v == 2) return launch_grouped_tile<128, 64>(ga, stream);
     return launch_grouped_tile<64, 64>(ga, stream);

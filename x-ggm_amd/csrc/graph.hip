@@ -101,6 +101,121 @@ __global__ __launch_bounds__(NT) void aggregate_kernel(const float* __restrict__
     }
 }
 
+// ---- bf16 storage: the same product on the bf16 matrix cores -------------------------------------------------
+// With bf16 node features the fp32 MFMA above spends 16x the matrix-core time the data deserve (v_mfma_f32_16x16x4
+// runs at 1/16 of the bf16 rate; at N = 64 it weighs as much as the HBM traffic).  Here M' is split into two bf16
+// terms, M' = hi + lo with hi = bf16(M'), lo = bf16(M' - hi): out = hi x + lo x accumulated in fp32 carries M' to 16
+// mantissa bits (relative 2^-17), far below the bf16 rounding of x and of the result, on v_mfma_f32_16x16x32_bf16.
+//   x slab [N, 64] bf16 by 16-byte loads -> LDS [k = j][n = c] (row stride 72), read transposed (ds_read_b64_tr_b16)
+//   as the A operand x^T; M' staged raw as fp32 (coalesced), then hi / lo [i][k = j] (row stride 72), read by rows
+//   (ds_read_b128) as the B operand M'^T.  D^T = x^T M'^T: a lane holds four consecutive columns of one output row.
+// One workgroup = one sample x 64 columns; the column blocks of a sample run on ONE XCD (blocks are dealt round-robin
+// over the 8 XCDs, so sample b gets the ids with id % 8 == b % 8): its adjacency is fetched into one L2, not eight.
+typedef __attribute__((ext_vector_type(8))) short agg_short8;
+typedef __attribute__((ext_vector_type(4))) short agg_short4;
+typedef __attribute__((ext_vector_type(8))) __bf16 agg_bf16x8;
+template <int NI>
+__global__ __launch_bounds__(NT) void aggregate_bf16_kernel(const float* __restrict__ Mx, const bf16* __restrict__ x, bf16* out,
+                                                            int B, int N, int H, int mode, float scale, const float* scale_ptr,
+                                                            float self_w, int accumulate) {
+    constexpr int NK = 64, LDX = 72, LDM = 72, LDR = 65;
+    __shared__ float Mr[64 * LDR];
+    __shared__ __attribute__((aligned(16))) bf16 xs[NK * LDX];
+    __shared__ __attribute__((aligned(16))) bf16 Mh[NI * 16 * LDM];
+    __shared__ __attribute__((aligned(16))) bf16 Ml[NI * 16 * LDM];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int ncb = (H + AGG_COLS - 1) / AGG_COLS;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int b = (q / ncb) * 8 + xcd, cb = (q % ncb) * AGG_COLS;
+    if (b >= B) return;  // (whole workgroup: the padding blocks of a batch that is not a multiple of 8)
+    const float* Mb = Mx + (int64_t)b * N * N;
+    if ((N & 3) == 0 && (reinterpret_cast<uintptr_t>(Mb) & 15) == 0) {  // 16-byte loads (N = 36, 64)
+        for (int e = tid; e < N * N / 4; e += NT) {
+            const float4 v = *reinterpret_cast<const float4*>(Mb + 4 * e);
+            float* d = Mr + ((4 * e) / N) * LDR + (4 * e) % N;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    } else {
+        for (int e = tid; e < N * N; e += NT) Mr[(e / N) * LDR + e % N] = Mb[e];
+    }
+    const bf16* xb = x + (int64_t)b * N * H + cb;
+    for (int e = tid; e < NK * 8; e += NT) {  // 8 chunks of 8 columns per k-row
+        const int j = e >> 3, c = (e & 7) * 8;
+        agg_short8 v = {};
+        if (j < N && cb + c + 8 <= H) v = *reinterpret_cast<const agg_short8*>(xb + (int64_t)j * H + c);  // H % 8 == 0 here
+        *reinterpret_cast<agg_short8*>(xs + j * LDX + c) = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < NI * 16 * NK / 4; e += NT) {  // four consecutive k per thread: 8-byte LDS stores
+        const int i = (4 * e) / NK, j0 = (4 * e) % NK;
+        agg_short4 h4, l4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u;
+            float v = 0.f;
+            if (i < N && j < N) {
+                if (mode == XGGM_AGG_PLAIN) v = Mr[i * LDR + j];
+                else if (mode == XGGM_AGG_TRANSPOSE) v = Mr[j * LDR + i];
+                else v = Mr[i * LDR + j] + Mr[j * LDR + i];
+            }
+            const bf16 hi = __float2bfloat16(v);
+            h4[u] = __builtin_bit_cast(short, hi);
+            l4[u] = __builtin_bit_cast(short, __float2bfloat16(v - __bfloat162float(hi)));
+        }
+        *reinterpret_cast<agg_short4*>(Mh + i * LDM + j0) = h4;
+        *reinterpret_cast<agg_short4*>(Ml + i * LDM + j0) = l4;
+    }
+    __syncthreads();
+    if (scale_ptr) scale *= (1.0f + *scale_ptr);  // GIN: (1 + eps)
+    const int fr = lane & 15, fq = lane >> 4, c0 = wid * 16;
+    float4_t acc[NI];
+#pragma unroll
+    for (int t = 0; t < NI; ++t) acc[t] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NK; ks += 32) {
+        // A operand x^T: lane (fr, fq) gets column c0 + fr, k = ks + 8 fq .. + 7 through two transposing reads
+        const int qq = fr >> 2, pp = fr & 3;
+        const bf16* a0 = xs + (ks + 8 * fq + qq) * LDX + c0 + 4 * pp;
+        const agg_short4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) agg_short4*)(a0));
+        const agg_short4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) agg_short4*)(a0 + 4 * LDX));
+        agg_short8 av;
+        av[0] = lo4[0]; av[1] = lo4[1]; av[2] = lo4[2]; av[3] = lo4[3];
+        av[4] = hi4[0]; av[5] = hi4[1]; av[6] = hi4[2]; av[7] = hi4[3];
+        const agg_bf16x8 a = __builtin_bit_cast(agg_bf16x8, av);
+#pragma unroll
+        for (int t = 0; t < NI; ++t) {
+            const agg_bf16x8 bh = __builtin_bit_cast(agg_bf16x8, *reinterpret_cast<const agg_short8*>(Mh + (t * 16 + fr) * LDM + ks + fq * 8));
+            const agg_bf16x8 bl = __builtin_bit_cast(agg_bf16x8, *reinterpret_cast<const agg_short8*>(Ml + (t * 16 + fr) * LDM + ks + fq * 8));
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bh, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bl, acc[t], 0, 0, 0);
+        }
+    }
+    // lane holds out[i = t*16 + fr][c = c0 + 4 fq .. + 3]
+    const int c = cb + c0 + 4 * fq;
+    if (c >= H) return;
+    bf16* ob = out + (int64_t)b * N * H + c;
+#pragma unroll
+    for (int t = 0; t < NI; ++t) {
+        const int i = t * 16 + fr;
+        if (i < N) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = scale * acc[t][r];
+            if (self_w != 0.f) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += self_w * __bfloat162float(xs[i * LDX + c0 + 4 * fq + r]);
+            }
+            if (accumulate) {
+                float o[4];
+                load4(ob + (int64_t)i * H, o);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += o[r];
+            }
+            store4(ob + (int64_t)i * H, v);
+        }
+    }
+}
+
 // d eps of GIN: sum_{b,i,c} dh[b,i,c] * (A @ x)[b,i,c]  -> one scalar (atomic)
 template <typename T, int NP>
 __global__ __launch_bounds__(NT) void agg_dot_kernel(const float* __restrict__ Mx, const T* __restrict__ x,
@@ -316,6 +431,19 @@ int aggregate(const float* M, const void* x, void* out, int B, int N, int H, int
     XGGM_REQUIRE(mode >= 0 && mode <= XGGM_AGG_SYMMETRIZE, "xggm_aggregate: bad mode %d", mode);
     XGGM_REQUIRE(B <= 65535, "xggm_aggregate: batch too large");
     XGGM_REQUIRE(H % 4 == 0, "xggm_aggregate: H=%d must be a multiple of 4", H);
+    if constexpr (sizeof(T) == 2) {
+        // bf16 storage, 8-aligned rows: bf16 matrix cores with the adjacency split into hi + lo (aggregate_bf16_kernel)
+        if (H % 8 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 8 == 0) {
+            const dim3 g8(ceil_div(B, 8) * 8 * ceil_div(H, AGG_COLS));
+            if (N <= 48)
+                hipLaunchKernelGGL((aggregate_bf16_kernel<3>), g8, dim3(NT), 0, st, M, (const bf16*)x, (bf16*)out, B, N, H, mode,
+                                   scale, scale_ptr, self_w, accumulate);
+            else
+                hipLaunchKernelGGL((aggregate_bf16_kernel<4>), g8, dim3(NT), 0, st, M, (const bf16*)x, (bf16*)out, B, N, H, mode,
+                                   scale, scale_ptr, self_w, accumulate);
+            return xggm_check_launch("xggm_aggregate");
+        }
+    }
     dim3 grid(ceil_div(H, AGG_COLS), B);
     if (N <= 48)
         hipLaunchKernelGGL((aggregate_kernel<T, 48>), grid, dim3(NT), 0, st, M, (const T*)x, (T*)out, N, H, mode, scale,
