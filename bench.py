@@ -526,6 +526,9 @@ def main():
     if os.environ.get("XGGM_GROUP_TILE"):  # A/B hook: pin the tile of grouped GEMM launches (1: 64x64, 2: 128x64, 3: 128x128)
         from xggm_amd import _lib
         _lib.lib.xggm_gemm_set_group_tile(int(os.environ["XGGM_GROUP_TILE"]))
+    if os.environ.get("XGGM_GEMM_FLAGS"):  # A/B hook: xggm_gemm_set_tile flags (0x400: register-staged k-loops, 0x800 / 0x1000: 2 / 3 LDS stages)
+        from xggm_amd import _lib
+        _lib.lib.xggm_gemm_set_tile(int(os.environ["XGGM_GEMM_FLAGS"], 0))
 
     log("building the model (rank %d/%d)" % (rank, world))
     model, optim, batch = build(args, device)

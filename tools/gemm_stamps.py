@@ -46,6 +46,12 @@ def run(tile_code, forms_shapes, label):
         for _, dlt in ev:
             live += dlt
             maxc = max(maxc, live)
+    # the cycle counters of the eight XCDs are not synchronised: first entry -> last exit per XCD
+    spans = [(s[xcc == x][:, 4].max() - s[xcc == x][:, 0].min()).item() for x in sorted(set(xcc.tolist()))]
+    late = [(s[xcc == x][:, 0].max() - s[xcc == x][:, 0].min()).item() for x in sorted(set(xcc.tolist()))]
+    span = sum(spans) / len(spans)
+    print("   per XCD: first entry -> last exit %s cycles; last entry - first entry %s" % (
+        " ".join("%.0f" % v for v in spans), " ".join("%.0f" % v for v in late)), flush=True)
     print("%-44s %7.1f us | %4d tiles, span %8.0f cyc (%.0f cyc/us) | prologue %6.0f  k-loop %7.0f  epi0 %6.0f  epi1 %6.0f | "
           "(staging %5.0f) CUs used %d, max co-resident %d" % (label, t_us, s.shape[0], span, span / t_us, d[0], d[1], d[2], d[3], stg,
                                                                 ncu, maxc),

@@ -49,6 +49,7 @@ struct GemmArgs {
     int a_rows, b_rows;  // rows an operand may be READ at (row-contiguous operands: padded up to a multiple of 8)
     int xcd_swizzle;
     int batch;
+    int use_glds;  // k-major operand pairs take the LDS-DMA k-loop (gemm_kloop_glds)
 #ifdef XGGM_STAMP
     long long* stamp;  // instrumented build (make stamp): 8 cycle-counter slots per workgroup
     int ablate;        // instrumented build: 1 skips the chunk loop of the epilogue, 2 the whole epilogue
@@ -59,6 +60,11 @@ struct GemmArgs {
 long long* g_stamp = nullptr;
 int g_ablate = 0;
 #define ABLATE(g, bit) ((g).ablate & (bit))
+#ifdef XGGM_KABLATE
+#define KABLATE(g, bit) ((g).ablate & (bit))
+#else
+#define KABLATE(g, bit) false
+#endif
 #define STAMP(g, slot)                                                                                \
     do {                                                                                              \
         if ((g).stamp && threadIdx.x == 0)                                                            \
@@ -81,6 +87,7 @@ int g_ablate = 0;
 #else
 #define STAMP_HW(g)
 #define ABLATE(g, bit) false
+#define KABLATE(g, bit) false
 #define STAMP(g, slot)
 #define SET_STAMP(g)
 #endif
@@ -100,6 +107,8 @@ template <> struct Tile<float> {
 constexpr int BM = 64, BN = 64, NT = 256;
 bool g_force_generic = false;  // test hook: xggm_gemm_set_generic
 int g_xcd_swizzle = 1;         // test hook: xggm_gemm_set_tile(variant | 0x100) disables it
+int g_glds_stages = 0;        // test hook: xggm_gemm_set_tile(variant | 0x800 / 0x1000) pins 2 / 3 LDS stages
+int g_glds = 1;                // test hook: xggm_gemm_set_tile(variant | 0x400) keeps k-major pairs on the register-staged k-loop
 int g_group_tile = 0;          // test hook: 0 heuristic, 1: 64x64, 2: 128x64, 3: 128x128
 
 // stage a [64 rows][BK] operand tile into LDS (k contiguous).  elem(r,k) = base[r*rs + k*ks]
@@ -624,6 +633,119 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, const float4_
     }
 }
 
+// ---- register epilogue ----------------------------------------------------------------------------
+// The same arithmetic straight out of the accumulators: with the MFMA operands swapped a lane already holds four
+// CONSECUTIVE columns of one row per 16 x 16 block (8 bytes of bf16, 16 bytes of fp32), so bias, activation and the
+// stores need no trip through LDS.  In-kernel stamps (tools/gemm_phase_report.py, tools/gemm_epi_ablate.py) put the
+// staged epilogue of a 128 x 64 tile at 6.1 k cycles, a quarter of the tile's life, and showed that removing its
+// global stores changes almost nothing: every SIMD holds two or three waves that reach the epilogue together, so
+// the epilogue costs what its INSTRUCTIONS cost to issue.  Hence two lean straight-line kinds, each a few dozen
+// instructions per 16 x 16 block, for what the step launches most -- and the staged, feature-complete walk for the rest:
+//   kind 0: C = alpha * acc + bias, bf16 or fp32 (weight gradients: non-temporal, optional norm slots)
+//   kind 1: pre = bf16(alpha * acc + bias), C = gelu(pre), optional e4m3 copy          (the FFN's first product)
+__device__ __forceinline__ int epilogue_kind(const GemmArgs& g, int bz) {
+    const int64_t coff = (int64_t)bz * g.c_bs;
+    auto al = [](const void* q, uintptr_t a) { return reinterpret_cast<uintptr_t>(q) % a == 0; };
+    if (g.N % 4 || g.ldc % 4 || coff % 4 || g.colsum || g.residual || g.accumulate || !al(g.C, g.c_f32 ? 16 : 8) ||
+        (int64_t)g.M * g.ldc >= (1ll << 31) || (g.sqsum && !g.c_f32))
+        return 2;
+    if (g.act == XGGM_ACT_NONE && !g.preact && !g.c8) return 0;
+    if (g.act == XGGM_ACT_GELU && g.preact && !g.c_f32 && !g.sqsum && al(g.preact, 8) && al(g.c8, 4)) return 1;
+    return 2;
+}
+
+template <int BM, int BN, int TM, int TN, int W, int KIND>
+__device__ __forceinline__ void epilogue_direct(const GemmArgs& g, const float4_t (&acc)[TM][TN], int m0, int n0, int bz,
+                                                float* stage, int wm, int wn) {
+    typedef short short4v __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int64_t coff = (int64_t)bz * g.c_bs;
+    float4_t bias[TN];
+    const int col0 = n0 + wn + fq * 4, row0 = m0 + wm + fr;
+    STAMP(g, 7);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+        bias[j] = (g.bias && col0 + j * 16 < g.N) ? *reinterpret_cast<const float4_t*>(g.bias + col0 + j * 16)
+                                                  : (float4_t){0.f, 0.f, 0.f, 0.f};
+    const Q8 qs(KIND == 1 && g.c8 ? g.c8_qscale : nullptr);
+    const float q8 = qs.q, alpha = g.alpha;
+    float amax8 = 0.f, sq = 0.f;
+    const int off0 = row0 * g.ldc + col0;  // 32-bit offsets from the (batch) base: epilogue_kind checked the range
+    float* cf = reinterpret_cast<float*>(g.C) + coff;
+    bf16* cb = reinterpret_cast<bf16*>(g.C) + coff;
+    bf16* pre = reinterpret_cast<bf16*>(g.preact) + coff;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        if (i == 1) STAMP(g, 3);
+        if (row0 + i * 16 >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            if (col0 + j * 16 >= g.N) continue;
+            const int off = off0 + i * 16 * g.ldc + j * 16;
+            float4_t v = alpha * acc[i][j] + bias[j];
+            if (KIND == 1) {
+                short4v pv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bf16 t = __float2bfloat16(v[e]);
+                    pv[e] = __builtin_bit_cast(short, t);
+                    v[e] = gelu_f(__bfloat162float(t));  // the activation sees the value as stored
+                }
+                *reinterpret_cast<short4v*>(pre + off) = pv;
+                if (g.c8) {
+                    amax8 = fmaxf(fmaxf(amax8, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                    *reinterpret_cast<int*>(g.c8 + coff + off) = pack4_e4m3(v[0], v[1], v[2], v[3], q8);
+                }
+            }
+            if (KIND == 0 && g.c_f32) {
+                sq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                __builtin_nontemporal_store(v, reinterpret_cast<float4_t*>(cf + off));
+            } else {
+                short4v ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = __builtin_bit_cast(short, __float2bfloat16(v[e]));
+                if (!ABLATE(g, 4) || ov[0] == 12345) *reinterpret_cast<short4v*>(cb + off) = ov;
+            }
+        }
+    }
+    // (the k-loop ended with a barrier: LDS is free)
+    if (KIND == 1 && g.c8 && g.c8_amax) {
+        const float wv = wave_max(amax8);
+        if (lane == 0) stage[wid] = wv;
+        lds_barrier();
+        if (tid == 0) {
+            float bm = stage[0];
+#pragma unroll
+            for (int w = 1; w < W; ++w) bm = fmaxf(bm, stage[w]);
+            if (bm > qs.thr) atomic_max_nonneg(g.c8_amax, bm);
+        }
+    }
+    if (KIND == 0 && g.sqsum) {
+        // norm slots (see epilogue_staged): a wave's tile lies inside ONE 64 x 64 block of the output; the waves of
+        // a block are added in a fixed order
+        static_assert(BM / (W / 2) <= 64 && BN / 2 <= 64, "a wave's tile inside one 64 x 64 block");
+        constexpr int RS = BM >= 64 ? BM / 64 : 1, CS = BN >= 64 ? BN / 64 : 1;
+        const float ws = wave_sum(sq);
+        if (lane == 0) stage[wid] = ws;
+        lds_barrier();
+        if (tid < RS * CS) {
+            const int r = tid / CS, c = tid % CS;
+            const int row = m0 + r * 64, cl = n0 + c * 64;
+            if (row < g.M && cl < g.N) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    const int wr = (w >> 1) * (BM / (W / 2)) / 64, wc = (w & 1) * (BN / 2) / 64;
+                    if (wr == r && wc == c) t += stage[w];
+                }
+                const int64_t sc = (g.N + 63) / 64, sr = (g.M + 63) / 64;
+                g.sqsum[(int64_t)bz * sr * sc + (int64_t)(row / 64) * sc + cl / 64] = t;
+            }
+        }
+    }
+}
+
 // F8: both operands are OCP e4m3 bytes, k-contiguous.  A k-tile is then 128 elements -- the same 128 bytes per
 // row, so loads, LDS image, swizzle and fragment reads are the bf16 ones byte for byte; a lane's 16-byte fragment
 // feeds two v_mfma_f32_16x16x32_fp8_fp8 (8 bytes each).  Which 8 k-indices a lane supplies does not matter to a
@@ -685,8 +807,10 @@ __device__ __forceinline__ void gemm_kloop(const GemmArgs& g, int tile_m, int ti
             const bf16* Bc = Ac + LA::ELEMS;
             bf16* An = fsm + ((u + 1) & 1) * STAGE;
             // stage (t % D) was copied to LDS one step ago: refill it with tile t + D
-            fast_load<BM, AK, ES, NT>(ra[u % D], sa, m0, (t + D) * KT, g.a_rows, g.K, tid);
-            fast_load<BN, BKM, ES, NT>(rb[u % D], sb, n0, (t + D) * KT, g.b_rows, g.K, tid);
+            if (!KABLATE(g, 8)) {
+                fast_load<BM, AK, ES, NT>(ra[u % D], sa, m0, (t + D) * KT, g.a_rows, g.K, tid);
+                fast_load<BN, BKM, ES, NT>(rb[u % D], sb, n0, (t + D) * KT, g.b_rows, g.K, tid);
+            }
             // (W == 8, measured and not kept: queueing the iteration's LDS writes ahead of its MFMAs -- slower, the
             // wave stalls on the prefetch's vmcnt in front of the matrix work, 14.97 -> 17.2 k cycles per 128 x 128 x 768
             // tile; running the two wave groups half an iteration apart with a barrier per half -- slower still,
@@ -696,9 +820,16 @@ __device__ __forceinline__ void gemm_kloop(const GemmArgs& g, int tile_m, int ti
             for (int ks = 0; ks < 64; ks += 32) {
                 bf16x8_t a[TM], b[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = fast_frag<BM, AK>(Ac, wm + i * 16, ks, lane);
+                for (int i = 0; i < TM; ++i) a[i] = fast_frag<BM, AK>(KABLATE(g, 64) ? fsm : Ac, wm + (KABLATE(g, 64) ? 0 : i * 16), ks, lane);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = fast_frag<BN, BKM>(Bc, wn + j * 16, ks, lane);
+                for (int j = 0; j < TN; ++j) b[j] = fast_frag<BN, BKM>(KABLATE(g, 64) ? fsm : Bc, wn + (KABLATE(g, 64) ? 0 : j * 16), ks, lane);
+                if (KABLATE(g, 32)) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) acc[i][0][0] += __builtin_bit_cast(float4_t, a[i])[0];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[0][j][1] += __builtin_bit_cast(float4_t, b[j])[0];
+                    continue;
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -714,13 +845,184 @@ __device__ __forceinline__ void gemm_kloop(const GemmArgs& g, int tile_m, int ti
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
                         }
             }
-            fast_store<BM, AK, NT>(An, ra[(u + 1) % D], tid, (t + 1) * KT, g.K, F8 ? 0 : g.a_tail);
-            fast_store<BN, BKM, NT>(An + LA::ELEMS, rb[(u + 1) % D], tid, (t + 1) * KT, g.K, F8 ? 0 : g.b_tail);
-            lds_barrier();
+            if (!KABLATE(g, 16)) {
+                fast_store<BM, AK, NT>(An, ra[(u + 1) % D], tid, (t + 1) * KT, g.K, F8 ? 0 : g.a_tail);
+                fast_store<BN, BKM, NT>(An + LA::ELEMS, rb[(u + 1) % D], tid, (t + 1) * KT, g.K, F8 ? 0 : g.b_tail);
+            }
+            if (!KABLATE(g, 128)) lds_barrier();
         }
     }
     // the k-loop ended with a barrier: LDS is free for the staged epilogue
     STAMP(g, 2);
+}
+
+// ---- k-loop for two k-major operands fed by LDS-DMA ------------------------------------------------------------
+// tools/gemm_kloop_ablate.py (k-loop with parts removed): of the register-staged iteration above, the LDS STORES are the
+// most expensive part -- a third of the k-loop's cycles (ds_write_b128 moves its 16 bytes per lane over the VGPR -> LDS
+// path at ~79 B/clk per CU, shared by all waves) -- ahead of the fragment reads, the MFMAs and the global loads.
+// `buffer_load_dwordx4 ... lds` writes LDS without passing through registers at all: no ds_write, no prefetch ring in
+// VGPRs, no vmcnt-ordered store sequence in front of the barrier.  One wave-instruction fills 1 KB of consecutive LDS
+// (64 lanes x 16 bytes) = 8 rows of the [row][64] image, so the XOR swizzle of the image moves to the SOURCE side: the
+// lane that owns slot s of row r fetches k-chunk s ^ ((r >> 1) & 7).  NS LDS stages: the loads of tile t + NS - 1 are
+// issued right after the barrier that frees the stage tile t - 1 was read from, and are waited for (counted vmcnt, then
+// the barrier that makes every wave's part visible) NS - 1 iterations later.  Requires K % k-tile == 0 (no partial
+// chunks to zero on the way); the forward products of the step all qualify.
+// An r-major operand (row index contiguous: weights in dgrad, both operands in wgrad) cannot keep the padded
+// [64 k][R + 16] image of the register path -- a wave-instruction's 1 KB spans several k-rows and would land in the
+// padding.  Its LDS-DMA image is [64 k][R] with the 16-byte chunks of k-row k XORed by glds_rx(k): the eight k-rows a
+// 32-lane group of ds_read_b64_tr_b16 touches (k = 8 fq + q, fq in {0, 1}, q < 4; +4 for the second read) then sit
+// in eight different 32-byte bank groups (R = 128: 256-byte rows; R = 64: two k-rows per bank row, the parity of k
+// picks the half), i.e. conflict-free without padding.
+template <int R> __device__ __forceinline__ int glds_rx(int k) {
+    return R >= 128 ? 2 * ((k & 3) | (((k >> 3) & 1) << 2)) : 2 * (((k >> 1) & 1) | (((k >> 3) & 1) << 1));
+}
+
+template <int R, bool KMAJ> struct GldsImg { static constexpr int ELEMS = R * 64; };
+
+// byte offsets (inside one k-tile) of the chunks this thread moves: chunk c = tid + NTH * i lands at LDS chunk c
+template <int R, bool KMAJ, int ES, int NTH>
+__device__ __forceinline__ void glds_offsets(int (&v)[R * 8 / NTH], const OpSrc& src, int r0, int Rtot, int tid) {
+#pragma unroll
+    for (int i = 0; i < R * 8 / NTH; ++i) {
+        const int c = tid + NTH * i;
+        if (KMAJ) {
+            const int row = c >> 3, kc = (c & 7) ^ ((row >> 1) & 7);
+            v[i] = (min(r0 + row, Rtot - 1) * src.rs + kc * (16 / ES)) * ES;
+        } else {
+            const int kl = c / (R / 8), rc = ((c % (R / 8)) ^ glds_rx<R>(kl)) * 8;
+            v[i] = (kl * src.ks + min(r0 + rc, Rtot - 8)) * 2;
+        }
+    }
+}
+
+template <int R, bool KMAJ>
+__device__ __forceinline__ bf16x8_t glds_frag(const bf16* lds, int row0, int ks, int lane) {
+    if (KMAJ) return fast_frag<R, true>(lds, row0, ks, lane);
+    const int fr = lane & 15, fq = lane >> 4, q = fr >> 2, p = fr & 3;
+    const int k0 = ks + 8 * fq + q, c0 = (row0 >> 3) + (p >> 1);
+    const bf16* a0 = lds + k0 * R + ((c0 ^ glds_rx<R>(k0)) << 3) + (p & 1) * 4;
+    const bf16* a1 = lds + (k0 + 4) * R + ((c0 ^ glds_rx<R>(k0 + 4)) << 3) + (p & 1) * 4;
+    const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(a0));
+    const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(a1));
+    short8_t v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// One LDS-DMA instruction: 64 lanes x 16 bytes from buffer offset voff (per lane) + soff (scalar) to LDS bytes
+// [lds, lds + 1024).  Written as asm on purpose: for the builtin, hipcc's wait-count pass orders every LDS read it
+// cannot prove disjoint behind the DMA -- it put an s_waitcnt vmcnt(0) between the loads of tile t + 2 and the
+// ds_read_b64_tr_b16 of tile t, i.e. a full memory round trip into every iteration of the r-major loops (k-loop
+// 53 k -> 86 k cycles on the FFN dgrad).  The waits these loads need are the counted ones in the loop below.
+typedef int int4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void glds16(const int4v& rsrc, unsigned lds, int voff, int soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory");
+}
+__device__ __forceinline__ int4v raw_rsrc(const bf16* base, int64_t bytes) {
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    int4v r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) & 0xffff;
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+
+template <int BM, int BN, bool AK, bool BKM, bool F8, int W, int NS>
+__device__ __forceinline__ void gemm_kloop_glds(const GemmArgs& g, int tile_m, int tile_n, int bz, bf16* fsm,
+                                                float4_t (&acc)[BM / (8 * W)][BN / 32]) {
+    static_assert(!F8 || (AK && BKM), "fp8 operands are k-contiguous");
+    constexpr int NT = 64 * W;
+    constexpr int ES = F8 ? 1 : 2, KT = 128 / ES;
+    constexpr int NCA = BM * 8 / NT, NCB = BN * 8 / NT;  // LDS-DMA instructions per thread and k-tile
+    constexpr int WM = W / 2;
+    constexpr int TM = BM / (16 * WM), TN = BN / 32;
+    constexpr int AEL = BM * 64, STAGE = (BM + BN) * 64;
+    constexpr int G = NCA + NCB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wid >> 1) * (BM / WM), wn = (wid & 1) * (BN / 2);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    STAMP(g, 0);
+    STAMP_HW(g);
+    const bf16* A = reinterpret_cast<const bf16*>(reinterpret_cast<const char*>(g.A) + (int64_t)bz * g.a_bs * ES);
+    const bf16* B = reinterpret_cast<const bf16*>(reinterpret_cast<const char*>(g.B) + (int64_t)bz * g.b_bs * ES);
+    const int64_t bytes_a = AK ? ((int64_t)(g.M - 1) * g.a_rs + g.K) * ES : ((int64_t)(g.K - 1) * g.a_ks + g.a_rows) * 2;
+    const int64_t bytes_b = BKM ? ((int64_t)(g.N - 1) * g.b_ns + g.K) * ES : ((int64_t)(g.K - 1) * g.b_ks + g.b_rows) * 2;
+    const OpSrc sa = make_src(A, bytes_a, g.a_rs, g.a_ks);
+    const OpSrc sb = make_src(B, bytes_b, g.b_ns, g.b_ks);
+    const int4v ra = raw_rsrc(A, bytes_a), rb = raw_rsrc(B, bytes_b);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    int va[NCA], vb[NCB];
+    glds_offsets<BM, AK, ES, NT>(va, sa, m0, g.a_rows, tid);
+    glds_offsets<BN, BKM, ES, NT>(vb, sb, n0, g.b_rows, tid);
+    // a k-tile further on: k-major operands advance along the row, r-major ones by 64 k-rows
+    const int step_a = AK ? KT * ES : 64 * sa.ks * 2, step_b = BKM ? KT * ES : 64 * sb.ks * 2;
+    const int nk = g.K / KT;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(
+        (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(fsm) + wid * 1024);
+    auto issue = [&](int t, int stage) {
+        const unsigned dst = lds0 + stage * (STAGE * 2);
+        const int oa = __builtin_amdgcn_readfirstlane(t * step_a), ob = __builtin_amdgcn_readfirstlane(t * step_b);
+#pragma unroll
+        for (int i = 0; i < NCA; ++i) glds16(ra, dst + i * NT * 16, va[i], oa);
+#pragma unroll
+        for (int i = 0; i < NCB; ++i) glds16(rb, dst + AEL * 2 + i * NT * 16, vb[i], ob);
+    };
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) issue(s, s);
+    STAMP(g, 1);
+    int stage = 0;
+    for (int t = 0; t < nk; ++t) {
+        // tile t has landed once at most the (NS - 2) younger tiles are still in flight
+        if (NS == 2 || t + NS - 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * G) : "memory");
+        lds_barrier();  // every wave's part of tile t is visible; stage (t - 1) % NS has been read by everyone
+        if (t + NS - 1 < nk) issue(t + NS - 1, stage == 0 ? NS - 1 : stage - 1);
+        const bf16* Ac = fsm + stage * STAGE;
+        const bf16* Bc = Ac + AEL;
+#pragma unroll
+        for (int ks = 0; ks < 64; ks += 32) {
+            bf16x8_t a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = glds_frag<BM, AK>(Ac, wm + i * 16, ks, lane);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = glds_frag<BN, BKM>(Bc, wn + j * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    if constexpr (F8) {
+                        typedef long long2_t __attribute__((ext_vector_type(2)));
+                        const long2_t a8 = __builtin_bit_cast(long2_t, a[i]), b8 = __builtin_bit_cast(long2_t, b[j]);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(b8[0], a8[0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(b8[1], a8[1], acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+                    }
+        }
+        stage = stage + 1 == NS ? 0 : stage + 1;
+    }
+    lds_barrier();  // every wave is done with the last stage: LDS is free for the epilogue
+    STAMP(g, 2);
+}
+
+// K a whole number of k-tiles (no partial chunk to zero on the way, no tile to skip), r-major rows readable in
+// whole 16-byte chunks
+template <bool F8> __host__ __device__ __forceinline__ bool glds_ok(const GemmArgs& g) {
+    constexpr int KT = F8 ? 128 : 64;
+    return g.use_glds && g.K % KT == 0 && !g.a_tail && !g.b_tail && (g.a_mode == 1 || g.a_rows >= 8) &&
+           (g.b_mode == 1 || g.b_rows >= 8);
 }
 
 // epilogue of one tile (shared by every operand-layout variant of the k-loop: ONE copy of its code per kernel)
@@ -740,7 +1042,10 @@ __device__ __forceinline__ void gemm_finish(const GemmArgs& g, int tile_m, int t
         if (keep == 123.456f) reinterpret_cast<float*>(g.C)[threadIdx.x] = keep;
         return;
     }
-    epilogue_staged<BM, BN, TM, TN, W>(g, acc, m0, n0, bz, reinterpret_cast<float*>(fsm), wm, wn);
+    const int kind = epilogue_kind(g, bz);
+    if (kind == 0) epilogue_direct<BM, BN, TM, TN, W, 0>(g, acc, m0, n0, bz, reinterpret_cast<float*>(fsm), wm, wn);
+    else if (kind == 1) epilogue_direct<BM, BN, TM, TN, W, 1>(g, acc, m0, n0, bz, reinterpret_cast<float*>(fsm), wm, wn);
+    else epilogue_staged<BM, BN, TM, TN, W>(g, acc, m0, n0, bz, reinterpret_cast<float*>(fsm), wm, wn);
     STAMP(g, 4);
 }
 
@@ -761,6 +1066,11 @@ __device__ __forceinline__ int xcd_remap(int L, int nb) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// (One level further down -- the CU's own L1 -- was measured and buys nothing: HW_ID stamps (tools/gemm_wg_map.py) show
+// that an XCD's q-th and (q + 32)-th workgroups start on the same CU within ~15 cycles of each other, so renumbering
+// the blocks puts the co-resident workgroups of a CU on neighbouring tiles of one tile row, asking for the same A
+// panel at the same time.  k-loop cycles of the forward pairs did not move (16.80 k -> 16.78 k per 128 x 64 x 768
+// tile), and the backward groups lost 15-20 % because a grid-wide renumbering breaks the longest-K-first order.)
 // The same idea in two dimensions.  An XCD that owns a run of whole tile rows pulls every B panel into its L2
 // (8 copies of B across the chip); an xr x xc arrangement of the XCDs over the tile grid fetches A xc times and
 // B xr times instead.  Position p of the XCD-contiguous order (xcd_remap) is read rectangle-major: bands of rh
@@ -847,6 +1157,7 @@ struct GroupArgs {
     GemmArgs p[MAX_GROUP];
     int tile_start[MAX_GROUP + 1];
     int nprob;
+    int stages;  // LDS stages of the LDS-DMA k-loop (2 or 3), chosen per launch: see launch_grouped_tile
 };
 
 template <int BM, int BN, int W = 4>
@@ -878,7 +1189,20 @@ __global__ __launch_bounds__(64 * W, (W == 8 ? 2 : min_waves<BM, BN>())) void ge
     }
     constexpr int DK = (BM * BN <= 64 * 64) ? 4 : 2;  // prefetch depth when an operand is k-major
     float4_t acc[BM / (8 * W)][BN / 32];
-    if (g.a_mode == 1) {
+    if (glds_ok<false>(g)) {
+#define XGGM_GLDS_FORMS(NS)                                                                                          \
+    if (g.a_mode == 1) {                                                                                             \
+        if (g.b_mode == 1) gemm_kloop_glds<BM, BN, true, true, false, W, NS>(g, tile_m, tile_n, bz, fsm, acc);       \
+        else gemm_kloop_glds<BM, BN, true, false, false, W, NS>(g, tile_m, tile_n, bz, fsm, acc);                    \
+    } else {                                                                                                         \
+        if (g.b_mode == 1) gemm_kloop_glds<BM, BN, false, true, false, W, NS>(g, tile_m, tile_n, bz, fsm, acc);      \
+        else gemm_kloop_glds<BM, BN, false, false, false, W, NS>(g, tile_m, tile_n, bz, fsm, acc);                   \
+    }
+        if (ga.stages == 2) { XGGM_GLDS_FORMS(2) }
+        else if (ga.stages == 3) { XGGM_GLDS_FORMS(3) }
+        else { XGGM_GLDS_FORMS(4) }
+#undef XGGM_GLDS_FORMS
+    } else if (g.a_mode == 1) {
         if (g.b_mode == 1) gemm_kloop<BM, BN, true, true, DK, false, W>(g, tile_m, tile_n, bz, fsm, acc);
         else gemm_kloop<BM, BN, true, false, DK, false, W>(g, tile_m, tile_n, bz, fsm, acc);
     } else {
@@ -895,14 +1219,25 @@ template <int BM, int BN, int W = 4> int launch_grouped_tile(GroupArgs& ga, hipS
         total += ceil_div(ga.p[i].M, BM) * ceil_div(ga.p[i].N, BN) * ga.p[i].batch;
     }
     ga.tile_start[ga.nprob] = total;
+    // Stages of the LDS-DMA k-loop (NS - 1 k-tiles in flight per workgroup).  On L2-hot operands (a micro-benchmark
+    // that relaunches the same problem) two stages win wherever a third costs a resident workgroup (72 KB per 128 x 64
+    // workgroup = two per CU; FFN forward pair, 672 tiles: 18.8 us with two stages, 21.4 with three).  Inside the
+    // training step the weights arrive from HBM, every k-step of every tile waits for lines nobody has touched yet,
+    // and depth beats occupancy: rocprofv3 averages over the step, registers | 2 | 3 | 4 stages --
+    // 128 x 64: 36.5 | 37.2 | 35.2 | 46.6 us (four stages = one workgroup per CU), 64 x 64: 15.3 | 17.9 | 14.6 | 15.4,
+    // 128 x 128 on 8 waves: 18.1 | 20.6 | 17.4 | 17.5.  Three everywhere except the 4-wave 128 x 128 tile (3 x 64 KB
+    // would leave one workgroup per CU where two fit).
+    ga.stages = g_glds_stages ? g_glds_stages : (BM * BN == 128 * 128 && W == 4) ? 2 : 3;
+    while (ga.stages > 2 && ga.stages * sizeof(bf16) * (BM + BN) * 64 > 160 * 1024) --ga.stages;
     // LDS of the largest operand images this group actually uses (r-major images carry padding)
     size_t lds = 0;
     for (int i = 0; i < ga.nprob; ++i) {
         const size_t a = ga.p[i].a_mode == 1 ? OpLds<BM, true>::ELEMS : OpLds<BM, false>::ELEMS;
         const size_t b = ga.p[i].b_mode == 1 ? OpLds<BN, true>::ELEMS : OpLds<BN, false>::ELEMS;
-        lds = std::max(lds, 2 * sizeof(bf16) * (a + b));
+        lds = std::max(lds, glds_ok<false>(ga.p[i]) ? ga.stages * sizeof(bf16) * (BM + BN) * 64 : 2 * sizeof(bf16) * (a + b));
     }
-    constexpr size_t lds_max = 2 * sizeof(bf16) * (OpLds<BM, false>::ELEMS + OpLds<BN, false>::ELEMS);
+    constexpr size_t lds_max = std::max<size_t>(2 * sizeof(bf16) * (OpLds<BM, false>::ELEMS + OpLds<BN, false>::ELEMS),
+                                                std::min<size_t>(160 * 1024, 4 * sizeof(bf16) * (BM + BN) * 64));
     static bool attr_set = false;
     if (lds_max > 48 * 1024 && !attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_grouped_kernel<BM, BN, W>),
@@ -1075,7 +1410,7 @@ template <typename T> int launch(GemmArgs g, int batch, hipStream_t stream) {
         g.bias = bias; g.residual = residual; g.preact = preact; g.aux = aux; g.colsum = colsum; g.sqsum = nullptr;   \
         g.c8 = nullptr; g.c8_qscale = nullptr; g.c8_amax = nullptr; g.scale_a = g.scale_b = nullptr;                     \
         g.act = act; g.c_f32 = c_f32; g.accumulate = accumulate; g.alpha = alpha;                                     \
-        g.a_mode = g.b_mode = 0; g.xcd_swizzle = g_xcd_swizzle; g.batch = batch; SET_STAMP(g); \
+        g.a_mode = g.b_mode = 0; g.xcd_swizzle = g_xcd_swizzle; g.batch = batch; g.use_glds = g_glds; SET_STAMP(g); \
         return launch<T>(g, batch, stream);                                                                            \
     }
 
@@ -1104,7 +1439,7 @@ extern "C" int xggm_gemm_fp8e4m3(const void* A, const void* B, void* C, int M, i
     g.c8 = nullptr; g.c8_qscale = nullptr; g.c8_amax = nullptr; g.scale_a = g.scale_b = nullptr;
     g.act = act; g.c_f32 = c_f32; g.accumulate = 0; g.alpha = 1.0f;
     g.a_mode = g.b_mode = 1; g.a_tail = g.b_tail = 0; g.a_rows = M; g.b_rows = N;
-    g.xcd_swizzle = g_xcd_swizzle; g.batch = 1; SET_STAMP(g);
+    g.xcd_swizzle = g_xcd_swizzle; g.batch = 1; g.use_glds = g_glds; SET_STAMP(g);
     switch (g_tile_override) {  // same pins as the bf16 kernels (xggm_gemm_set_tile); default 64 x 64, depth 4
         case 3: return launch_fp8_tile<128, 64, 2>(g, scale_a, scale_b, stream);
         case 5: return launch_fp8_tile<128, 128, 2>(g, scale_a, scale_b, stream);
@@ -1122,6 +1457,8 @@ extern "C" int xggm_gemm_set_generic(int on) {
 extern "C" int xggm_gemm_set_tile(int variant) {
     g_tile_override = variant & 0xff;
     g_xcd_swizzle = (variant & 0x100) ? 0 : 1;
+    g_glds = (variant & 0x400) ? 0 : 1;
+    g_glds_stages = (variant & 0x800) ? 2 : (variant & 0x1000) ? 3 : (variant & 0x2000) ? 4 : 0;
     return XGGM_OK;
 }
 
@@ -1136,7 +1473,7 @@ GemmArgs from_problem(const xggm_gemm_problem& p) {
     g.c8 = reinterpret_cast<unsigned char*>(p.c8); g.c8_qscale = p.c8_qscale; g.c8_amax = p.c8_amax;
     g.scale_a = p.scale_a; g.scale_b = p.scale_b;
     g.act = p.act; g.c_f32 = p.c_f32; g.accumulate = p.accumulate; g.alpha = p.alpha;
-    g.a_mode = g.b_mode = 0; g.xcd_swizzle = g_xcd_swizzle; g.batch = p.batch; SET_STAMP(g);
+    g.a_mode = g.b_mode = 0; g.xcd_swizzle = g_xcd_swizzle; g.batch = p.batch; g.use_glds = g_glds; SET_STAMP(g);
     return g;
 }
 
