@@ -344,7 +344,7 @@ def pmc_traffic(family):
     key = {"xggm_gemm_bf16": "gemm_", "xggm_bertadam_f32": "bertadam_kernel", "xggm_bertadam_ex": "bertadam_kernel",
            "xggm_ln_bwd_bf16": "ln_bwd_kernel",
            "xggm_ln_fwd_bf16": "ln_fwd_kernel", "xggm_attn_bwd_bf16": "attn_bwd", "xggm_attn_fwd_bf16": "attn_fwd",
-           "xggm_aggregate_bf16": "aggregate_kernel"}.get(family)
+           "xggm_aggregate_bf16": "aggregate_"}.get(family)
     if key is None:
         return None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):

@@ -503,6 +503,14 @@ int xggm_zero_diag_f32(const float* in, float* out, int B, int N, xggm_stream_t 
 int xggm_additive_mask(const int64_t* mask, float* out, int64_t n, xggm_stream_t stream);
 /* *out = *a + *b + *c + *d (NULL terms skipped): the sum of the loss terms of a pass, src/vqa/vqacpv2.py:220-221 */
 int xggm_add_scalars_f32(const float* a, const float* b, const float* c, const float* d, float* out, xggm_stream_t stream);
+/* out = a + b (+ c (+ d)), n elements, summed in fp32 and rounded once; out may alias an input.  Replaces the sums
+ * torch's autograd engine forms (at::add) where a tensor of the training loop feeds several consumers
+ * (reference: x, feat_seq[1], node_feats, adj_noise in src/vqa/vqacpv2.py:195-251). */
+int xggm_add_n_f32(const float* a, const float* b, const float* c, const float* d, float* out, int64_t n, xggm_stream_t stream);
+int xggm_add_n_bf16(const void* a, const void* b, const void* c, const void* d, void* out, int64_t n, xggm_stream_t stream);
+/* dst [rows, ld] bf16 = cast(src [rows, n], fp32 if src_f32 else bf16), columns n .. ld - 1 zero: the padded row stride
+ * the backward products of an odd-width output run on (answer logits of src/vqa/vqacpv2_model.py:63-70). */
+int xggm_pad_rows_bf16(const void* src, int src_f32, void* dst, int rows, int n, int ld, xggm_stream_t stream);
 /* zero up to 16 element ranges [offset[i], offset[i] + length[i]) of one fp32 buffer in ONE launch: the
  * atomically accumulated gradient ranges of all parameter groups at the start of a backward pass.
  * offsets / lengths are HOST arrays (copied into the kernel arguments); both multiples of 4. */

@@ -152,7 +152,7 @@ def test_two_data_parallel_ranks_on_one_gpu_stay_identical():
     assert "overlapped vs plain exchange: relative parameter difference 0.00e+00" in r.stdout
     # the sharded update (ZeRO-1) on the wire arena: eager, two-graph and staged engines
     assert r.stdout.count("bf16 weights identical on both ranks: True") == 3
-    assert "sharded vs replicated update, 3 iteration(s): relative parameter difference" in r.stdout
+    assert "sharded vs replicated update, 3 iterations: relative parameter difference" in r.stdout
 
 
 def test_bench_on_a_one_rank_rccl_group():

@@ -1100,3 +1100,50 @@ def test_cosine_adjacency_matches_reference_golden_and_oracle(ops):
         compute_cosin_sim_v2(torch.zeros(1, 4, 6, device=DEV), torch.zeros(1, 4, 6, device=DEV))
     with pytest.raises(RuntimeError, match="GPU"):
         compute_cosin_sim_v2(torch.zeros(4, 8), torch.zeros(4, 8))
+
+
+def test_add_n_pad_rows_and_fan_out(ops):
+    """the kernels that replaced the framework's glue inside a pass: xggm_add_n (sum of 2..4 tensors, fp32 arithmetic,
+    one rounding; may write over an input), xggm_pad_rows_bf16 (cast + zero-padded row stride in one launch) and
+    functional.fan_out (gradients of several consumers meet in ONE launch; values and gradients of plain reuse)."""
+    from xggm_amd import functional as XF
+    F32, BF = torch.float32, torch.bfloat16
+    gen = torch.Generator().manual_seed(5)
+    for dt in (F32, BF):
+        ts = [torch.randn(7, 33, 5, generator=gen).to(dt) for _ in range(4)]
+        for n in (2, 3, 4):
+            got = ops.add_n([t.to(DEV) for t in ts[:n]]).cpu()
+            ref = sum(t.double() for t in ts[:n]).to(dt)  # fp64 sum rounded once == fp32 sum rounded once here
+            assert float((got.double() - ref.double()).abs().max()) <= (0 if dt == F32 else 1e-2) + 1e-6
+        a, b = ts[0].to(DEV), ts[1].to(DEV)
+        want = ops.add_n([a, b]).clone()
+        assert torch.equal(ops.add_n([a, b], out=a), want) and torch.equal(a, want)
+    x = torch.randn(5, 630, generator=gen)
+    for src in (x, x.to(BF)):
+        p = ops.pad_rows(src.to(DEV), 632)
+        assert p.shape == (5, 630) and p.stride() == (632, 1) and p.dtype == BF
+        assert torch.equal(p.cpu(), src.to(BF))
+        full = torch.as_strided(p, (5, 632), (632, 1))
+        assert float(full[:, 630:].abs().max()) == 0.0
+    with pytest.raises(RuntimeError, match="pad_rows"):
+        _lib_call_bad_pad()
+    # fan_out: three consumers with different weights
+    w = [0.5, -2.0, 3.0]
+    for dt in (F32, BF):
+        v = torch.randn(4, 36, 16, generator=gen).to(dt).to(DEV).requires_grad_(True)
+        parts = XF.fan_out(v, 3)
+        assert all(torch.equal(p, v) for p in parts)
+        sum((p.float() * c).sum() for p, c in zip(parts, w)).backward()
+        ref = torch.full_like(v, sum(w))
+        assert float((v.grad.float() - ref.float()).abs().max()) < (1e-6 if dt == F32 else 2e-2)
+    v = torch.randn(3, 8, device=DEV, requires_grad=True)
+    a, b = XF.fan_out(v, 2)
+    (a.sum() * 2).backward()  # one consumer never used: its gradient is None, not a zero fill
+    assert torch.equal(v.grad, torch.full_like(v, 2.0))
+
+
+def _lib_call_bad_pad():
+    from xggm_amd import _lib
+    x = torch.zeros(4, 8, device=DEV)
+    out = torch.zeros(4, 4, device=DEV, dtype=torch.bfloat16)
+    _lib.call("xggm_pad_rows_bf16", x.data_ptr(), 1, out.data_ptr(), 4, 8, 4, None)

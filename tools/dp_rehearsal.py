@@ -28,9 +28,13 @@ def run(overlap, rank, use_graph=True, iters=("rel", "node", "rel"), layers=(2, 
     opt = make_optimizer(m, 1e-3, 20)
     enable_data_parallel(m, wire_dtype=torch.bfloat16, overlap=overlap, zero1=zero1)
     tr = CapturedTrainer(m, opt, b, sigma=1.0, order="vqa", use_graph=use_graph, warmup_iters=1)
+    norms = []
     for br in iters:
-        tr.iteration(br)
+        outs = [tr.run_pass("plain")] if br == "plain" else tr.iteration(br)
+        for out in outs:
+            norms.append(float(out[2]))  # the clip norm of the pass
     torch.cuda.synchronize()
+    run.norms = norms
     run.names = [(n, p.numel()) for n, p in m.named_parameters()]
     arena = m.arena()
     if want == "shadow":  # what the GEMMs read: must be identical on every rank after the all-gather
@@ -79,20 +83,35 @@ def check_sharded(rank):
             print("sharded update overlap=%s graphs=%s: bf16 weights identical on both ranks: %s" % (overlap, use_graph, same),
                   flush=True)
         assert same
-    # One iteration: the two runs differ only in the order the clip norm is summed in (an ulp of the coefficient).
-    # Three iterations: that ulp has been through bf16 roundings and BertAdam's sign-like first steps (m / sqrt(v) is
-    # +-3.16 whatever |g| is), so single elements move by ~lr; the bound only says "same training", as it would for
-    # any two orders of a floating-point sum.
-    for iters, bound in ((("rel",), 1e-5), (("rel", "node", "rel"), 5e-3)):
+    # ONE PASS (the plain one): the two runs differ only in the order the clip norm is summed in -- an ulp of the clip
+    # coefficient.  More passes: that ulp goes through bf16 roundings of the weights, BertAdam's sign-like first steps
+    # (m / sqrt(v) is +-3.16 whatever |g| is) and the DISCRETE steps of the generation pass (column arg-max of the
+    # adjacency regeneration, masked entries): one flipped decision changes its gradients by per cents (measured: a
+    # 4e-6 difference of the first pass's norm -> 0.7 % of the second pass's), so the bound only says "same training",
+    # as it would for any two orders of a floating-point sum.
+    for iters, bound in ((("plain",), 1e-5), (("rel", "node", "rel"), 5e-3)):
         ref = run(True, rank, layers=(5, 4, 4), iters=iters)
+        n_ref = run.norms
         got = run(True, rank, layers=(5, 4, 4), zero1=True, iters=iters)
+        if rank == 0:
+            print("   clip norms per pass, replicated: %s\n   clip norms per pass, sharded:    %s" % (
+                " ".join("%.6f" % v for v in n_ref), " ".join("%.6f" % v for v in run.norms)), flush=True)
         other = [torch.empty_like(got) for _ in range(2)]
         dist.all_gather(other, got)
         assert torch.equal(other[0], other[1]), "fp32 masters differ after gather_state"
         d = float((got - ref).double().norm() / ref.double().norm())
         if rank == 0:
-            print("sharded vs replicated update, %d iteration(s): relative parameter difference %.2e" % (len(iters), d),
+            print("sharded vs replicated update, %s: relative parameter difference %.2e" % ("one pass" if iters == ("plain",) else "%d iterations" % len(iters), d),
                   flush=True)
+            if d >= bound:  # which tensors?
+                o, worst = 0, []
+                for n, k in run.names:
+                    dd = (got[o:o + k] - ref[o:o + k]).abs()
+                    worst.append((float(dd.max()), float((dd > 0).float().mean()), n, k))
+                    o += k
+                worst.sort(reverse=True)
+                for w in worst[:12]:
+                    print("   max |diff| %.3e, %.0f %% of elements differ: %s (%d)" % (w[0], 100 * w[1], w[2], w[3]), flush=True)
         assert d < bound
 
 

@@ -127,11 +127,54 @@ __global__ void add_scalars_kernel(const float* a, const float* b, const float* 
 }
 }  // namespace
 
+// out = a + b (+ c + d): the sum autograd forms where a tensor feeds several consumers (xggm_amd.functional.FanOutFn),
+// in fp32, rounded once; `out` may alias any input.
+template <typename T>
+__global__ __launch_bounds__(NT) void add_n_kernel(const T* a, const T* b, const T* c, const T* d, T* out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        float v = to_f32(a[i]) + to_f32(b[i]);
+        if (c) v += to_f32(c[i]);
+        if (d) v += to_f32(d[i]);
+        out[i] = from_f32<T>(v);
+    }
+}
+
+// dst [rows, ld] (bf16) = cast(src [rows, n]) with zeros in columns n .. ld - 1: a row stride the tuned GEMM path accepts
+// for outputs whose width is not a multiple of 8 (2274 answers, 630 edges)
+template <typename S>
+__global__ __launch_bounds__(NT) void pad_rows_kernel(const S* __restrict__ src, bf16* __restrict__ dst, int64_t total, int n,
+                                                      int ld) {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int64_t r = i / ld;
+        const int c = (int)(i - r * ld);
+        dst[i] = c < n ? from_f32<bf16>(to_f32(src[r * n + c])) : from_f32<bf16>(0.f);
+    }
+}
+
 extern "C" int xggm_zero_diag_f32(const float* in, float* out, int B, int N, hipStream_t st) {
     XGGM_REQUIRE(in && out && B > 0 && N > 0, "xggm_zero_diag_f32: bad arguments");
     const int64_t total = (int64_t)B * N * N;
     hipLaunchKernelGGL(zero_diag_kernel, dim3(grid1d(total)), dim3(NT), 0, st, in, out, total, N);
     return xggm_check_launch("xggm_zero_diag_f32");
+}
+
+extern "C" int xggm_add_n_f32(const float* a, const float* b, const float* c, const float* d, float* out, int64_t n, hipStream_t st) {
+    XGGM_REQUIRE(a && b && out && n > 0 && (c || !d), "xggm_add_n_f32: bad arguments");
+    hipLaunchKernelGGL(add_n_kernel<float>, dim3(grid1d(n)), dim3(NT), 0, st, a, b, c, d, out, n);
+    return xggm_check_launch("xggm_add_n_f32");
+}
+extern "C" int xggm_add_n_bf16(const void* a, const void* b, const void* c, const void* d, void* out, int64_t n, hipStream_t st) {
+    XGGM_REQUIRE(a && b && out && n > 0 && (c || !d), "xggm_add_n_bf16: bad arguments");
+    hipLaunchKernelGGL(add_n_kernel<bf16>, dim3(grid1d(n)), dim3(NT), 0, st, (const bf16*)a, (const bf16*)b, (const bf16*)c,
+                       (const bf16*)d, (bf16*)out, n);
+    return xggm_check_launch("xggm_add_n_bf16");
+}
+extern "C" int xggm_pad_rows_bf16(const void* src, int src_f32, void* dst, int rows, int n, int ld, hipStream_t st) {
+    XGGM_REQUIRE(src && dst && rows > 0 && n > 0 && ld >= n, "xggm_pad_rows_bf16: bad arguments (rows %d, n %d, ld %d)", rows, n, ld);
+    const int64_t total = (int64_t)rows * ld;
+    if (src_f32) hipLaunchKernelGGL(pad_rows_kernel<float>, dim3(grid1d(total)), dim3(NT), 0, st, (const float*)src, (bf16*)dst, total, n, ld);
+    else hipLaunchKernelGGL(pad_rows_kernel<bf16>, dim3(grid1d(total)), dim3(NT), 0, st, (const bf16*)src, (bf16*)dst, total, n, ld);
+    return xggm_check_launch("xggm_pad_rows_bf16");
 }
 
 extern "C" int xggm_additive_mask(const int64_t* mask, float* out, int64_t n, hipStream_t st) {

@@ -514,9 +514,67 @@ class PairFn(Function):
                 if link is not None:  # the vision direction accumulated into the language direction's buffers
                     assert dv_q is dx_v and dv_kv is dx_l
                 else:
-                    dx_v = dv_q if dx_v is None else dx_v.add_(dv_q)
-                    dx_l = dv_kv if dx_l is None else dx_l.add_(dv_kv)
+                    dx_v = dv_q if dx_v is None else ops.add_n([dx_v, dv_q], out=dx_v)
+                    dx_l = dv_kv if dx_l is None else ops.add_n([dx_l, dv_kv], out=dx_l)
         return (None, None, None, dx_l, dx_v, None, None, None, None) + (None,) * ctx.np
+
+
+# --------------------------------------------------------------------------------- fan-out
+class FanOutFn(Function):
+    """``n`` aliases of one tensor for ``n`` consumers.  Where a tensor of the training loop is used more than once
+    (x, feat_seq[1], node_feats, adj_noise in src/vqa/vqacpv2.py:195-251) torch's autograd engine adds the consumers'
+    gradients with at::add, one framework kernel per extra consumer; routed through here the sum is ONE launch of
+    xggm_add_n (fp32 arithmetic, rounded once).  Values and gradients are those of plain multiple use."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g.contiguous() for g in gs if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        if len(gs) <= 4:
+            return ops.add_n(gs), None
+        acc = ops.add_n(gs[:4])
+        for k in range(4, len(gs), 3):
+            acc = ops.add_n([acc] + gs[k:k + 3], out=acc)
+        return acc, None
+
+
+def fan_out(x, n):
+    return FanOutFn.apply(x, n) if (n > 1 and x.requires_grad) else (x,) * n
+
+
+class FirstTokenFn(Function):
+    """``hidden_states[:, 0]`` (src/lxrt/modeling.py:616): the strided view forward; backward writes the gradient rows
+    into a buffer of our own zeroing (autograd's select backward is a framework fill plus a strided copy)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = x.shape
+        return x[:, 0]
+
+    @staticmethod
+    def backward(ctx, g):
+        B, S, H = ctx.shape
+        if g.dtype != torch.bfloat16:  # fp32 parity mode: the framework's way
+            full = g.new_zeros(B, S, H)
+            full[:, 0] = g
+            return full
+        # rows of width H in a row stride of S * H, zeros behind them: exactly xggm_pad_rows
+        return _first_token_grad(g.contiguous(), B, S, H)
+
+
+def _first_token_grad(g, B, S, H):
+    out = torch.empty((B, S * H), device=g.device, dtype=g.dtype)
+    ops.call("xggm_pad_rows_bf16", ops.ptr(g), 0, ops.ptr(out), B, H, S * H, ops.stream())
+    return out.view(B, S, H)
+
 
 
 # --------------------------------------------------------------------------------- heads
@@ -548,12 +606,14 @@ class LinearActFn(Function):
         elif act == ops.ACT_TANH:
             g = ops.tanh_bwd(dy, y)
         else:
-            g = ops.cast_from_f32(dy, dt) if dy.dtype == F32 and dt != F32 else dy
+            g = dy
         if g.shape[1] % 8 and dt != F32:
             # an output width that is not a multiple of 8 (2274 answers, 630 edges): zero-pad the row stride so the
             # backward products run on the tuned GEMM path (see pick_mode in gemm.hip) instead of the generic kernel
-            N = g.shape[1]
-            g = torch.nn.functional.pad(g, (0, (-N) % 8))[:, :N]
+            # (cast + pad in one launch of ours; F.pad was a fill and a strided copy of the framework's)
+            g = ops.pad_rows(g, g.shape[1] + (-g.shape[1]) % 8)
+        elif g.dtype == F32 and dt != F32:
+            g = ops.cast_from_f32(g, dt)
         if lin.bias is not None:
             _colsum(rt, g, lin.bias)
         probs, dx = [_p_wgrad(rt, g, x2, lin.weight)], None
@@ -664,7 +724,7 @@ class GCNFn(Function):
             ops.aggregate(adj, d_agg, mode=ops.AGG_TRANSPOSE, out=dh[k].view(B, N, H))
             if ctx.needs_input_grad[3]:
                 g = ops.bmm_nt(d_agg, hs[k])
-                d_adj = g if d_adj is None else d_adj.add_(g)
+                d_adj = g if d_adj is None else ops.add_n([d_adj, g], out=d_adj)
         dx = dh[0].view(B, N, H) if ctx.needs_input_grad[2] else None
         return (None, None, dx, d_adj) + (None,) * ctx.np
 
@@ -756,11 +816,12 @@ class AdjInitFn(Function):
     def forward(ctx, e, N, sigma, randn, rng, sid):
         adj, g = ops.adj_init_fwd(e.contiguous(), N, sigma, randn=randn, rng=rng, sid=sid)
         ctx.mark_non_differentiable(g)
+        ctx.set_materialize_grads(False)  # no zero-filled "gradient" of g (a framework fill per pass)
         return adj, g
 
     @staticmethod
     def backward(ctx, d_adj, _):
-        return ops.adj_init_bwd(d_adj.contiguous()), None, None, None, None, None
+        return (None if d_adj is None else ops.adj_init_bwd(d_adj.contiguous())), None, None, None, None, None
 
 
 class FeatureNoiseFn(Function):
@@ -770,6 +831,7 @@ class FeatureNoiseFn(Function):
     def forward(ctx, x, sigma, randn, rng, sid):
         out, g = ops.feature_noise(x.contiguous(), sigma, randn=randn, rng=rng, sid=sid)
         ctx.mark_non_differentiable(g)
+        ctx.set_materialize_grads(False)
         return out, g
 
     @staticmethod

@@ -399,7 +399,7 @@ class BertPooler(nn.Module):
 
     def forward(self, hidden_states):
         rt = runtime_of(self)
-        first_token_tensor = hidden_states[:, 0]  # strided rows, read in place by the GEMM
+        first_token_tensor = XF.FirstTokenFn.apply(hidden_states)  # hidden_states[:, 0]: strided rows, read in place
         return XF.LinearActFn.apply(rt, self.dense, first_token_tensor, ops.ACT_TANH, False, *self.dense.parameters())
 
 

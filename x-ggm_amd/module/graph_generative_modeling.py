@@ -13,7 +13,8 @@ class _Generator(nn.Module):
         """(x or adj) sampling from noise.  x [bs, n_node, hidden], adj [bs, n_node, n_node]"""
         for layer in range(self.n_layers):
             x = self.gnn_layers[layer](x, adj)
-            adj = XF.RegenFn.apply(x)  # bmm(x, x^T) / column max -> sigmoid -> zero diagonal
+            x, x_r = XF.fan_out(x, 2)    # x feeds the regeneration AND the next layer: their gradients meet in one launch
+            adj = XF.RegenFn.apply(x_r)  # bmm(x, x^T) / column max -> sigmoid -> zero diagonal
         return x, adj
 
 

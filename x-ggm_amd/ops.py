@@ -882,6 +882,30 @@ def zero_diag(adj):
     return out
 
 
+def add_n(terms, out=None):
+    """sum of 2..4 same-shaped contiguous tensors (fp32 or bf16) in ONE launch, fp32 arithmetic; ``out`` may be one of
+    them"""
+    assert 2 <= len(terms) <= 4
+    t0 = terms[0]
+    for t in terms:
+        assert t.is_cuda and t.dtype == t0.dtype and t.shape == t0.shape and t.is_contiguous()
+    if out is None:
+        out = torch.empty_like(t0)
+    ps = [ptr(t) for t in terms] + [None] * (4 - len(terms))
+    call("xggm_add_n_f32" if t0.dtype == F32 else "xggm_add_n_bf16", ps[0], ps[1], ps[2], ps[3], ptr(out), t0.numel(),
+         stream())
+    return out
+
+
+def pad_rows(x, ld):
+    """[rows, n] fp32 / bf16 -> bf16 [rows, ld] with zero columns n.. (one launch); returns the [rows, n] VIEW with row
+    stride ld"""
+    assert x.dim() == 2 and x.is_cuda and x.is_contiguous() and x.dtype in (F32, BF16) and ld >= x.shape[1]
+    out = torch.empty((x.shape[0], ld), device=x.device, dtype=BF16)
+    call("xggm_pad_rows_bf16", ptr(x), int(x.dtype == F32), ptr(out), x.shape[0], x.shape[1], ld, stream())
+    return out[:, :x.shape[1]]
+
+
 def add_scalars(terms):
     """sum of up to four 0-dim fp32 device tensors"""
     ts = [_c(t, F32) for t in terms]

@@ -132,26 +132,31 @@ def forward_backward_ggm(model, bce_loss, feats, boxes, sent, target, adj_true, 
     N = feat_seq[1].shape[1]
     A = target.size(1)
     rt.begin_losses(4)  # the three loss kernels accumulate into slots of one buffer zeroed by one launch
+    # tensors the reference uses more than once go through XF.fan_out: same values, same gradients, but the sum of
+    # the consumers' gradients is one launch of ours instead of the autograd engine's at::add per extra consumer
+    x, x_fuse = XF.fan_out(x, 2)
     if branch == "rel":
         e = model.encoder_adj(x)
         adj_noise, grad_log_noise = XF.AdjInitFn.apply(e, N, sigma, randn, None if randn is not None else rt.rng, 9001)
         node_feats, adj_noise = model.generator(feat_seq[1], adj_noise)
+        adj_noise, adj_kl = XF.fan_out(adj_noise, 2)
         # loss = bce * A + 6 * (kl_weight * (kl * A) + dsm), the weights folded into the loss kernels
         w_kl, w_dsm = 6.0 * kl_weight * A, 6.0
         loss_grad = loss_func(adj_noise, grad_log_noise, sigma=sigma, scale=w_dsm, slot=rt.scalar_slot())
-        d_loss = compute_kl_loss(adj_true, adj_noise, scale=w_kl, slot=rt.scalar_slot())
+        d_loss = compute_kl_loss(adj_true, adj_kl, scale=w_kl, slot=rt.scalar_slot())
     elif branch == "node":
         node_feats = XF.BcastRowsFn.apply(model.node_fc(x), N)  # == node_fc(x.unsqueeze(1).repeat(1, N, 1))
         node_feats, feat_grad = XF.FeatureNoiseFn.apply(node_feats, sigma, randn,
                                                         None if randn is not None else rt.rng, 9002)
         node_feats, _ = model.generator(node_feats, adj_true)
+        node_feats, node_kl, node_dsm = XF.fan_out(node_feats, 3)
         # loss = bce * A + 1.1 * (0.15 * (kl * A) + 6 * dsm)
         w_kl, w_dsm = 1.1 * 0.15 * A, 1.1 * 6.0
-        d_loss = compute_kl_loss(node_feats, feat_seq[1], scale=w_kl, slot=rt.scalar_slot())
-        loss_grad = loss_func(node_feats, feat_grad, sigma=sigma, scale=w_dsm, slot=rt.scalar_slot())
+        d_loss = compute_kl_loss(node_kl, feat_seq[1], scale=w_kl, slot=rt.scalar_slot())
+        loss_grad = loss_func(node_dsm, feat_grad, sigma=sigma, scale=w_dsm, slot=rt.scalar_slot())
     else:
         raise ValueError(branch)
-    x_gen = model.fusion_fc(XF.PoolConcatFn.apply(x, node_feats))
+    x_gen = model.fusion_fc(XF.PoolConcatFn.apply(x_fuse, node_feats))
     logit = model.logit_fc(x_gen)
     loss = XF.LossSumFn.apply(bce_loss(logit, target, scale=A, slot=rt.scalar_slot()), d_loss, loss_grad)
     rt.backward(loss, between)
