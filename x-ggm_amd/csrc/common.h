@@ -115,6 +115,9 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __ex
 // Counter-based RNG: the dropout mask / Gaussian draw of element `idx` of random
 // stream `stream_id` at step `offset` is a pure function of (seed, offset, stream_id,
 // idx), so forward and backward regenerate the same mask without storing it.
+// (Seven rounds -- the smallest Crush-resistant count -- were measured against the standard ten, same box, alternating
+// runs: 11.55 / 11.60 / 11.53 vs 11.53 / 11.47 / 11.51 ms per iteration.  The generator's integer multiplies run
+// under the memory waits of the kernels that call it; nothing to gain, so the standard count stays.)
 struct Philox {
     uint32_t k0, k1;
     __host__ __device__ Philox(uint64_t seed) : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)) {}
