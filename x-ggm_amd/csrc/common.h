@@ -49,6 +49,19 @@ __device__ __forceinline__ void load4(const bf16* p, float (&o)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] = __bfloat162float(t.v[i]);
 }
+// raw 4-element loads: the conversion to fp32 is a USE of the loaded registers (the compiler puts the s_waitcnt in
+// front of it), so kernels that want several loads in flight fetch raw first and convert after the last one is issued
+template <typename T> struct Raw4;
+template <> struct Raw4<float> { typedef float4 type; };
+template <> struct Raw4<bf16> { typedef bf16x4 type; };
+template <typename T> __device__ __forceinline__ typename Raw4<T>::type load_raw4(const T* p) {
+    return *reinterpret_cast<const typename Raw4<T>::type*>(p);
+}
+__device__ __forceinline__ void cvt4(const float4& t, float (&o)[4]) { o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w; }
+__device__ __forceinline__ void cvt4(const bf16x4& t, float (&o)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = __bfloat162float(t.v[i]);
+}
 __device__ __forceinline__ void store4(float* p, const float (&o)[4]) {
     *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
 }

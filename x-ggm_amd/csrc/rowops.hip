@@ -56,6 +56,35 @@ __device__ __forceinline__ void block_store_partial(const float (&p)[NV][4], flo
     }
 }
 
+// the three partial rows of a LayerNorm backward workgroup (dgamma, dbeta, dbias) in ONE pass through LDS: 16-byte
+// LDS writes, one barrier pair instead of three, 16-byte sums and non-temporal stores.  `lds` holds 3 * W * H floats.
+// Summation order over the waves as in block_store_partial (bitwise the same partial rows).
+template <int NV, int W>
+__device__ __forceinline__ void block_store_partial3(const float (&p0)[NV][4], const float (&p1)[NV][4],
+                                                     const float (&p2)[NV][4], float* lds, float* dst, int H, int lane,
+                                                     int wid) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int c = (v * 64 + lane) * 4;
+        if (c < H) {
+            *reinterpret_cast<f4*>(lds + (0 * W + wid) * H + c) = (f4){p0[v][0], p0[v][1], p0[v][2], p0[v][3]};
+            *reinterpret_cast<f4*>(lds + (1 * W + wid) * H + c) = (f4){p1[v][0], p1[v][1], p1[v][2], p1[v][3]};
+            *reinterpret_cast<f4*>(lds + (2 * W + wid) * H + c) = (f4){p2[v][0], p2[v][1], p2[v][2], p2[v][3]};
+        }
+    }
+    __syncthreads();
+    const int h4 = H >> 2;
+    for (int q = threadIdx.x; q < 3 * h4; q += W * 64) {
+        const int k = q / h4, c = (q - k * h4) * 4;
+        f4 t = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < W; ++w) t += *reinterpret_cast<const f4*>(lds + (k * W + w) * H + c);
+        __builtin_nontemporal_store(t, reinterpret_cast<f4*>(dst + k * H + c));
+    }
+}
+
 struct ReduceTargets {
     float* t[10];
     int stride[10];  // element stride of the target (1, or 4 for the columns of box_fc.weight [H,4])
@@ -183,49 +212,121 @@ __global__ __launch_bounds__(LN_FWD_W * 64) void ln_fwd_kernel(LnFwdGroup G, int
     const Q8 qs(out8 ? sg.qscale : nullptr);
     const float q8 = qs.q;
     float amax8 = 0.f;
+    // Every load of a row is issued before the first one is used: the row's critical path is then ONE memory round
+    // trip for the inputs (+ one for the accumulate target) instead of one per vector and operand.  The first version
+    // walked the vectors one by one, each behind its own `c < H` branch, and hipcc put an s_waitcnt vmcnt(0) behind
+    // every load -- nine to twelve serial round trips per row, which WAS the kernel (9 us per launch for 5 MB).
+    // Columns past H are read at a clamped address and masked out of the arithmetic; only the stores are predicated.
+    int cc[NV];
+    bool ok[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int c = (v * 64 + lane) * 4;
+        ok[v] = c < H;
+        cc[v] = ok[v] ? c : H - 4;
+    }
+    float g4[NV][4], be4[NV][4];
+    {   // gamma / beta do not depend on the row
+        float4 rg[NV], rbt[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            rg[v] = load_raw4<float>(gamma + cc[v]);
+            rbt[v] = load_raw4<float>(beta + cc[v]);
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            cvt4(rg[v], g4[v]);
+            cvt4(rbt[v], be4[v]);
+        }
+    }
+    float b4[NV][4];
+    if (bias) {
+        float4 rb4[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) rb4[v] = load_raw4<float>(bias + cc[v]);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) cvt4(rb4[v], b4[v]);
+    } else {
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b4[v][i] = 0.f;
+    }
     for (int row = blk * LN_FWD_W + wid; row < M; row += nblk * LN_FWD_W) {
         const int64_t rb = (int64_t)row * H;
         float z[NV][4];
-        float sum = 0.f;
+        typename Raw4<T>::type rin[NV], rres[NV], racc[NV];
+        if (sg.in_slabs > 0) {  // split-K partial sums (fp32), added in slab order
+            const float* part = reinterpret_cast<const float*>(sg.in) + rb;
+            const int64_t slab = (int64_t)M * H;
+            float4 rs[4][NV];
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const int c = (v * 64 + lane) * 4;
-            if (c < H) {
-                if (sg.in_slabs > 0) {  // split-K partial sums (fp32), added in slab order
-                    const float* part = reinterpret_cast<const float*>(sg.in) + rb + c;
-                    load4(part, z[v]);
-                    for (int sl = 1; sl < sg.in_slabs; ++sl) {
+            for (int sl = 0; sl < 4; ++sl)
+                if (sl < sg.in_slabs) {  // uniform: the loads of one slab back to back, nothing used in between
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) rs[sl][v] = load_raw4<float>(part + sl * slab + cc[v]);
+                }
+#pragma unroll
+            for (int v = 0; v < NV; ++v) cvt4(rs[0][v], z[v]);
+#pragma unroll
+            for (int sl = 1; sl < 4; ++sl)
+                if (sl < sg.in_slabs) {
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
                         float t4[4];
-                        load4(part + (int64_t)sl * M * H, t4);
+                        cvt4(rs[sl][v], t4);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) z[v][i] += t4[i];
                     }
-                } else {
-                    load4(in + rb + c, z[v]);
                 }
-                if (bias) {
-                    float b4[4];
-                    load4(bias + c, b4);
+            for (int sl = 4; sl < sg.in_slabs; ++sl) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) z[v][i] += b4[i];
-                }
-                if (d.p_pre > 0.f) {
-                    float s4[4];
-                    dropout_scale4(d.p_pre, ik_pre, seed, off, d.s_pre, (uint64_t)(rb + c), s4);
+                for (int v = 0; v < NV; ++v) {
+                    float t4[4];
+                    load4(part + sl * slab + cc[v], t4);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) z[v][i] *= s4[i];
+                    for (int i = 0; i < 4; ++i) z[v][i] += t4[i];
                 }
-                if (residual) {
-                    float r4[4];
-                    load4(residual + rb + c, r4);
+            }
+        } else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) z[v][i] += r4[i];
-                }
-                if (z_out) {
+            for (int v = 0; v < NV; ++v) rin[v] = load_raw4<T>(in + rb + cc[v]);
+        }
+        if (residual) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) z[v][i] = round_to<T>(z[v][i]);
-                    store4(z_out + rb + c, z[v]);
-                }
+            for (int v = 0; v < NV; ++v) rres[v] = load_raw4<T>(residual + rb + cc[v]);
+        }
+        if (accumulate) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) racc[v] = load_raw4<T>(out + rb + cc[v]);
+        }
+        if (sg.in_slabs <= 0) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) cvt4(rin[v], z[v]);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) z[v][i] += b4[v][i];
+            if (d.p_pre > 0.f) {
+                float s4[4];
+                dropout_scale4(d.p_pre, ik_pre, seed, off, d.s_pre, (uint64_t)(rb + cc[v]), s4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) z[v][i] *= s4[i];
+            }
+            if (residual) {
+                float r4[4];
+                cvt4(rres[v], r4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) z[v][i] += r4[i];
+            }
+            if (z_out) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) z[v][i] = round_to<T>(z[v][i]);
+                if (ok[v]) store4(z_out + rb + cc[v], z[v]);
+            }
+            if (ok[v]) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) sum += z[v][i];
             }
@@ -234,8 +335,7 @@ __global__ __launch_bounds__(LN_FWD_W * 64) void ln_fwd_kernel(LnFwdGroup G, int
         float var = 0.f;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            const int c = (v * 64 + lane) * 4;
-            if (c < H) {
+            if (ok[v]) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float t = z[v][i] - mean;
@@ -250,31 +350,28 @@ __global__ __launch_bounds__(LN_FWD_W * 64) void ln_fwd_kernel(LnFwdGroup G, int
         }
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            const int c = (v * 64 + lane) * 4;
-            if (c < H) {
-                float g4[4], b4[4], y[4];
-                load4(gamma + c, g4);
-                load4(beta + c, b4);
+            float y[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) y[i] = (z[v][i] - mean) * rstd * g4[i] + b4[i];
-                if (d.p_post > 0.f) {
-                    float s4[4];
-                    dropout_scale4(d.p_post, ik_post, seed, off, d.s_post, (uint64_t)(rb + c), s4);
+            for (int i = 0; i < 4; ++i) y[i] = (z[v][i] - mean) * rstd * g4[v][i] + be4[v][i];
+            if (d.p_post > 0.f) {
+                float s4[4];
+                dropout_scale4(d.p_post, ik_post, seed, off, d.s_post, (uint64_t)(rb + cc[v]), s4);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) y[i] *= s4[i];
-                }
+                for (int i = 0; i < 4; ++i) y[i] *= s4[i];
+            }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) y[i] *= out_scale;
-                if (accumulate) {
-                    float o4[4];
-                    load4(out + rb + c, o4);
+            for (int i = 0; i < 4; ++i) y[i] *= out_scale;
+            if (accumulate) {
+                float o4[4];
+                cvt4(racc[v], o4);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) y[i] += o4[i];
-                }
-                store4(out + rb + c, y);
+                for (int i = 0; i < 4; ++i) y[i] += o4[i];
+            }
+            if (ok[v]) {
+                store4(out + rb + cc[v], y);
                 if (out8) {  // e4m3 operand of the next fp8 product: 4 bytes per lane, 256 contiguous bytes per wave
                     amax8 = fmaxf(fmaxf(amax8, fmaxf(fabsf(y[0]), fabsf(y[1]))), fmaxf(fabsf(y[2]), fabsf(y[3])));
-                    *reinterpret_cast<int*>(out8 + rb + c) = pack4_e4m3(y[0], y[1], y[2], y[3], q8);
+                    *reinterpret_cast<int*>(out8 + rb + cc[v]) = pack4_e4m3(y[0], y[1], y[2], y[3], q8);
                 }
             }
         }
@@ -306,6 +403,8 @@ struct LnBwdGroup {
 // LN backward runs LN_BWD_W waves (rows in flight) per workgroup: eight halve the number of partial rows it writes
 // and the reduce launch reads (one [3, H] row per workgroup)
 constexpr int LN_BWD_W = 8;  // (same-box A/B against 4: 12.32 vs 12.37 ms per iteration)
+// the three partial rows go through LDS together when 3 x W x H floats fit beside nothing else (H = 768: 72 KB)
+__host__ __device__ inline bool ln_bwd_fused_tail(int H) { return (size_t)3 * LN_BWD_W * H * sizeof(float) <= 144 * 1024; }
 template <typename T, int NV>
 __global__ __launch_bounds__(LN_BWD_W * 64) void ln_bwd_kernel(LnBwdGroup G, int H, float p_pre, float p_post,
                                                              const uint64_t* rng, float out_scale) {
@@ -330,36 +429,64 @@ __global__ __launch_bounds__(LN_BWD_W * 64) void ln_bwd_kernel(LnBwdGroup G, int
     rng_load(d.rng, seed, off);
     const float ik_pre = d.p_pre > 0.f ? 1.f / (1.f - d.p_pre) : 1.f;
     const float ik_post = d.p_post > 0.f ? 1.f / (1.f - d.p_post) : 1.f;
+    // as in the forward: clamped columns, every load of a row issued before the first use (one memory round trip per
+    // row instead of one per vector and operand); only stores and the column partials are predicated
     float pg[NV][4], pb[NV][4], pbias[NV][4], g4[NV][4];
+    int cc[NV];
+    bool ok[NV];
+    {
+        float4 rg[NV];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        const int c = (v * 64 + lane) * 4;
+        for (int v = 0; v < NV; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            ok[v] = c < H;
+            cc[v] = ok[v] ? c : H - 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pg[v][i] = pb[v][i] = pbias[v][i] = 0.f;
-        if (c < H) load4(gamma + c, g4[v]);
+            for (int i = 0; i < 4; ++i) pg[v][i] = pb[v][i] = pbias[v][i] = 0.f;
+            rg[v] = load_raw4<float>(gamma + cc[v]);
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) cvt4(rg[v], g4[v]);
     }
     for (int row = blk * LN_BWD_W + wid; row < M; row += nblk * LN_BWD_W) {
         const int64_t rb = (int64_t)row * H;
-        const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+        typename Raw4<T>::type rdy[NV], rz[NV], rprev[NV], raux[NV];
+        const float2 st = *reinterpret_cast<const float2*>(stats + 2 * row);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            rdy[v] = load_raw4<T>(dy + rb + cc[v]);
+            rz[v] = load_raw4<T>(z + rb + cc[v]);
+        }
+        if (d_res && accumulate_dres) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) rprev[v] = load_raw4<T>(d_res + rb + cc[v]);
+        }
+        if (gelu_aux) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) raux[v] = load_raw4<T>(gelu_aux + rb + cc[v]);
+        }
+        const float mean = st.x, rstd = st.y;
         float dyn[NV][4], xh[NV][4];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            const int c = (v * 64 + lane) * 4;
-            if (c < H) {
-                float zz[4];
-                load4(dy + rb + c, dyn[v]);
-                load4(z + rb + c, zz);
-                if (d.p_post > 0.f) {
-                    float s4[4];
-                    dropout_scale4(d.p_post, ik_post, seed, off, d.s_post, (uint64_t)(rb + c), s4);
+            float zz[4];
+            cvt4(rdy[v], dyn[v]);
+            cvt4(rz[v], zz);
+            if (d.p_post > 0.f) {
+                float s4[4];
+                dropout_scale4(d.p_post, ik_post, seed, off, d.s_post, (uint64_t)(rb + cc[v]), s4);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) dyn[v][i] *= s4[i];
-                }
+                for (int i = 0; i < 4; ++i) dyn[v][i] *= s4[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                dyn[v][i] *= out_scale;
+                xh[v][i] = (zz[i] - mean) * rstd;
+            }
+            if (ok[v]) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    dyn[v][i] *= out_scale;
-                    xh[v][i] = (zz[i] - mean) * rstd;
                     pg[v][i] += dyn[v][i] * xh[v][i];
                     pb[v][i] += dyn[v][i];
                     const float t = dyn[v][i] * g4[v][i];
@@ -372,35 +499,34 @@ __global__ __launch_bounds__(LN_BWD_W * 64) void ln_bwd_kernel(LnBwdGroup G, int
         s2 = wave_sum(s2) / (float)H;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            const int c = (v * 64 + lane) * 4;
-            if (c < H) {
-                float dz[4];
+            float dz[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) dz[i] = rstd * (dyn[v][i] * g4[v][i] - s1 - xh[v][i] * s2);
-                if (d_res) {
-                    if (accumulate_dres) {
-                        float o4[4], w4[4];
-                        load4(d_res + rb + c, o4);
+            for (int i = 0; i < 4; ++i) dz[i] = rstd * (dyn[v][i] * g4[v][i] - s1 - xh[v][i] * s2);
+            if (d_res) {
+                if (accumulate_dres) {
+                    float o4[4], w4[4];
+                    cvt4(rprev[v], o4);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) w4[i] = o4[i] + dz[i];
-                        store4(d_res + rb + c, w4);
-                    } else {
-                        store4(d_res + rb + c, dz);
-                    }
+                    for (int i = 0; i < 4; ++i) w4[i] = o4[i] + dz[i];
+                    if (ok[v]) store4(d_res + rb + cc[v], w4);
+                } else if (ok[v]) {
+                    store4(d_res + rb + cc[v], dz);
                 }
-                if (d.p_pre > 0.f) {
-                    float s4[4];
-                    dropout_scale4(d.p_pre, ik_pre, seed, off, d.s_pre, (uint64_t)(rb + c), s4);
+            }
+            if (d.p_pre > 0.f) {
+                float s4[4];
+                dropout_scale4(d.p_pre, ik_pre, seed, off, d.s_pre, (uint64_t)(rb + cc[v]), s4);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) dz[i] *= s4[i];
-                }
-                if (gelu_aux) {  // `in` was gelu(u): chain through the activation
-                    float u4[4];
-                    load4(gelu_aux + rb + c, u4);
+                for (int i = 0; i < 4; ++i) dz[i] *= s4[i];
+            }
+            if (gelu_aux) {  // `in` was gelu(u): chain through the activation
+                float u4[4];
+                cvt4(raux[v], u4);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) dz[i] *= gelu_grad_f(u4[i]);
-                }
-                if (d_in) store4(d_in + rb + c, dz);
+                for (int i = 0; i < 4; ++i) dz[i] *= gelu_grad_f(u4[i]);
+            }
+            if (ok[v]) {
+                if (d_in) store4(d_in + rb + cc[v], dz);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) pbias[v][i] += dz[i];
             }
@@ -408,9 +534,13 @@ __global__ __launch_bounds__(LN_BWD_W * 64) void ln_bwd_kernel(LnBwdGroup G, int
     }
     extern __shared__ __attribute__((aligned(16))) float red_lds[];
     float* wsb = ws + (int64_t)blk * 3 * H;
-    block_store_partial<NV, LN_BWD_W>(pg, red_lds, wsb, H, lane, wid);
-    block_store_partial<NV, LN_BWD_W>(pb, red_lds, wsb + H, H, lane, wid);
-    block_store_partial<NV, LN_BWD_W>(pbias, red_lds, wsb + 2 * H, H, lane, wid);
+    if (ln_bwd_fused_tail(H)) {
+        block_store_partial3<NV, LN_BWD_W>(pg, pb, pbias, red_lds, wsb, H, lane, wid);
+    } else {
+        block_store_partial<NV, LN_BWD_W>(pg, red_lds, wsb, H, lane, wid);
+        block_store_partial<NV, LN_BWD_W>(pb, red_lds, wsb + H, H, lane, wid);
+        block_store_partial<NV, LN_BWD_W>(pbias, red_lds, wsb + 2 * H, H, lane, wid);
+    }
 }
 
 // ------------------------------------------------------------------------------- embeddings
@@ -807,11 +937,12 @@ int ln_bwd_grouped(const xggm_ln_bwd_problem* probs, int n, int H, float p_pre, 
             static bool big_lds = false;  // rows of up to 2048 floats x 8 waves exceed the 48 KB default
             if (!big_lds) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<T, NV>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * LN_BWD_W * 256 * NV));
+                                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)std::min<size_t>(sizeof(float) * LN_BWD_W * 256 * NV * 3, 144 * 1024));
                 big_lds = true;
             }
         });
-        DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), dim3(total), dim3(LN_BWD_W * 64), sizeof(float) * LN_BWD_W * H, st, G, H,
+        DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), dim3(total), dim3(LN_BWD_W * 64), sizeof(float) * LN_BWD_W * H * (ln_bwd_fused_tail(H) ? 3 : 1), st, G, H,
                                            p_pre, p_post, rng, out_scale));
         if (int e = xggm_check_launch("xggm_ln_bwd")) return e;
         for (int i = 0; i < G.n; ++i) {
