@@ -149,7 +149,12 @@ def test_two_data_parallel_ranks_on_one_gpu_stay_identical():
                        env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("replicas identical: True") == 4 and "replicas identical: False" not in r.stdout
-    assert "overlapped vs plain exchange: relative parameter difference 0.00e+00" in r.stdout
+    # bit for bit in most runs; the bias gradients folded into GEMM epilogues are fp32 atomics whose order depends on
+    # which tiles finish first, and the staged pass schedules them differently: single elements may differ by an ulp
+    # (seen: one element of one FFN bias, 2e-7) -- the same run-dependence DESIGN.md section 2 documents
+    import re
+    ds = [float(v) for v in re.findall(r"overlapped vs plain exchange: relative parameter difference ([0-9.e+-]+)", r.stdout)]
+    assert len(ds) == 2 and max(ds) < 1e-6, ds
     # the sharded update (ZeRO-1) on the wire arena: eager, two-graph and staged engines
     assert r.stdout.count("bf16 weights identical on both ranks: True") == 3
     assert "sharded vs replicated update, 3 iterations: relative parameter difference" in r.stdout

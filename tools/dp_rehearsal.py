@@ -83,13 +83,14 @@ def check_sharded(rank):
             print("sharded update overlap=%s graphs=%s: bf16 weights identical on both ranks: %s" % (overlap, use_graph, same),
                   flush=True)
         assert same
-    # ONE PASS (the plain one): the two runs differ only in the order the clip norm is summed in -- an ulp of the clip
-    # coefficient.  More passes: that ulp goes through bf16 roundings of the weights, BertAdam's sign-like first steps
-    # (m / sqrt(v) is +-3.16 whatever |g| is) and the DISCRETE steps of the generation pass (column arg-max of the
-    # adjacency regeneration, masked entries): one flipped decision changes its gradients by per cents (measured: a
-    # 4e-6 difference of the first pass's norm -> 0.7 % of the second pass's), so the bound only says "same training",
-    # as it would for any two orders of a floating-point sum.
-    for iters, bound in ((("plain",), 1e-5), (("rel", "node", "rel"), 5e-3)):
+    # The two runs differ in the order the clip norm is summed in -- an ulp of the clip coefficient -- from the
+    # trainer's warm-up passes on.  That ulp goes through bf16 roundings of the weights, BertAdam's sign-like first
+    # steps (m / sqrt(v) is +-3.16 whatever |g| is) and the DISCRETE steps of the generation pass (column arg-max of
+    # the adjacency regeneration, masked entries): one flipped decision changes its gradients by per cents (measured:
+    # a 4e-6 difference of one pass's norm -> 0.7 % of the next pass's).  So the bound says "same training", as it
+    # would for any two orders of a floating-point sum; what it is there to catch -- a slice nobody updates, a run
+    # gathered from the wrong owner -- moves whole tensors by lr * 3.16 and shows as >= 5e-2.
+    for iters, bound in ((("plain",), 5e-3), (("rel", "node", "rel"), 5e-3)):
         ref = run(True, rank, layers=(5, 4, 4), iters=iters)
         n_ref = run.norms
         got = run(True, rank, layers=(5, 4, 4), zero1=True, iters=iters)
@@ -130,6 +131,16 @@ def check(rank, layers):
     d = float((out[True] - out[False]).double().norm() / out[False].double().norm())
     if rank == 0:
         print("overlapped vs plain exchange: relative parameter difference %.2e" % d, flush=True)
+    if d > 0 and os.environ.get("XGGM_DEBUG_RUNS"):
+        again = run(False, rank, layers=layers)
+        if rank == 0:
+            print("   plain vs plain again: %.2e" % float((out[False] - again).double().norm() / again.double().norm()), flush=True)
+            o = 0
+            for n, k in run.names:
+                dd = (out[False][o:o + k] - out[True][o:o + k]).abs()
+                if float(dd.max()) > 0:
+                    print("   differs: %s max %.3e, %d elements" % (n, float(dd.max()), int((dd > 0).sum())), flush=True)
+                o += k
     assert d < 2e-3
 
 
