@@ -1272,7 +1272,12 @@ template <int BM, int BN> __global__ __launch_bounds__(NT, (min_waves<BM, BN>())
     }
     constexpr int DK = (BM * BN <= 64 * 64) ? 4 : 2;
     float4_t acc[BM / 32][BN / 32];
-    gemm_kloop<BM, BN, true, true, DK, true>(g, tile_m, tile_n, bz, fsm, acc);
+    if (glds_ok<true>(g)) {  // K a whole number of 128-element k-tiles: the LDS-DMA k-loop (same bytes per k-tile as bf16)
+        if (ga.stages == 3) gemm_kloop_glds<BM, BN, true, true, true, 4, 3>(g, tile_m, tile_n, bz, fsm, acc);
+        else gemm_kloop_glds<BM, BN, true, true, true, 4, 2>(g, tile_m, tile_n, bz, fsm, acc);
+    } else {
+        gemm_kloop<BM, BN, true, true, DK, true>(g, tile_m, tile_n, bz, fsm, acc);
+    }
     g.alpha *= (g.scale_a ? *g.scale_a : 1.f) * (g.scale_b ? *g.scale_b : 1.f);
     gemm_finish<BM, BN>(g, tile_m, tile_n, bz, fsm, acc);
 }
@@ -1286,12 +1291,17 @@ template <int BM, int BN> int launch_grouped_fp8_tile(GroupArgs& ga, hipStream_t
     ga.tile_start[ga.nprob] = total;
     // k-major images of 128 bytes per row (128 e4m3 values), double buffered; the staged epilogue needs
     // (BM / 2) x (BN + 4) floats of the same memory
-    constexpr size_t lds = std::max(2 * sizeof(bf16) * (OpLds<BM, true>::ELEMS + OpLds<BN, true>::ELEMS),
-                                    sizeof(float) * (BM / 2) * (BN + 4));
+    ga.stages = g_glds_stages ? std::min(g_glds_stages, 3) : (BM * BN == 128 * 128) ? 2 : 3;
+    bool glds = true;
+    for (int i = 0; i < ga.nprob; ++i) glds = glds && glds_ok<true>(ga.p[i]);
+    const size_t lds = std::max((glds ? ga.stages : 2) * sizeof(bf16) * (OpLds<BM, true>::ELEMS + OpLds<BN, true>::ELEMS),
+                                sizeof(float) * (BM / 2) * (BN + 4));
+    constexpr size_t lds_max = std::max(3 * sizeof(bf16) * (OpLds<BM, true>::ELEMS + OpLds<BN, true>::ELEMS),
+                                        sizeof(float) * (BM / 2) * (BN + 4));
     static bool attr_set = false;
-    if (lds > 48 * 1024 && !attr_set) {
+    if (lds_max > 48 * 1024 && !attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_grouped_fp8_kernel<BM, BN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         attr_set = true;
     }
     hipLaunchKernelGGL((gemm_grouped_fp8_kernel<BM, BN>), dim3(total), dim3(NT), lds, stream, ga);
