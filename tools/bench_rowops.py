@@ -33,8 +33,9 @@ def timeit(fn, n=200):
     return e0.elapsed_time(e1) * 1e3 / (5 * n)
 
 
-def ln_fwd(slabs, p=0.1):
+def ln_fwd(slabs, p=0.1, emit8=False):
     rng = ops.make_rng(1, dev)
+    qs, am = torch.full((1,), 8.0, device=dev), torch.zeros(1, device=dev)
     H = 768
     gam, bet, bias = torch.ones(H, device=dev), torch.zeros(H, device=dev), torch.zeros(H, device=dev)
     reqs_in = []
@@ -44,7 +45,8 @@ def ln_fwd(slabs, p=0.1):
         reqs_in.append((x, r))
 
     def run():
-        reqs = [ops.LnFwdReq(x, bias, r, gam, bet, 1e-12, p_pre=p, rng=rng, sid_pre=3, dtype=BF) for x, r in reqs_in]
+        reqs = [ops.LnFwdReq(x, bias, r, gam, bet, 1e-12, p_pre=p, rng=rng, sid_pre=3, dtype=BF,
+                             emit8=(qs, am) if emit8 else None) for x, r in reqs_in]
         ops.launch_row_requests(reqs)
         return reqs
     return run
@@ -69,8 +71,9 @@ def ln_bwd(p=0.1):
     return run
 
 
-def attn(bwd):
+def attn(bwd, emit8=False):
     rng = ops.make_rng(1, dev)
+    qs, am = torch.full((1,), 8.0, device=dev), torch.zeros(1, device=dev)
     B, heads = 32, 12
     shapes = ((20, 20), (36, 36))
     data = []
@@ -89,7 +92,7 @@ def attn(bwd):
                 reqs.append(ops.AttnBwdReq(q, k, v, mask, d_out, dqkv[:, :768], dqkv[:, 768:1536], dqkv[:, 1536:], B, heads, Sq, Sk,
                                            0.1, rng, 5))
             else:
-                reqs.append(ops.AttnFwdReq(q, k, v, mask, B, heads, Sq, Sk, 0.1, rng, 5))
+                reqs.append(ops.AttnFwdReq(q, k, v, mask, B, heads, Sq, Sk, 0.1, rng, 5, emit8=(qs, am) if emit8 else None))
         ops.launch_row_requests(reqs)
     return run
 
@@ -97,9 +100,11 @@ def attn(bwd):
 if __name__ == "__main__":
     print("LN fwd pair, bf16 input (attention block)   %6.2f us" % timeit(ln_fwd(0)))
     print("LN fwd pair, bf16 input, no dropout         %6.2f us" % timeit(ln_fwd(0, p=0.0)))
+    print("LN fwd pair, bf16 input + e4m3 copy         %6.2f us" % timeit(ln_fwd(0, emit8=True)))
     print("LN fwd pair, 3 fp32 split-K slabs (FFN)     %6.2f us" % timeit(ln_fwd(3)))
     print("LN fwd pair, 2 fp32 split-K slabs           %6.2f us" % timeit(ln_fwd(2)))
     print("LN bwd pair                                 %6.2f us" % timeit(ln_bwd()))
     print("LN bwd pair, no dropout                     %6.2f us" % timeit(ln_bwd(0.0)))
     print("attention fwd pair (20x20 + 36x36)          %6.2f us" % timeit(attn(False)))
+    print("attention fwd pair + e4m3 copy              %6.2f us" % timeit(attn(False, emit8=True)))
     print("attention bwd pair                          %6.2f us" % timeit(attn(True)))
