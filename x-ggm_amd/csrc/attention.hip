@@ -303,7 +303,8 @@ int attn_bwd_grouped(const xggm_attn_problem* probs, int n, int head_dim, const 
         XGGM_REQUIRE(q.d_out && q.dq && q.dk && q.dv, "xggm_attn_bwd: null pointer");
         XGGM_REQUIRE(q.dq_rs % 4 == 0 && q.dk_rs % 4 == 0 && q.dv_rs % 4 == 0, "xggm_attn_bwd: row strides must be multiples of 4");
         XGGM_REQUIRE((q.dbk == nullptr) == (q.dbv == nullptr), "xggm_attn_bwd: dbk and dbv go together");
-        if (sizeof(T) == 2 && mfma_ok(q.q, q.k, q.v, q.d_out, q.q_rs, q.k_rs, q.v_rs, q.o_rs)) {
+        const bool grads8 = (reinterpret_cast<uintptr_t>(q.dq) | reinterpret_cast<uintptr_t>(q.dk) | reinterpret_cast<uintptr_t>(q.dv)) % 8 == 0;
+        if (sizeof(T) == 2 && grads8 && mfma_ok(q.q, q.k, q.v, q.d_out, q.q_rs, q.k_rs, q.v_rs, q.o_rs)) {  // 8-byte gradient stores
             pend[np++] = q;
             if (np == 2 || i == n - 1) {
                 if (int e = xggm_attn_bwd_mfma_group(pend, np, rng, st)) return e;

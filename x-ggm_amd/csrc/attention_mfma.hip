@@ -108,6 +108,8 @@ long long* g_attn_stamp = nullptr;
 #endif
 
 // S = scale * Q K^T + mask  ->  Sf (fp32, row stride lds_s), tiles shared round-robin by the waves
+// (staging the sample's mask row in LDS with the Q / K / V tiles instead of reading it inside the tile loop was
+// measured: 7.68 -> 7.77 us forward, 13.0 -> 13.3 us backward -- the other waves cover that round trip already)
 __device__ __forceinline__ void scores(const MArgs& a, const bf16* Qs, const bf16* Ks, float* Sf, int lds_s, int b, int tid) {
     const int lane = tid & 63, wid = tid >> 6, fr = lane & 15, fq = lane >> 4;
     const int tq = rup(a.Sq, 16) / 16, tk = rup(a.Sk, 16) / 16;
@@ -326,23 +328,30 @@ __global__ __launch_bounds__(NT) void attn_fwd_mfma_kernel(MGroup G) {
     }
 }
 
-// store a 16x16 gradient tile (rows row0.., 16 columns at col0) and fold its column sums into csum
+// store a 16x16 gradient tile (rows row0.., 16 columns at col0) and fold its column sums into csum.  The tile comes out
+// of an MFMA with SWAPPED operands: lane (fr, fq) holds row fr, columns 4 fq .. 4 fq + 3 -- one 8-byte store per lane
+// (was four 2-byte ones) and column sums by DPP moves inside the 16-lane rows (was two ds_bpermute round trips).
 __device__ __forceinline__ void store_grad_tile(const float4_t& acc, bf16* dst, int64_t rs, int row_base, int rows_valid,
                                                 int row0, int col0, float* csum, int lane) {
     const int fr = lane & 15, fq = lane >> 4;
-    float s = 0.f;
+    const int i = row0 + fr;
+    const bool ok = i < rows_valid;
+    if (ok) {
+        short4_t pk;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int i = row0 + fq * 4 + r;
-        if (i < rows_valid) {
-            dst[(int64_t)(row_base + i) * rs + col0 + fr] = __float2bfloat16(acc[r]);
-            s += acc[r];
-        }
+        for (int r = 0; r < 4; ++r) pk[r] = __builtin_bit_cast(short, __float2bfloat16(acc[r]));
+        *reinterpret_cast<short4_t*>(dst + (int64_t)(row_base + i) * rs + col0 + 4 * fq) = pk;
     }
     if (csum) {
-        s += __shfl_xor(s, 16, 64);
-        s += __shfl_xor(s, 32, 64);
-        if (lane < 16) atomicAdd(csum + col0 + fr, s);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float s = ok ? acc[r] : 0.f;
+            s += dpp_move<0xB1>(s);
+            s += dpp_move<0x4E>(s);
+            s += dpp_move<0x141>(s);
+            s += dpp_move<0x140>(s);  // every lane of the 16-lane row holds the column's sum over the tile's rows
+            if (fr == 0) atomicAdd(csum + col0 + 4 * fq + r, s);
+        }
     }
 }
 
@@ -478,17 +487,17 @@ __global__ __launch_bounds__(NT) void attn_bwd_mfma_kernel(MGroup G) {
         if (t < n_dq) {
             const int ti = t >> 2, tc = t & 3;  // dQ = dS K: k = j
             for (int ks = 0; ks < RK; ks += 32)
-                acc = MFMA(frag_rows(dSb, LDP, ti * 16, ks, lane), frag_tr(Ks, LDT, ks, tc * 16, lane), acc);
+                acc = MFMA(frag_tr(Ks, LDT, ks, tc * 16, lane), frag_rows(dSb, LDP, ti * 16, ks, lane), acc);
             store_grad_tile(acc, dq + h * D, dq_rs, b * Sq, Sq, ti * 16, tc * 16, dbq ? csum[0] : nullptr, lane);
         } else if (t < n_dq + n_dk) {
             const int u = t - n_dq, tj = u >> 2, tc = u & 3;  // dK = dS^T Q: k = i
             for (int ks = 0; ks < RQ; ks += 32)
-                acc = MFMA(frag_tr(dSb, LDP, ks, tj * 16, lane), frag_tr(Qs, LDT, ks, tc * 16, lane), acc);
+                acc = MFMA(frag_tr(Qs, LDT, ks, tc * 16, lane), frag_tr(dSb, LDP, ks, tj * 16, lane), acc);
             store_grad_tile(acc, dk + h * D, dk_rs, b * Sk, Sk, tj * 16, tc * 16, dbk ? csum[1] : nullptr, lane);
         } else {
             const int u = t - n_dq - n_dk, tj = u >> 2, tc = u & 3;  // dV = (P D)^T dO: k = i
             for (int ks = 0; ks < RQ; ks += 32)
-                acc = MFMA(frag_tr(Pdb, LDP, ks, tj * 16, lane), frag_tr(dOs, LDT, ks, tc * 16, lane), acc);
+                acc = MFMA(frag_tr(dOs, LDT, ks, tc * 16, lane), frag_tr(Pdb, LDP, ks, tj * 16, lane), acc);
             store_grad_tile(acc, dv + h * D, dv_rs, b * Sk, Sk, tj * 16, tc * 16, dbv ? csum[2] : nullptr, lane);
         }
     }

@@ -108,6 +108,7 @@ constexpr int BM = 64, BN = 64, NT = 256;
 bool g_force_generic = false;  // test hook: xggm_gemm_set_generic
 int g_xcd_swizzle = 1;         // test hook: xggm_gemm_set_tile(variant | 0x100) disables it
 int g_glds_stages = 0;        // test hook: xggm_gemm_set_tile(variant | 0x800 / 0x1000) pins 2 / 3 LDS stages
+int g_no_8w = 0;               // test hook: xggm_gemm_set_tile(variant | 0x4000): no 8-wave 128 x 128 tile
 int g_glds = 1;                // test hook: xggm_gemm_set_tile(variant | 0x400) keeps k-major pairs on the register-staged k-loop
 int g_group_tile = 0;          // test hook: 0 heuristic, 1: 64x64, 2: 128x64, 3: 128x128
 
@@ -1468,6 +1469,7 @@ extern "C" int xggm_gemm_set_tile(int variant) {
     g_tile_override = variant & 0xff;
     g_xcd_swizzle = (variant & 0x100) ? 0 : 1;
     g_glds = (variant & 0x400) ? 0 : 1;
+    g_no_8w = (variant & 0x4000) ? 1 : 0;
     g_glds_stages = (variant & 0x800) ? 2 : (variant & 0x1000) ? 3 : (variant & 0x2000) ? 4 : 0;
     return XGGM_OK;
 }
@@ -1573,7 +1575,7 @@ template <typename T> int grouped(const xggm_gemm_problem* probs, int n, hipStre
             kmaj = kmaj && ga.p[i].a_mode == 1 && ga.p[i].b_mode == 1;
             nkmin = std::min(nkmin, ceil_div(ga.p[i].K, 64));
         }
-        if (kmaj && t128 > 200 && t128 <= 256 && nkmin >= 12) v = 4;
+        if (kmaj && t128 > 200 && t128 <= 256 && nkmin >= 12 && !g_no_8w) v = 4;
     }
     if (v == 4) return launch_grouped_tile<128, 128, 8>(ga, stream);
     if (v == 3) return launch_grouped_tile<128, 128>(ga, stream);

@@ -148,7 +148,18 @@ __global__ __launch_bounds__(NT) void partial_reduce_batch_kernel(BatchJobs bj) 
     if (idx < KH) {
         const float* p = job.ws + idx;
         int b = sl;
-        for (; b + 8 < job.nblk; b += 16) {  // read once: non-temporal
+        // four loads in flight per thread (the sums keep the two-accumulator order: even steps into a0, odd into a1)
+        for (; b + 24 < job.nblk; b += 32) {  // read once: non-temporal
+            const f4 r0 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p + (int64_t)b * KH));
+            const f4 r1 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p + (int64_t)(b + 8) * KH));
+            const f4 r2 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p + (int64_t)(b + 16) * KH));
+            const f4 r3 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p + (int64_t)(b + 24) * KH));
+            a0 += r0;
+            a1 += r1;
+            a0 += r2;
+            a1 += r3;
+        }
+        for (; b + 8 < job.nblk; b += 16) {
             a0 += __builtin_nontemporal_load(reinterpret_cast<const f4*>(p + (int64_t)b * KH));
             a1 += __builtin_nontemporal_load(reinterpret_cast<const f4*>(p + (int64_t)(b + 8) * KH));
         }
