@@ -29,7 +29,8 @@ def main():
     for ev in prof.events():
         if not ev.name.startswith("aten::"):
             continue
-        if not any(k.name and ("at::native" in k.name or "elementwise" in k.name) for k in ev.kernels):
+        if not any(k.name and ("at::native" in k.name or "elementwise" in k.name or "emcpy" in k.name or "copyBuffer" in k.name
+                               or "fillBuffer" in k.name) for k in ev.kernels):
             continue
         st = [s for s in (ev.stack or []) if "ggm" in s or "bench.py" in s][:4]
         if not st:

@@ -108,6 +108,8 @@ constexpr int BM = 64, BN = 64, NT = 256;
 bool g_force_generic = false;  // test hook: xggm_gemm_set_generic
 int g_xcd_swizzle = 1;         // test hook: xggm_gemm_set_tile(variant | 0x100) disables it
 int g_glds_stages = 0;        // test hook: xggm_gemm_set_tile(variant | 0x800 / 0x1000) pins 2 / 3 LDS stages
+int g_single_grouped = 1;      // single problems with whole k-tiles also take the grouped (LDS-DMA) kernel: -0.05 ms per iteration
+                               // (same-box A/B 11.33 / 11.05 / 11.06 vs 11.01 / 11.00 / 11.03); xggm_gemm_set_tile(variant | 0x8000) turns it off
 int g_no_8w = 0;               // test hook: xggm_gemm_set_tile(variant | 0x4000): no 8-wave 128 x 128 tile
 int g_glds = 1;                // test hook: xggm_gemm_set_tile(variant | 0x400) keeps k-major pairs on the register-staged k-loop
 int g_group_tile = 0;          // test hook: 0 heuristic, 1: 64x64, 2: 128x64, 3: 128x128
@@ -1470,6 +1472,7 @@ extern "C" int xggm_gemm_set_tile(int variant) {
     g_xcd_swizzle = (variant & 0x100) ? 0 : 1;
     g_glds = (variant & 0x400) ? 0 : 1;
     g_no_8w = (variant & 0x4000) ? 1 : 0;
+    g_single_grouped = (variant & 0x8000) ? 0 : 1;
     g_glds_stages = (variant & 0x800) ? 2 : (variant & 0x1000) ? 3 : (variant & 0x2000) ? 4 : 0;
     return XGGM_OK;
 }
@@ -1556,7 +1559,7 @@ template <typename T> int grouped(const xggm_gemm_problem* probs, int n, hipStre
     // longest k-loops first: their tiles start early and the short ones fill the tail
     for (int i = 1; i < n && fast; ++i)
         for (int j = i; j > 0 && ga.p[j].K > ga.p[j - 1].K; --j) std::swap(ga.p[j], ga.p[j - 1]);
-    if (!fast || n == 1) {  // odd shapes, fp32 mode or a single problem: one launch each
+    if (!fast || (n == 1 && !(g_single_grouped && glds_ok<false>(ga.p[0])))) {  // odd shapes, fp32 mode or a single problem: one launch each
         for (int i = 0; i < n; ++i)
             if (int e = launch<T>(from_problem(probs[i]), probs[i].batch, stream)) return e;
         return XGGM_OK;
