@@ -106,6 +106,11 @@ typedef struct xggm_gemm_problem {
     void* c8;
     const float* c8_qscale;
     float* c8_amax;
+    /* amax entries may be spread over `amax_slots` floats (a power of two <= 64; 0 reads as 1): workgroup w raises
+     * c8_amax[w % amax_slots] and xggm_fp8_scale_update takes the maximum over the slots.  Hundreds of workgroups
+     * raising ONE address are same-address device-scope atomics the kernel end waits for (measured: +2 us per LayerNorm
+     * launch, +3.9 us per attention launch, 0.25 ms per iteration of the fp8 step). */
+    int amax_slots;
 } xggm_gemm_problem;
 int xggm_gemm_grouped_f32(const xggm_gemm_problem* probs, int n, xggm_stream_t stream);
 int xggm_gemm_grouped_bf16(const xggm_gemm_problem* probs, int n, xggm_stream_t stream);
@@ -139,9 +144,10 @@ int xggm_gemm_grouped_fp8e4m3(const xggm_gemm_problem* probs, int n, xggm_stream
  *   dscale[i] = 1 / qscale[i];   bump != 0: *pos += 1.
  * Activation sites: once per pass, margin 1.25, shrink, bump.  Weight operands: for the parameter groups a pass
  * updates, BEFORE xggm_bertadam_ex writes their e4m3 copies with the new scale (margin 4/3, no shrink, no bump).
- * Everything is device-resident (graph replay); n <= 1024. */
+ * Everything is device-resident (graph replay); n <= 1024.  `amax_slots` (power of two <= 64, 0 = 1): entry i's maximum
+ * is the largest of amax[i * amax_slots .. + amax_slots - 1] (all cleared). */
 int xggm_fp8_scale_update(float* amax, float* hist, float* qscale, float* dscale, int64_t* pos, int n, int hist_len,
-                          float margin, int shrink, int bump, xggm_stream_t stream);
+                          float margin, int shrink, int bump, int amax_slots, xggm_stream_t stream);
 /* y[i] = e4m3fn(clamp(x[i] * *qscale, -448, 448)), round-to-nearest-even; x fp32 / bf16, n % 8 == 0; qscale: device
  * scalar or null (1); amax: device scalar or null, raised to max |x| (atomic; the caller zeroes it): the next
  * step's scale without another pass over x. */
@@ -210,6 +216,7 @@ typedef struct xggm_attn_problem {
     void* out8;
     const float* qscale;
     float* amax;
+    int amax_slots; /* see xggm_gemm_problem.amax_slots */
 } xggm_attn_problem;
 int xggm_attn_fwd_grouped_f32(const xggm_attn_problem* probs, int n, int head_dim, const uint64_t* rng, xggm_stream_t stream);
 int xggm_attn_fwd_grouped_bf16(const xggm_attn_problem* probs, int n, int head_dim, const uint64_t* rng, xggm_stream_t stream);
@@ -268,6 +275,7 @@ typedef struct xggm_ln_fwd_problem {
     void* out8;
     const float* qscale;
     float* amax;
+    int amax_slots; /* see xggm_gemm_problem.amax_slots */
 } xggm_ln_fwd_problem;
 typedef struct xggm_ln_bwd_problem {
     const void* dy;
@@ -486,6 +494,7 @@ typedef struct xggm_adam_args {
     int64_t elem0;
     float g_scale; /* > 0: every gradient is multiplied by it (1 / world: the exchange SUMS over the data-parallel ranks
                       and the average is taken here); <= 0 reads as 1 */
+    int w8_amax_slots; /* entry id of w8_amax starts at w8_amax[id * max(1, w8_amax_slots)]; see xggm_gemm_problem.amax_slots */
 } xggm_adam_args;
 int xggm_bertadam_ex(const xggm_adam_args* args, xggm_stream_t stream);
 /* *out += sum g^2 of a flat bf16 range (the wire arena), same fixed summation order as xggm_sqnorm_f32 */

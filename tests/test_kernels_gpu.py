@@ -1065,6 +1065,51 @@ def test_fp8_scale_update_protocol(ops):
     assert int(pos) == 5 and abs(float(q[6]) - 448 / (4.0 / 3.0 * 3.0)) < 1e-3 and float(q[7]) == 7.0
 
 
+def test_fp8_amax_entries_spread_over_slots(ops):
+    """an amax entry may be spread over 2^k floats (xggm_*_problem.amax_slots): workgroup w of a producer raises slot
+    w % slots -- hundreds of workgroups raising one address were 0.25 ms of the fp8 iteration -- and the scale update
+    takes the maximum over the slots and clears them all.  Producers: LayerNorm forward, attention forward, the GELU
+    epilogue; a 1-float entry keeps the old behaviour (the other fp8 tests)."""
+    BF = torch.bfloat16
+    S = 64
+    gen = torch.Generator().manual_seed(11)
+    # LayerNorm forward
+    M, H = 640, 768
+    h, r = torch.randn(M, H, generator=gen).to(BF).to(DEV), torch.randn(M, H, generator=gen).to(BF).to(DEV)
+    gam, bet = torch.ones(H, device=DEV), torch.zeros(H, device=DEV)
+    outs = []
+    for slots in (1, S):
+        q, amax = torch.tensor([200.0], device=DEV), torch.zeros(slots, device=DEV)
+        req = ops.LnFwdReq(h.clone(), None, r, gam, bet, 1e-12, emit8=(q, amax))
+        ops.launch_row_requests([req])
+        outs.append((req.out8.clone(), amax.clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert float(outs[0][1].max()) > 0 and float(outs[1][1].max()) == float(outs[0][1][0])
+    assert int((outs[1][1] > 0).sum()) > 8  # really spread: 80 workgroups over 64 slots
+    # attention forward
+    B, heads, Sq = 8, 12, 36
+    qkv = [torch.randn(B * Sq, 768, generator=gen).to(BF).to(DEV) for _ in range(3)]
+    rng = ops.make_rng(3, DEV)
+    am = []
+    for slots in (1, S):
+        qs, amax = torch.tensor([1000.0], device=DEV), torch.zeros(slots, device=DEV)
+        a = ops.AttnFwdReq(qkv[0], qkv[1], qkv[2], None, B, heads, Sq, Sq, 0.0, rng, 7, emit8=(qs, amax))
+        ops.launch_row_requests([a])
+        am.append(amax.clone())
+    assert float(am[0][0]) > 0 and float(am[1].max()) == float(am[0][0]) and int((am[1] > 0).sum()) > 8
+    # the scale update reduces and clears the slots
+    Hh = 4
+    amax = torch.zeros(3 * S, device=DEV)
+    amax[1 * S + 17], amax[1 * S + 40], amax[2 * S + 63] = 2.0, 5.0, 3.0
+    hist, q, d = torch.zeros(3 * Hh, device=DEV), torch.full((3,), -1.0, device=DEV), torch.ones(3, device=DEV)
+    pos = torch.zeros(1, dtype=torch.int64, device=DEV)
+    ops.fp8_scale_update(amax, hist, q, d, pos, 1, 2, Hh, 1.25, 1, 1, slots=S)
+    assert float(amax.abs().max()) == 0.0 and float(q[0]) == -1.0
+    assert abs(float(q[1]) - 448 / (1.25 * 5.0)) < 1e-3 and abs(float(q[2]) - 448 / (1.25 * 3.0)) < 1e-3
+    with pytest.raises(RuntimeError, match="power of two"):
+        ops.fp8_scale_update(amax, hist, q, d, pos, 0, 1, Hh, 1.25, 1, 1, slots=48)
+
+
 # ------------------------------------------------------------------------------------------------ preprocessing
 def test_cosine_adjacency_matches_reference_golden_and_oracle(ops):
     """xggm_cosine_adjacency_f32 (data/preprocess/vqa/compute_adjacency.py:38-45, :90) against the fixture the

@@ -40,6 +40,7 @@ struct MSeg {
     unsigned char* out8;  // or null: e4m3 copy of the output (operand of the fp8 output projection)
     const float* qscale;
     float* amax;
+    int amax_slots;
     const bf16* d_out;
     bf16 *dq, *dk, *dv;
     int64_t dq_rs, dk_rs, dv_rs;
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(NT) void attn_fwd_mfma_kernel(MGroup G) {
             float bm = red8[0];
 #pragma unroll
             for (int w = 1; w < NT / 64; ++w) bm = fmaxf(bm, red8[w]);
-            if (bm > qs.thr) atomic_max_nonneg(sg.amax, bm);
+            if (bm > qs.thr) amax_record(sg.amax, sg.amax_slots, (int)blockIdx.x, bm);
         }
     }
 }
@@ -527,6 +528,7 @@ MSeg make_seg(const xggm_attn_problem& q, const uint64_t* rng) {
     g.out8 = (unsigned char*)q.out8;
     g.qscale = q.qscale;
     g.amax = q.amax;
+    g.amax_slots = q.amax_slots > 1 ? q.amax_slots : 1;
     g.d_out = (const bf16*)q.d_out;
     g.dq = (bf16*)q.dq; g.dk = (bf16*)q.dk; g.dv = (bf16*)q.dv;
     g.dq_rs = q.dq_rs; g.dk_rs = q.dk_rs; g.dv_rs = q.dv_rs;

@@ -210,6 +210,11 @@ __device__ __forceinline__ void atomic_max_nonneg(float* dst, float v) {
     if (v > 0.f) atomicMax(reinterpret_cast<unsigned int*>(dst), __float_as_uint(v));
 }
 
+// raise entry `amax` (spread over `slots` floats, see xggm_gemm_problem.amax_slots) from workgroup `wg`
+__device__ __forceinline__ void amax_record(float* amax, int slots, int wg, float v) {
+    atomic_max_nonneg(amax + (slots > 1 ? (wg & (slots - 1)) : 0), v);
+}
+
 // Scale-table protocol of the e4m3 producers (xggm_fp8_scale_update): *qscale <= 0 marks an entry that has not been
 // calibrated -- quantise with 1 and record every maximum; otherwise only maxima beyond half the representable range
 // 448 / q are recorded (e4m3 is a floating-point format: a smaller stale range costs no precision, only a larger

@@ -37,6 +37,7 @@ struct GemmArgs {
     unsigned char* c8;     // or null: e4m3 copy of the stored result (layout of C), scaled by *c8_qscale
     const float* c8_qscale;
     float* c8_amax;        // or null: raised to max |stored value|
+    int amax_slots;        // floats the entry is spread over (xggm_gemm_problem.amax_slots)
     const float* scale_a;  // fp8 operands: reciprocal quantisation scales (device scalars, null = 1)
     const float* scale_b;
     int act;
@@ -604,7 +605,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, const float4_
             float bm = stage[0];
 #pragma unroll
             for (int w = 1; w < W; ++w) bm = fmaxf(bm, stage[w]);
-            if (bm > qs.thr) atomic_max_nonneg(g.c8_amax, bm);
+            if (bm > qs.thr) amax_record(g.c8_amax, g.amax_slots, (int)(blockIdx.x + blockIdx.y * gridDim.x), bm);
         }
         lds_barrier();
     }
@@ -721,7 +722,7 @@ __device__ __forceinline__ void epilogue_direct(const GemmArgs& g, const float4_
             float bm = stage[0];
 #pragma unroll
             for (int w = 1; w < W; ++w) bm = fmaxf(bm, stage[w]);
-            if (bm > qs.thr) atomic_max_nonneg(g.c8_amax, bm);
+            if (bm > qs.thr) amax_record(g.c8_amax, g.amax_slots, (int)(blockIdx.x + blockIdx.y * gridDim.x), bm);
         }
     }
     if (KIND == 0 && g.sqsum) {
@@ -1421,7 +1422,7 @@ template <typename T> int launch(GemmArgs g, int batch, hipStream_t stream) {
         g.a_rs = a_rs; g.a_ks = a_ks; g.b_ns = b_ns; g.b_ks = b_ks; g.ldc = ldc;                                       \
         g.a_bs = a_bs; g.b_bs = b_bs; g.c_bs = c_bs;                                                                   \
         g.bias = bias; g.residual = residual; g.preact = preact; g.aux = aux; g.colsum = colsum; g.sqsum = nullptr;   \
-        g.c8 = nullptr; g.c8_qscale = nullptr; g.c8_amax = nullptr; g.scale_a = g.scale_b = nullptr;                     \
+        g.c8 = nullptr; g.c8_qscale = nullptr; g.c8_amax = nullptr; g.scale_a = g.scale_b = nullptr; g.amax_slots = 1;  \
         g.act = act; g.c_f32 = c_f32; g.accumulate = accumulate; g.alpha = alpha;                                     \
         g.a_mode = g.b_mode = 0; g.xcd_swizzle = g_xcd_swizzle; g.batch = batch; g.use_glds = g_glds; SET_STAMP(g); \
         return launch<T>(g, batch, stream);                                                                            \
@@ -1449,7 +1450,7 @@ extern "C" int xggm_gemm_fp8e4m3(const void* A, const void* B, void* C, int M, i
     g.a_rs = a_rs; g.a_ks = 1; g.b_ns = b_ns; g.b_ks = 1; g.ldc = ldc;
     g.a_bs = g.b_bs = g.c_bs = 0;
     g.bias = bias; g.residual = residual; g.preact = preact; g.aux = nullptr; g.colsum = nullptr; g.sqsum = nullptr;
-    g.c8 = nullptr; g.c8_qscale = nullptr; g.c8_amax = nullptr; g.scale_a = g.scale_b = nullptr;
+    g.c8 = nullptr; g.c8_qscale = nullptr; g.c8_amax = nullptr; g.scale_a = g.scale_b = nullptr; g.amax_slots = 1;
     g.act = act; g.c_f32 = c_f32; g.accumulate = 0; g.alpha = 1.0f;
     g.a_mode = g.b_mode = 1; g.a_tail = g.b_tail = 0; g.a_rows = M; g.b_rows = N;
     g.xcd_swizzle = g_xcd_swizzle; g.batch = 1; g.use_glds = g_glds; SET_STAMP(g);
@@ -1486,6 +1487,7 @@ GemmArgs from_problem(const xggm_gemm_problem& p) {
     g.a_bs = p.a_bs; g.b_bs = p.b_bs; g.c_bs = p.c_bs;
     g.bias = p.bias; g.residual = p.residual; g.preact = p.preact; g.aux = p.aux; g.colsum = p.colsum; g.sqsum = p.sqsum;
     g.c8 = reinterpret_cast<unsigned char*>(p.c8); g.c8_qscale = p.c8_qscale; g.c8_amax = p.c8_amax;
+    g.amax_slots = p.amax_slots > 1 ? p.amax_slots : 1;
     g.scale_a = p.scale_a; g.scale_b = p.scale_b;
     g.act = p.act; g.c_f32 = p.c_f32; g.accumulate = p.accumulate; g.alpha = p.alpha;
     g.a_mode = g.b_mode = 0; g.xcd_swizzle = g_xcd_swizzle; g.batch = p.batch; g.use_glds = g_glds; SET_STAMP(g);

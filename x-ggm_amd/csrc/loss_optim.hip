@@ -282,6 +282,7 @@ struct AdamArgs {
     float* w8_amax;
     int64_t elem0;              // arena offset of p[0] (multiple of 256 with shadow8)
     float g_scale;              // gradients are SUMS over data-parallel ranks: 1 / world (1 otherwise)
+    int w8_slots;               // floats every w8_amax entry is spread over (>= 1)
 };
 
 // One float4 of each of p, g, m, v per step; UNR independent float4 quadruples per thread and
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(NT) void bertadam_kernel(AdamArgs a) {
                     // floating-point format: a stale smaller range costs nothing until values shrink by orders of
                     // magnitude, see xggm_fp8_scale_update): a few per cent of the waves issue the atomic.
                     mx = wave_max(mx);
-                    if (lane == 0 && mx > 0.75f * 448.f / q) atomic_max_nonneg(a.w8_amax + id, mx);
+                    if (lane == 0 && mx > 0.75f * 448.f / q) amax_record(a.w8_amax + (int64_t)id * a.w8_slots, a.w8_slots, (int)blockIdx.x, mx);
                 }
             }
         }
@@ -400,13 +401,17 @@ __global__ __launch_bounds__(NT) void bertadam_kernel(AdamArgs a) {
 // (weights).  qscale <= 0 marks an entry that has not been calibrated: its producers quantise with 1 and record
 // every maximum, and it stays uncalibrated until something was recorded.
 __global__ void fp8_scale_update_kernel(float* amax, float* hist, float* qscale, float* dscale, int64_t* pos, int n,
-                                        int hist_len, float margin, int shrink, int bump) {
+                                        int hist_len, float margin, int shrink, int bump, int slots) {
     const int i = threadIdx.x;
     const int slot = (int)(*pos % hist_len);
     if (i < n) {
         const float q0 = qscale[i];
-        hist[(int64_t)i * hist_len + slot] = amax[i];
-        amax[i] = 0.f;
+        float am = 0.f;
+        for (int s = 0; s < slots; ++s) {  // the entry's maximum is spread over `slots` floats (producers' atomics)
+            am = fmaxf(am, amax[(int64_t)i * slots + s]);
+            amax[(int64_t)i * slots + s] = 0.f;
+        }
+        hist[(int64_t)i * hist_len + slot] = am;
         float m = 0.f;
         for (int j = 0; j < hist_len; ++j) m = fmaxf(m, hist[(int64_t)i * hist_len + j]);
         float q = q0;
@@ -562,7 +567,7 @@ extern "C" int xggm_bertadam_f32(float* p, const float* g, float* m, float* v, v
                  "xggm_bertadam_f32: pointers must be 16-byte aligned");
     XGGM_REQUIRE(!shadow_bf16 || reinterpret_cast<uintptr_t>(shadow_bf16) % 8 == 0, "xggm_bertadam_f32: shadow misaligned");
     AdamArgs a{p, g, m, v, (bf16*)shadow_bf16, n, sqnorm, max_norm, lr, nullptr, lr_scale, b1, b2, eps, weight_decay,
-               nullptr, nullptr, nullptr, nullptr, 0, 1.f};
+               nullptr, nullptr, nullptr, nullptr, 0, 1.f, 1};
     return launch_adam(a, false, st);
 }
 
@@ -610,7 +615,7 @@ extern "C" int xggm_bertadam_ex(const xggm_adam_args* x, hipStream_t st) {
                  "256-element chunk of the arena");
     AdamArgs a{x->p, x->g, x->m, x->v, (bf16*)x->shadow_bf16, x->n, x->sqnorm, x->max_norm, x->lr, x->lr_dev, x->lr_scale,
                x->b1, x->b2, x->eps, x->weight_decay, (unsigned char*)x->shadow8, x->w8_id, x->w8_qscale, x->w8_amax, x->elem0,
-               x->g_scale > 0.f ? x->g_scale : 1.f};
+               x->g_scale > 0.f ? x->g_scale : 1.f, x->w8_amax_slots > 1 ? x->w8_amax_slots : 1};
     return launch_adam(a, x->g_bf16 != 0, st);
 }
 
@@ -624,12 +629,14 @@ extern "C" int xggm_sqnorm_bf16(const void* g, int64_t n, float* out, float* ws,
 }
 
 extern "C" int xggm_fp8_scale_update(float* amax, float* hist, float* qscale, float* dscale, int64_t* pos, int n,
-                                     int hist_len, float margin, int shrink, int bump, hipStream_t st) {
+                                     int hist_len, float margin, int shrink, int bump, int amax_slots, hipStream_t st) {
+    const int slots = amax_slots > 1 ? amax_slots : 1;
+    XGGM_REQUIRE(slots <= 64 && (slots & (slots - 1)) == 0, "xggm_fp8_scale_update: amax_slots %d must be a power of two <= 64", slots);
     XGGM_REQUIRE(amax && hist && qscale && dscale && pos && n > 0 && n <= 1024 && hist_len > 0 && hist_len <= 64 && margin >= 1.f,
                  "xggm_fp8_scale_update: bad arguments (n = %d <= 1024 entries, history %d <= 64, margin %g >= 1)", n,
                  hist_len, (double)margin);
     hipLaunchKernelGGL(fp8_scale_update_kernel, dim3(1), dim3(1024), 0, st, amax, hist, qscale, dscale, pos, n, hist_len,
-                       margin, shrink, bump);
+                       margin, shrink, bump, slots);
     return xggm_check_launch("xggm_fp8_scale_update");
 }
 

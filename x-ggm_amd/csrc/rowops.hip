@@ -396,7 +396,7 @@ __global__ __launch_bounds__(LN_FWD_W * 64) void ln_fwd_kernel(LnFwdGroup G, int
             float bm = red8[0];
 #pragma unroll
             for (int w = 1; w < LN_FWD_W; ++w) bm = fmaxf(bm, red8[w]);
-            if (bm > qs.thr) atomic_max_nonneg(sg.amax, bm);
+            if (bm > qs.thr) amax_record(sg.amax, sg.amax_slots, (int)blockIdx.x, bm);
         }
     }
 }

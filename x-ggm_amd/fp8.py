@@ -23,6 +23,8 @@ from . import ops
 
 HIST = 4          # steps of amax history per entry
 CAP = 1024        # entries of the scale table (weight operands + activation sites)
+AMAX_SLOTS = 64   # floats every amax entry is spread over: workgroup w of a producer raises slot w % 64, the scale update
+                  # takes the maximum -- hundreds of workgroups raising ONE address cost 0.25 ms per fp8 iteration
 MARGIN_ACT = 1.25
 MARGIN_W = 4.0 / 3.0
 
@@ -33,7 +35,7 @@ class Fp8State:
             raise RuntimeError("the fp8 forward needs bf16 storage (compute_dtype = torch.bfloat16)")
         dev = arena.device
         self.arena = arena
-        self.amax = torch.zeros(CAP, device=dev)
+        self.amax = torch.zeros(CAP * AMAX_SLOTS, device=dev)
         self.hist = torch.zeros(CAP * HIST, device=dev)
         self.qscale = torch.full((CAP,), -1.0, device=dev)  # <= 0: not calibrated
         self.dscale = torch.ones(CAP, device=dev)
@@ -97,7 +99,7 @@ class Fp8State:
                 ops.quantize_fp8(a.shadow[o:o + k], qscale=self.qscale[e:e + 1], out=self.shadow8[o:o + k])
         nw = self.n_w or self.n
         self.hist[:nw * HIST].zero_()
-        self.amax[:nw].zero_()
+        self.amax[:nw * AMAX_SLOTS].zero_()
 
     def w8(self, ps):
         """e4m3 [rows, cols] view of (adjacent) weight parameters + the 1-element reciprocal-scale tensor"""
@@ -114,13 +116,14 @@ class Fp8State:
         """arguments of the e4m3 copy for the update of arena group ``gname`` (None: the group has none)"""
         if gname not in self.w_range:
             return None
-        return self.w8_id, self.qscale, self.amax
+        return self.w8_id, self.qscale, self.amax, AMAX_SLOTS
 
     def update_weight_scales(self, gname):
         """new scales for the operands of one arena group, BEFORE its BertAdam launch rewrites their e4m3 copies"""
         if gname in self.w_range:
             i0, n = self.w_range[gname]
-            ops.fp8_scale_update(self.amax, self.hist, self.qscale, self.dscale, self.pos, i0, n, HIST, MARGIN_W, 0, 0)
+            ops.fp8_scale_update(self.amax, self.hist, self.qscale, self.dscale, self.pos, i0, n, HIST, MARGIN_W, 0, 0,
+                                 slots=AMAX_SLOTS)
 
     # ------------------------------------------------------------------ activations
     def site(self, key):
@@ -138,7 +141,7 @@ class Fp8State:
     def emit(self, key):
         """(qscale, amax) handed to a producer kernel, and the entry"""
         e = self.site(key)
-        return (self.qscale[e:e + 1], self.amax[e:e + 1]), e
+        return (self.qscale[e:e + 1], self.amax[e * AMAX_SLOTS:(e + 1) * AMAX_SLOTS]), e
 
     def put(self, x, x8, e):
         self._q8[x.data_ptr()] = (x8, e, x)
@@ -162,7 +165,8 @@ class Fp8State:
         """once per pass (Runtime.advance): new scales for the activation sites from the maxima of this pass"""
         n_act = self.n - self.n_w
         if n_act > 0:
-            ops.fp8_scale_update(self.amax, self.hist, self.qscale, self.dscale, self.pos, self.n_w, n_act, HIST, MARGIN_ACT, 1, 1)
+            ops.fp8_scale_update(self.amax, self.hist, self.qscale, self.dscale, self.pos, self.n_w, n_act, HIST, MARGIN_ACT, 1, 1,
+                                 slots=AMAX_SLOTS)
         self._q8.clear()
         if self.seen_forward and not torch.cuda.is_current_stream_capturing():
             self.calibrated = True

@@ -165,7 +165,7 @@ class GemmProblem(_ct.Structure):
                 ("colsum", _ct.c_void_p), ("act", _ct.c_int), ("c_f32", _ct.c_int), ("accumulate", _ct.c_int), ("alpha", _ct.c_float),
                 ("sqsum", _ct.c_void_p),
                 ("scale_a", _ct.c_void_p), ("scale_b", _ct.c_void_p), ("c8", _ct.c_void_p), ("c8_qscale", _ct.c_void_p),
-                ("c8_amax", _ct.c_void_p)]
+                ("c8_amax", _ct.c_void_p), ("amax_slots", _ct.c_int)]
 
 
 def _problem(A, B, C, M, N, K, a_rs, a_ks, b_ns, b_ks, ldc, bias=None, residual=None, preact=None, aux=None,
@@ -191,6 +191,7 @@ def p_fwd(x, w, bias=None, act=ACT_NONE, want_preact=False, out_f32=False, emit8
         y8, q, amax = emit8
         assert y8.shape == y.shape and y8.element_size() == 1 and y8.is_contiguous() and x.dtype == BF16 and not out_f32
         p.c8, p.c8_qscale, p.c8_amax = ptr(y8), ptr(q), ptr(amax)
+        p.amax_slots = amax.numel() if amax is not None else 0  # a table entry spread over several floats (fp8.AMAX_SLOTS)
         p.keep = p.keep + (y8, q, amax)
     return p, y, pre
 
@@ -236,6 +237,7 @@ def p_fwd8(x8, w8, sx, sw, bias=None, act=ACT_NONE, want_preact=False, emit8=Non
         y8, q, amax = emit8
         assert y8.shape == y.shape and y8.element_size() == 1 and y8.is_contiguous()
         p.c8, p.c8_qscale, p.c8_amax = ptr(y8), ptr(q), ptr(amax)
+        p.amax_slots = amax.numel() if amax is not None else 0  # a table entry spread over several floats (fp8.AMAX_SLOTS)
         p.keep = p.keep + (y8, q, amax)
     return p, y, pre
 
@@ -354,7 +356,7 @@ class AttnProblem(_ct.Structure):
                 ("d_out", _ct.c_void_p), ("dq", _ct.c_void_p), ("dk", _ct.c_void_p), ("dv", _ct.c_void_p),
                 ("dq_rs", _ct.c_int64), ("dk_rs", _ct.c_int64), ("dv_rs", _ct.c_int64),
                 ("dbq", _ct.c_void_p), ("dbk", _ct.c_void_p), ("dbv", _ct.c_void_p),
-                ("out8", _ct.c_void_p), ("qscale", _ct.c_void_p), ("amax", _ct.c_void_p)]
+                ("out8", _ct.c_void_p), ("qscale", _ct.c_void_p), ("amax", _ct.c_void_p), ("amax_slots", _ct.c_int)]
 
 
 class AttnFwdReq:
@@ -382,6 +384,7 @@ class AttnFwdReq:
         if emit8 is not None:
             self.out8 = torch.empty((B * Sq, H), device=q.device, dtype=torch.uint8)
             self.prob.out8, self.prob.qscale, self.prob.amax = ptr(self.out8), ptr(emit8[0]), ptr(emit8[1])
+            self.prob.amax_slots = emit8[1].numel() if emit8[1] is not None else 0
             self.keep = self.keep + tuple(emit8)
 
 
@@ -438,7 +441,7 @@ class LnFwdProblem(_ct.Structure):
     _fields_ = [("inp", _ct.c_void_p), ("bias", _ct.c_void_p), ("residual", _ct.c_void_p), ("gamma", _ct.c_void_p),
                 ("beta", _ct.c_void_p), ("out", _ct.c_void_p), ("z_out", _ct.c_void_p), ("stats", _ct.c_void_p),
                 ("M", _ct.c_int), ("sid_pre", _ct.c_uint32), ("sid_post", _ct.c_uint32), ("in_slabs", _ct.c_int),
-                ("out8", _ct.c_void_p), ("qscale", _ct.c_void_p), ("amax", _ct.c_void_p)]
+                ("out8", _ct.c_void_p), ("qscale", _ct.c_void_p), ("amax", _ct.c_void_p), ("amax_slots", _ct.c_int)]
 
 
 class LnBwdProblem(_ct.Structure):
@@ -487,6 +490,7 @@ class LnFwdReq:
             assert dtype == BF16
             self.out8 = torch.empty((M, H), device=x.device, dtype=torch.uint8)
             self.prob.out8, self.prob.qscale, self.prob.amax = ptr(self.out8), ptr(emit8[0]), ptr(emit8[1])
+            self.prob.amax_slots = emit8[1].numel() if emit8[1] is not None else 0
             self.keep = self.keep + tuple(emit8)
 
 
@@ -934,7 +938,7 @@ class AdamArgs(_ct.Structure):
                 ("lr", _ct.c_float), ("lr_dev", _ct.c_void_p), ("lr_scale", _ct.c_void_p),
                 ("b1", _ct.c_float), ("b2", _ct.c_float), ("eps", _ct.c_float), ("weight_decay", _ct.c_float),
                 ("g_bf16", _ct.c_int), ("shadow8", _ct.c_void_p), ("w8_id", _ct.c_void_p), ("w8_qscale", _ct.c_void_p),
-                ("w8_amax", _ct.c_void_p), ("elem0", _ct.c_int64), ("g_scale", _ct.c_float)]
+                ("w8_amax", _ct.c_void_p), ("elem0", _ct.c_int64), ("g_scale", _ct.c_float), ("w8_amax_slots", _ct.c_int)]
 
 
 def bertadam_ex(p, g, m, v, shadow, sqn, max_norm, lr, lr_scale, b1, b2, eps, wd, lr_dev=None, w8=None, elem0=0, g_scale=1.0):
@@ -947,11 +951,12 @@ def bertadam_ex(p, g, m, v, shadow, sqn, max_norm, lr, lr_scale, b1, b2, eps, wd
     assert g.numel() == p.numel() and g.dtype in (F32, BF16)
     a = AdamArgs(ptr(p), ptr(g), ptr(m), ptr(v), ptr(shadow), p.numel(), ptr(sqn), float(max_norm), float(lr), ptr(lr_dev),
                  ptr(lr_scale), float(b1), float(b2), float(eps), float(wd), int(g.dtype == BF16), None, None, None, None,
-                 int(elem0), float(g_scale))
+                 int(elem0), float(g_scale), 1)
     if w8 is not None:
-        s8, ids, q, amax = w8
+        s8, ids, q, amax = w8[:4]
         assert s8.numel() == p.numel() and s8.element_size() == 1 and ids.dtype == torch.int16
         a.shadow8, a.w8_id, a.w8_qscale, a.w8_amax = ptr(s8), ptr(ids), ptr(q), ptr(amax)
+        a.w8_amax_slots = int(w8[4]) if len(w8) > 4 else 1  # floats per entry of the amax table
     call("xggm_bertadam_ex", _ct.byref(a), stream())
 
 
@@ -963,13 +968,14 @@ def sqnorm_bf16(g, out):
     call("xggm_sqnorm_bf16", ptr(g), g.numel(), ptr(out), ptr(ws), stream())
 
 
-def fp8_scale_update(amax, hist, qscale, dscale, pos, i0, n, hist_len, margin, shrink, bump):
-    """entries [i0, i0 + n) of a scale table (xggm_fp8_scale_update)"""
+def fp8_scale_update(amax, hist, qscale, dscale, pos, i0, n, hist_len, margin, shrink, bump, slots=1):
+    """entries [i0, i0 + n) of a scale table (xggm_fp8_scale_update); ``slots``: floats every amax entry is spread over"""
     for t in (amax, hist, qscale, dscale):
         _c(t, F32)
     _c(pos, torch.int64)
-    call("xggm_fp8_scale_update", amax.data_ptr() + 4 * i0, hist.data_ptr() + 4 * i0 * hist_len, qscale.data_ptr() + 4 * i0,
-         dscale.data_ptr() + 4 * i0, ptr(pos), n, hist_len, float(margin), int(shrink), int(bump), stream())
+    call("xggm_fp8_scale_update", amax.data_ptr() + 4 * i0 * slots, hist.data_ptr() + 4 * i0 * hist_len,
+         qscale.data_ptr() + 4 * i0, dscale.data_ptr() + 4 * i0, ptr(pos), n, hist_len, float(margin), int(shrink),
+         int(bump), int(slots), stream())
 
 
 def sched_step(step, lr_scale, t_total, warmup):
