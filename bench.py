@@ -60,7 +60,7 @@ def parse(argv=None):
     p.add_argument("--no-loader", action="store_true", help="skip the loader-inclusive leg")
     p.add_argument("--wire", default="bf16", choices=["bf16", "f32"], help="gradient all-reduce dtype")
     p.add_argument("--zero1", type=int, default=None, help="1: shard the update over the ranks (reduce-scatter -> "
-                   "BertAdam on the shard -> all-gather of the weights); default: on from 8 ranks")
+                   "BertAdam on the shard -> all-gather of the weights); default: off (see DESIGN.md section 6)")
     p.add_argument("--seed", type=int, default=9595)
     a = p.parse_args(argv)
     if a.answers is None:
@@ -538,8 +538,10 @@ def main():
     zero1 = False
     if world > 1 or force_dp:
         from xggm_amd.vqa.vqacpv2 import enable_data_parallel
-        # the sharded update trades the update's HBM traffic for an exposed all-gather: it pays with 7 links per GPU, not 1 - 3
-        zero1 = bool(args.zero1) if args.zero1 is not None else (world >= 8 and args.wire == "bf16" and args.dtype == "bf16")
+        # The sharded update trades 7/8 of the update's HBM traffic (0.75 ms per pass at 8 ranks) for an all-gather of
+        # the bf16 matrix weights (388 MB) that nothing overlaps yet: it pays only above ~450 GB/s of gather rate per GPU.
+        # Opt-in until that is measured on an 8-GPU node.
+        zero1 = bool(args.zero1) if args.zero1 is not None else False
         enable_data_parallel(model, wire_dtype=torch.bfloat16 if args.wire == "bf16" else None, zero1=zero1)
     trainer = CapturedTrainer(model, optim, batch, sigma=1.0, order=args.order, use_graph=not args.no_graph)
     log("trainer ready (hip_graph=%s)" % (not args.no_graph))
