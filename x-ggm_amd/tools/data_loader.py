@@ -24,6 +24,18 @@ import numpy as np
 import torch
 
 
+def _packed(spec, device, pin):
+    """one flat byte buffer + typed views {name: tensor} at 256-byte aligned offsets (``spec``: name -> (shape, dtype))"""
+    offs, total = {}, 0
+    for k, (shape, dt) in spec.items():
+        n = int(np.prod(shape)) * torch.empty((), dtype=dt).element_size()
+        offs[k] = (total, n)
+        total += (n + 255) // 256 * 256
+    flat = torch.zeros(total, dtype=torch.uint8, device=device) if device is not None else (
+        torch.zeros(total, dtype=torch.uint8).pin_memory() if pin else torch.zeros(total, dtype=torch.uint8))
+    return flat, {k: flat[o:o + n].view(spec[k][1]).view(spec[k][0]) for k, (o, n) in offs.items()}
+
+
 class DataLoaderX:
     def __init__(self, dataset, batch_size, shuffle=False, drop_last=False, device=None, batcher=None, depth=3, seed=0,
                  epochs=1):
@@ -39,14 +51,24 @@ class DataLoaderX:
         self.batcher, self.depth, self.seed, self.epochs = batcher, depth, seed, epochs
         self._epoch = 0
         pin = self.device is not None and self.device.type == "cuda"
-        self.host = [dataset.alloc(batch_size, pin) for _ in range(depth)]
         self.dev = None
-        if pin:
-            self.dev = [{k: torch.empty_like(v, device=self.device) for k, v in h.items()} for h in self.host]
-            if batcher is not None:
-                for d in self.dev:
-                    d["ids"] = torch.zeros((3, batch_size, batcher.T), dtype=torch.long, device=self.device)
-            self.copy_stream = torch.cuda.Stream(device=self.device)
+        if not pin:
+            self.host = [dataset.alloc(batch_size, False) for _ in range(depth)]
+            return
+        # ONE pinned buffer and ONE device buffer per slot, the fields of a batch are typed views at 256-byte offsets:
+        # a batch crosses PCIe as one copy (one DMA command, one event) instead of one per field
+        spec = {k: (tuple(v.shape), v.dtype) for k, v in dataset.alloc(batch_size, False).items()}
+        if batcher is not None:
+            spec["ids"] = ((3, batch_size, batcher.T), torch.long)
+        self.host_flat, self.dev_flat, self.host, self.dev = [], [], [], []
+        for _ in range(depth):
+            hf, hv = _packed(spec, None, True)
+            df, dv = _packed(spec, self.device, False)
+            self.host_flat.append(hf)
+            self.dev_flat.append(df)
+            self.host.append(hv)
+            self.dev.append(dv)
+        self.copy_stream = torch.cuda.Stream(device=self.device)
 
     def __len__(self):
         n = len(self.ds)
@@ -101,15 +123,13 @@ class _Iter:
                 if L.dev is not None:
                     rel = self.released[slot]
                     dev = L.dev[slot]
+                    if L.batcher is not None:  # token ids into this slot's pinned buffer (host copy of a few KB)
+                        host["ids"].numpy()[:, :B] = L.batcher.host_batch(sents).numpy()
+                        sent = (dev["ids"][0, :B], dev["ids"][1, :B], dev["ids"][2, :B])
                     with torch.cuda.stream(L.copy_stream):
                         if rel is not None:
                             L.copy_stream.wait_event(rel)  # the consumer's kernels on this slot's buffers are done
-                        for k, v in host.items():
-                            dev[k][:B].copy_(v[:B], non_blocking=True)
-                        if L.batcher is not None:
-                            dev["ids"][:, :B].copy_(L.batcher.host_batch(sents), non_blocking=True)
-                            L.batcher.record_copy(L.copy_stream)
-                            sent = (dev["ids"][0, :B], dev["ids"][1, :B], dev["ids"][2, :B])
+                        L.dev_flat[slot].copy_(L.host_flat[slot], non_blocking=True)  # the whole batch: one copy
                         ev = torch.cuda.Event()
                         ev.record(L.copy_stream)
                     out = {k: v[:B] for k, v in dev.items() if k != "ids"}
