@@ -366,3 +366,28 @@ def test_training_state_restored_under_live_graphs(tmp_path):
     sa, sb = ma.state_dict(), mb.state_dict()
     assert max(rel_err(sb[k].float(), sa[k].float()) for k in sa) < 2e-3
     assert oa.state_dict()["state"][0]["step"] == ob.state_dict()["state"][0]["step"]
+
+
+def test_no_framework_kernel_inside_a_training_pass():
+    """every device kernel a pass launches is one of the package's own: the plain, the relation
+    and the node-generation pass of a small model run eagerly under torch.profiler -- no aten op may launch a kernel
+    (at::native fills, adds, copies: F.pad of odd-width logit gradients, autograd's sums where a tensor feeds several
+    consumers, select backward of the pooler, zero 'gradients' of non-differentiable outputs all used to)."""
+    from torch.profiler import ProfilerActivity, profile
+    from xggm_amd.engine import CapturedTrainer
+    B, A = 4, 29
+    cfg, m, opt = _tiny(5, 11)
+    batch = batch_tensors(synth.vqa_batch(B, A=A, F=cfg["feat_dim"], vocab=cfg["vocab"], seed=3), DEV)
+    tr = CapturedTrainer(m, opt, batch, sigma=1.0, order="vqa", use_graph=False)
+    tr.iteration("rel")
+    tr.iteration("node")
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+        tr.iteration("rel")
+        tr.iteration("node")
+        torch.cuda.synchronize()
+    bad = []
+    for ev in prof.events():
+        if ev.name.startswith("aten::") and any(k.name for k in ev.kernels):
+            bad.append((ev.name, str(ev.input_shapes)[:60], [k.name[:50] for k in ev.kernels][:2]))
+    assert not bad, bad[:8]
