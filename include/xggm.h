@@ -517,6 +517,11 @@ int xggm_add_scalars_f32(const float* a, const float* b, const float* c, const f
  * (reference: x, feat_seq[1], node_feats, adj_noise in src/vqa/vqacpv2.py:195-251). */
 int xggm_add_n_f32(const float* a, const float* b, const float* c, const float* d, float* out, int64_t n, xggm_stream_t stream);
 int xggm_add_n_bf16(const void* a, const void* b, const void* c, const void* d, void* out, int64_t n, xggm_stream_t stream);
+/* Rows of a [V, H] table by index (H % 4 == 0; indices outside [0, V) are skipped): dst[i, :] = bf16(src[idx[i], :]) and
+ * dst[idx[i], :] = src[i, :] (duplicate indices must carry identical rows).  Data parallelism exchanges only the rows of
+ * the word-embedding gradient (nn.Embedding(30522, 768), src/lxrt/modeling.py:283) that some rank touched. */
+int xggm_gather_rows_bf16(const float* src, const int64_t* idx, void* dst, int n, int H, int64_t V, xggm_stream_t stream);
+int xggm_scatter_rows_bf16(const void* src, const int64_t* idx, void* dst, int n, int H, int64_t V, xggm_stream_t stream);
 /* dst [rows, ld] bf16 = cast(src [rows, n], fp32 if src_f32 else bf16), columns n .. ld - 1 zero: the padded row stride
  * the backward products of an odd-width output run on (answer logits of src/vqa/vqacpv2_model.py:63-70). */
 int xggm_pad_rows_bf16(const void* src, int src_f32, void* dst, int rows, int n, int ld, xggm_stream_t stream);

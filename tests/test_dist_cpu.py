@@ -248,3 +248,80 @@ def test_sharded_update_bookkeeping_world2():
     for p in procs:
         p.join(60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _sparse_table_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from xggm_amd.dist import GradSync, ShardedUpdate
+
+        class Grp:
+            def __init__(self, start, vec_start, end):
+                self.start, self.vec_start, self.end = start, vec_start, end
+
+        ok = True
+        for cls in (GradSync, ShardedUpdate):
+            class Arena:
+                pass
+            a = Arena()
+            V, H = 40, 8                     # the "word table": 40 rows of 8, inside the vector region of g0
+            t0 = 1024 + 16
+            a.groups = {"g0": Grp(0, 1024, 1024 + 16 + V * H + 24)}
+            n = 2048
+            a.total = n
+            gen = torch.Generator().manual_seed(7 + rank)
+            a.grads = torch.zeros(n)
+            a.grads[1024:t0] = torch.randn(16, generator=gen)                 # other vectors in front of the table
+            a.grads[t0 + V * H:t0 + V * H + 24] = torch.randn(24, generator=gen)  # ... and behind it
+            ids = torch.tensor([[3, 7, 7, 0], [11, 3, 39, 0]]) if rank == 0 else torch.tensor([[5, 7, 20, 0], [39, 39, 2, 0]])
+            tab = a.grads[t0:t0 + V * H].view(V, H)
+            for i in ids.reshape(-1).tolist():  # the local scatter-add of the embedding backward (row 0 = padding too)
+                tab[i] += torch.randn(H, generator=gen)
+            a.wire = torch.zeros(n, dtype=torch.bfloat16)
+            a.wire[:1024] = (torch.randn(1024, generator=gen)).to(torch.bfloat16)  # matrix gradients are born here
+            a.shadow = torch.zeros(n, dtype=torch.bfloat16)
+            a.params, a.m, a.v = torch.zeros(n), torch.zeros(n), torch.zeros(n)
+            # reference: the dense exchange of the same buffers
+            ref_w = a.wire.clone()
+            ref_w[1024:a.groups["g0"].end] = a.grads[1024:a.groups["g0"].end].to(torch.bfloat16)
+            dense = ref_w.clone()
+            dist.all_reduce(dense, op=dist.ReduceOp.SUM)
+            gs = cls(a) if cls is ShardedUpdate else cls(a.grads, None, torch.bfloat16, arena=a)
+            gs.set_sparse_table(t0, V, H, lambda: ids)
+            gs.sync([(0, a.groups["g0"].end)])
+            got = a.wire
+            touched = sorted(set(ids.reshape(-1).tolist()) | set([3, 7, 0, 11, 39, 5, 20, 2]))
+            # touched rows: the sum of both ranks' rows (bf16 sums of two terms are exact up to one rounding);
+            # untouched rows: zero; everything outside the table: as the dense exchange
+            ok &= bool(torch.equal(got[:t0], dense[:t0])) and bool(torch.equal(got[t0 + V * H:], dense[t0 + V * H:]))
+            gt, dt_ = got[t0:t0 + V * H].view(V, H).float(), dense[t0:t0 + V * H].view(V, H).float()
+            ok &= bool(((gt - dt_).abs() <= 1e-2 * dt_.abs() + 1e-6).all())
+            un = [r for r in range(V) if r not in touched]
+            ok &= float(gt[un].abs().max()) == 0.0 and float(gt[touched].abs().max()) > 0.0
+            # both ranks hold the same table afterwards
+            both = [torch.empty_like(got) for _ in range(world)]
+            dist.all_gather(both, got)
+            ok &= bool(torch.equal(both[0][t0:t0 + V * H], both[1][t0:t0 + V * H]))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sparse_word_table_exchange_world2():
+    """data parallelism, the word-embedding gradient: the ranks exchange the rows of the tokens of the step (ids
+    all-gathered, rows gathered into a compact bf16 buffer, all-reduced, written back) instead of the whole table --
+    same result as the dense exchange on the touched rows, zeros elsewhere, identical on both ranks, the ranges around
+    the table untouched by the special path; for the replicated and for the sharded exchange."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sparse_table_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)]

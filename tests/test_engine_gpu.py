@@ -299,7 +299,11 @@ def test_prefetching_loader_feeds_the_captured_trainer(tmp_path):
     # two engines that started equal: fp32 atomics make the last bits of a pass run-dependent and the updates carry
     # that forward, so the trajectories agree to rounding, not bit for bit
     # (lr 2e-3 on a tiny model: by the third step the loss is in the hundreds and the run is chaotic: 1 % there)
-    assert len(losses) == n_img // B and np.allclose(np.asarray(losses[:1]), np.asarray(losses2[:1]), rtol=1e-6)
+    # (first step: the plain pass has seen no update yet -- same loss to rounding; its update carries the atomics' last
+    # bits into the generation pass, whose discrete steps (column arg-max of the regenerated adjacency) amplify them:
+    # 3e-5 was seen there)
+    assert len(losses) == n_img // B and np.allclose(losses[0][0], losses2[0][0], rtol=1e-6)
+    assert np.allclose(losses[0][1], losses2[0][1], rtol=1e-3)
     assert np.allclose(np.asarray(losses), np.asarray(losses2), rtol=2e-2)
     torch.cuda.synchronize()
 

@@ -1192,3 +1192,24 @@ def _lib_call_bad_pad():
     x = torch.zeros(4, 8, device=DEV)
     out = torch.zeros(4, 4, device=DEV, dtype=torch.bfloat16)
     _lib.call("xggm_pad_rows_bf16", x.data_ptr(), 1, out.data_ptr(), 4, 8, 4, None)
+
+
+def test_gather_and_scatter_rows(ops):
+    """xggm_gather_rows_bf16 / xggm_scatter_rows_bf16: the rows of the word-embedding gradient a data-parallel step
+    exchanges (dist.GradSync.set_sparse_table); duplicates, out-of-range indices, a width that is not a multiple of 256."""
+    gen = torch.Generator().manual_seed(4)
+    for V, H in ((100, 768), (37, 36)):
+        t = torch.randn(V, H, generator=gen)
+        idx = torch.tensor([0, 5, 5, V - 1, 17, -1, V, 3], dtype=torch.int64)
+        got = ops.gather_rows(t.to(DEV), idx.to(DEV)).cpu()
+        ok = (idx >= 0) & (idx < V)
+        assert torch.equal(got[ok], t[idx[ok]].to(torch.bfloat16))
+        dst = torch.zeros(V, H, dtype=torch.bfloat16, device=DEV)
+        rows = torch.randn(8, H, generator=gen).to(torch.bfloat16)
+        rows[2] = rows[1]  # duplicates carry identical rows
+        ops.scatter_rows(rows.to(DEV), idx.to(DEV), dst)
+        want = torch.zeros(V, H, dtype=torch.bfloat16)
+        for i in range(8):
+            if ok[i]:
+                want[idx[i]] = rows[i]
+        assert torch.equal(dst.cpu(), want)

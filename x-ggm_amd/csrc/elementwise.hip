@@ -151,6 +151,33 @@ __global__ __launch_bounds__(NT) void pad_rows_kernel(const S* __restrict__ src,
     }
 }
 
+// dst[i, :] = bf16(src[idx[i], :]) / dst[idx[i], :] = src[i, :]: the rows of the word-embedding gradient the ranks of a
+// data-parallel group actually touched (xggm_amd.dist: the table is 23.4 M parameters, a step touches <= 640 rows per
+// rank -- the exchange moves world x 640 rows instead of 30522).  One wave per row, 8 bytes per lane and step.
+__global__ __launch_bounds__(NT) void gather_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx,
+                                                         bf16* __restrict__ dst, int n, int H, int64_t V) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int i = blockIdx.x * (NT / 64) + wid; i < n; i += gridDim.x * (NT / 64)) {
+        const int64_t r = idx[i];
+        if (r < 0 || r >= V) continue;
+        for (int c = lane * 4; c < H; c += 256) {
+            float v[4];
+            load4(src + r * H + c, v);
+            store4(dst + (int64_t)i * H + c, v);
+        }
+    }
+}
+__global__ __launch_bounds__(NT) void scatter_rows_kernel(const bf16* __restrict__ src, const int64_t* __restrict__ idx,
+                                                          bf16* __restrict__ dst, int n, int H, int64_t V) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int i = blockIdx.x * (NT / 64) + wid; i < n; i += gridDim.x * (NT / 64)) {
+        const int64_t r = idx[i];
+        if (r < 0 || r >= V) continue;
+        for (int c = lane * 4; c < H; c += 256)  // duplicates of an index carry identical rows: plain stores
+            *reinterpret_cast<bf16x4*>(dst + r * H + c) = *reinterpret_cast<const bf16x4*>(src + (int64_t)i * H + c);
+    }
+}
+
 extern "C" int xggm_zero_diag_f32(const float* in, float* out, int B, int N, hipStream_t st) {
     XGGM_REQUIRE(in && out && B > 0 && N > 0, "xggm_zero_diag_f32: bad arguments");
     const int64_t total = (int64_t)B * N * N;
@@ -175,6 +202,17 @@ extern "C" int xggm_pad_rows_bf16(const void* src, int src_f32, void* dst, int r
     if (src_f32) hipLaunchKernelGGL(pad_rows_kernel<float>, dim3(grid1d(total)), dim3(NT), 0, st, (const float*)src, (bf16*)dst, total, n, ld);
     else hipLaunchKernelGGL(pad_rows_kernel<bf16>, dim3(grid1d(total)), dim3(NT), 0, st, (const bf16*)src, (bf16*)dst, total, n, ld);
     return xggm_check_launch("xggm_pad_rows_bf16");
+}
+
+extern "C" int xggm_gather_rows_bf16(const float* src, const int64_t* idx, void* dst, int n, int H, int64_t V, hipStream_t st) {
+    XGGM_REQUIRE(src && idx && dst && n > 0 && H > 0 && H % 4 == 0 && V > 0, "xggm_gather_rows_bf16: bad arguments");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(std::min(ceil_div(n, NT / 64), 2048)), dim3(NT), 0, st, src, idx, (bf16*)dst, n, H, V);
+    return xggm_check_launch("xggm_gather_rows_bf16");
+}
+extern "C" int xggm_scatter_rows_bf16(const void* src, const int64_t* idx, void* dst, int n, int H, int64_t V, hipStream_t st) {
+    XGGM_REQUIRE(src && idx && dst && n > 0 && H > 0 && H % 4 == 0 && V > 0, "xggm_scatter_rows_bf16: bad arguments");
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(std::min(ceil_div(n, NT / 64), 2048)), dim3(NT), 0, st, (const bf16*)src, idx, (bf16*)dst, n, H, V);
+    return xggm_check_launch("xggm_scatter_rows_bf16");
 }
 
 extern "C" int xggm_additive_mask(const int64_t* mask, float* out, int64_t n, hipStream_t st) {

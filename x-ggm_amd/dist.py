@@ -76,6 +76,66 @@ class GradSync:
             else:
                 a.wire[s:e].copy_(a.grads[s:e])
 
+    # ---- the word-embedding table: only the rows some rank touched go on the links
+    def set_sparse_table(self, o, rows, H, ids_of):
+        """the gradient of an embedding table (arena elements [o, o + rows * H), fp32, accumulated by scatter-adds) is
+        zero outside the rows of the tokens of this step: instead of all-reducing 30522 x 768 values (47 MB of bf16,
+        the largest piece of the LAST, exposed stage of the exchange) the ranks all-gather their token ids (world x
+        B x 20 int64), gather those rows of their own gradient into a compact bf16 buffer (world x 640 rows, 7.9 MB at
+        8 ranks), all-reduce THAT, and write the summed rows back over the wire arena's table.  Identical on every
+        rank (the sum is the collective's); ``ids_of()`` returns this pass's [B, T] token ids on the device."""
+        self.table = (int(o), int(rows), int(H), ids_of)
+
+    def _without_table(self, ranges):
+        """ranges minus the table's; whether the table was inside"""
+        t = getattr(self, "table", None)
+        if t is None or self.arena is None or self.world == 1 and not self.force:
+            return ranges, False
+        o, e = t[0], t[0] + t[1] * t[2]
+        out, hit = [], False
+        for s, f in ranges:
+            if f <= o or s >= e:
+                out.append((s, f))
+                continue
+            if s > o or f < e:
+                return ranges, False  # only part of the table in these ranges: no special path
+            hit = True
+            if s < o:
+                out.append((s, o))
+            if f > e:
+                out.append((e, f))
+        return out, hit
+
+    def _begin_table(self):
+        o, V, H, ids_of = self.table
+        ids = ids_of().reshape(-1).contiguous()
+        n = ids.numel()
+        ids_all = torch.empty(self.world * n, dtype=torch.int64, device=ids.device)
+        if self.backend == "nccl":
+            dist.all_gather_into_tensor(ids_all, ids, group=self.group)
+        else:
+            dist.all_gather([ids_all[i * n:(i + 1) * n] for i in range(self.world)], ids, group=self.group)
+        a = self.arena
+        g = a.grads[o:o + V * H].view(V, H)
+        if g.is_cuda:
+            from . import ops
+            rows = ops.gather_rows(g, ids_all)
+        else:
+            rows = g[ids_all].to(torch.bfloat16)
+        work = dist.all_reduce(rows, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return (rows, ids_all, work)
+
+    def _finish_table(self, h):
+        rows, ids_all, work = h
+        work.wait()
+        o, V, H, _ = self.table
+        w = self.arena.wire[o:o + V * H].view(V, H)
+        if w.is_cuda:
+            from . import ops
+            ops.scatter_rows(rows, ids_all, w)
+        else:
+            w[ids_all] = rows
+
     @staticmethod
     def merged(ranges):
         """touching ranges as one -- also across the < 256-element alignment gap between two arena groups, which no
@@ -91,15 +151,19 @@ class GradSync:
     def _begin_inplace(self, ranges):
         # SUM, not AVG: the norm pass and the update take the average (``arena.grad_scale`` = 1 / world) on the way
         # in.  Same bytes on the links and no pre-multiply kernel (on a one-rank group RCCL then launches nothing).
-        self.cast_vectors(ranges)
+        self.cast_vectors(ranges)  # (the table included: its untouched rows are zeros on every rank)
         w = self.arena.wire
-        rs = self.merged(ranges)
+        dense, sparse = self._without_table(ranges)
+        tab = self._begin_table() if sparse else None
+        rs = self.merged(dense)
         works = [dist.all_reduce(w[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for s, e in rs]
-        return ("inplace", rs, works, True)
+        return ("inplace", rs, works, True, tab)
 
     def _finish_inplace(self, handle):
         for wk in handle[2]:
             wk.wait()
+        if len(handle) > 4 and handle[4] is not None:
+            self._finish_table(handle[4])
 
     def sync(self, ranges):
         """average ``flat_grads[s:e]`` over ranks for every (s, e) in ``ranges``."""
@@ -255,7 +319,9 @@ class ShardedUpdate(GradSync):
         w = self.arena.wire
         nccl = self.backend == "nccl"
         op = dist.ReduceOp.SUM  # the average is taken by the norm pass and the update (arena.grad_scale)
-        mats, vecs = self.split(ranges)
+        dense, sparse = self._without_table(ranges)
+        tab = self._begin_table() if sparse else None
+        mats, vecs = self.split(dense)
         works = []
         for run in mats:
             self.runs.append(run)
@@ -267,7 +333,7 @@ class ShardedUpdate(GradSync):
             else:     # gloo has no reduce-scatter: all-reduce, every rank then uses its slice only
                 works.append(dist.all_reduce(w[a:b], op=op, group=self.group, async_op=True))
         works += [dist.all_reduce(w[s:e], op=op, group=self.group, async_op=True) for s, e in vecs]
-        return ("inplace", mats + vecs, works, nccl)
+        return ("inplace", mats + vecs, works, nccl, tab)
 
     def begin(self, ranges, slot=0):
         if not ranges:

@@ -146,6 +146,7 @@ class EmbedFn(Function):
                                       mod.LayerNorm.bias.data, 1e-12, rt.p(rt.p_hidden), rt.rng, mod._sid)
         ctx.rt, ctx.mod, ctx.p = rt, mod, rt.p(rt.p_hidden)
         ctx.saved = (ids, seg, z, stats)
+        rt.emb_ids = ids  # the rows of the word table this pass touches (data parallel: dist.GradSync.set_sparse_table)
         return out
 
     @staticmethod

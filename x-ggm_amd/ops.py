@@ -910,6 +910,22 @@ def pad_rows(x, ld):
     return out[:, :x.shape[1]]
 
 
+def gather_rows(table_f32, idx, out=None):
+    """out[i] = bf16(table[idx[i]]): ``table`` fp32 [V, H] (contiguous), ``idx`` int64 [n] on the device"""
+    V, H = table_f32.shape
+    n = idx.numel()
+    if out is None:
+        out = torch.empty((n, H), device=table_f32.device, dtype=BF16)
+    call("xggm_gather_rows_bf16", ptr(table_f32), ptr(idx), ptr(out), n, H, V, stream())
+    return out
+
+
+def scatter_rows(rows_bf16, idx, table_bf16):
+    """table[idx[i]] = rows[i] (duplicate indices carry identical rows)"""
+    V, H = table_bf16.shape
+    call("xggm_scatter_rows_bf16", ptr(rows_bf16), ptr(idx), ptr(table_bf16), idx.numel(), H, V, stream())
+
+
 def add_scalars(terms):
     """sum of up to four 0-dim fp32 device tensors"""
     ts = [_c(t, F32) for t in terms]

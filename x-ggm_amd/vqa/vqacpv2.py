@@ -93,6 +93,12 @@ def enable_data_parallel(model, group=None, wire_dtype=None, overlap=None, zero1
         gs = rt.arena.zero1 = ShardedUpdate(rt.arena, group)
     else:
         gs = GradSync(rt.arena.grads, group, wire_dtype, arena=rt.arena if inplace else None)
+    if inplace and os.environ.get("XGGM_DP_SPARSE_EMB", "1") != "0":
+        # the word-embedding gradient: exchange the rows of this step's tokens, not the 30522-row table
+        wt = model.lxrt_encoder.model.bert.embeddings.word_embeddings.weight
+        xg = getattr(wt, "_xg", None)
+        if xg is not None and xg[0] is rt.arena:
+            gs.set_sparse_table(xg[1], wt.shape[0], wt.shape[1], lambda: rt.emb_ids)
     object.__setattr__(model, "_grad_sync", gs)
     rt.arena.sq_enabled = False  # the clip norm is that of the AVERAGED gradients: read them after the exchange
     if overlap is None:
