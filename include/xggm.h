@@ -56,8 +56,12 @@ const char* xggm_last_error(void);
  *   A(z,m,k) = A[z*a_bs + m*a_rs + k*a_ks],  B(z,k,n) = B[z*b_bs + n*b_ns + k*b_ks],
  *   C at C[z*c_bs + m*ldc + n].
  * epilogue: v = alpha*acc + bias[n]; preact (if given) <- v; v = act(v) (GELU_GRAD: v *
- * gelu'(aux)); v += residual; colsum[n] += sum_m v (if given: bias gradients, fp32 atomics);
- * C = accumulate ? C + v : v; C is T, or float when c_f32.
+ * gelu'(aux)); v += residual; C = accumulate ? C + v : v; C is T, or float when c_f32.
+ * colsum (or NULL; bias gradients): fp32 [batch][ceil(M/32)][N] PARTIAL column sums of v -- row r of batch z holds
+ * sum over output rows 32r .. 32r+31 of v[z][m][n]; every element is written exactly once by exactly one workgroup,
+ * in a fixed summation order (no floating-point atomics anywhere on the path: a pass gives the same bits whatever the
+ * scheduling).  The caller adds the partial rows into the gradient with xggm_partial_reduce_batch (K = 1, H = N,
+ * nblk = batch * ceil(M/32)).
  * Replaces nn.Linear forward/backward (src/lxrt/modeling.py:345-347, 385, 429, 442, 617;
  * src/module/gcn.py:28; src/vqa/vqacpv2_model.py:63-105) and torch.bmm(x, x^T)
  * (src/module/graph_generative_modeling.py:225). */
@@ -172,8 +176,10 @@ size_t xggm_colsum_workspace_bytes(int M, int N);
  * projections).  q/k/v/out rows of sample b start at row b*S of a matrix with the given row
  * stride (so fused-QKV buffers are addressed in place); head h occupies columns
  * [64h, 64h+64).  mask: additive [B,Sk] fp32 or NULL.  Sq, Sk <= 64, head_dim == 64.
- * backward: dbq/dbk/dbv (fp32 [heads*64], NULL ok) += column sums of dq/dk/dv = the gradients
- * of the query/key/value biases (fp32 atomics, one per column per workgroup). */
+ * backward: dbq/dbk/dbv (NULL ok; dbk and dbv go together): fp32 [B][heads*64] PARTIAL rows with batch stride db_bs
+ * elements -- row b receives the column sums of dq/dk/dv over sample b's rows, each element written once by the
+ * (sample, head) workgroup that owns it, in a fixed order.  Summed over b into the query/key/value bias gradients by
+ * xggm_partial_reduce_batch (ws = dbq laid out [B][3][H]: K = 3, nblk = B) -- no floating-point atomics. */
 int xggm_attn_fwd_f32(const void* q, const void* k, const void* v, const float* mask, void* out, int B, int heads, int Sq,
                       int Sk, int head_dim, int64_t q_rs, int64_t k_rs, int64_t v_rs, int64_t o_rs, float scale, float p,
                       const uint64_t* rng, uint32_t sid, xggm_stream_t stream);
@@ -183,11 +189,12 @@ int xggm_attn_fwd_bf16(const void* q, const void* k, const void* v, const float*
 int xggm_attn_bwd_f32(const void* q, const void* k, const void* v, const float* mask, const void* d_out, void* dq, void* dk,
                       void* dv, int B, int heads, int Sq, int Sk, int head_dim, int64_t q_rs, int64_t k_rs, int64_t v_rs,
                       int64_t o_rs, int64_t dq_rs, int64_t dk_rs, int64_t dv_rs, float scale, float p, const uint64_t* rng,
-                      uint32_t sid, float* dbq, float* dbk, float* dbv, xggm_stream_t stream);
+                      uint32_t sid, float* dbq, float* dbk, float* dbv, int64_t db_bs, xggm_stream_t stream);
 int xggm_attn_bwd_bf16(const void* q, const void* k, const void* v, const float* mask, const void* d_out, void* dq,
                        void* dk, void* dv, int B, int heads, int Sq, int Sk, int head_dim, int64_t q_rs, int64_t k_rs,
                        int64_t v_rs, int64_t o_rs, int64_t dq_rs, int64_t dk_rs, int64_t dv_rs, float scale, float p,
-                       const uint64_t* rng, uint32_t sid, float* dbq, float* dbk, float* dbv, xggm_stream_t stream);
+                       const uint64_t* rng, uint32_t sid, float* dbq, float* dbk, float* dbv, int64_t db_bs,
+                       xggm_stream_t stream);
 
 /* Grouped form: independent attention problems (the language and the vision stream of a layer, or
  * the two directions of a cross-attention layer, src/lxrt/modeling.py:485-516) in one launch; two
@@ -211,6 +218,7 @@ typedef struct xggm_attn_problem {
     float* dbq;
     float* dbk;
     float* dbv;
+    int64_t db_bs; /* batch stride (floats) of the dbq / dbk / dbv partial rows, see above */
     /* forward, bf16 storage only: out8 (or NULL) = e4m3 copy of `out` scaled by *qscale (NULL = 1), rows of o_rs
      * bytes -- the A operand of the fp8 output projection; *amax (or NULL) raised to max |out| */
     void* out8;
@@ -358,9 +366,11 @@ int xggm_aggregate_f32(const float* M, const void* x, void* out, int B, int N, i
                        const float* scale_ptr, float self_w, int accumulate, xggm_stream_t stream);
 int xggm_aggregate_bf16(const float* M, const void* x, void* out, int B, int N, int H, int mode, float scale,
                         const float* scale_ptr, float self_w, int accumulate, xggm_stream_t stream);
-/* *out += sum_{b,i,c} dh[b,i,c] * (M @ x)[b,i,c]   (gradient of GIN's eps) */
-int xggm_agg_dot_f32(const float* M, const void* x, const void* dh, float* out, int B, int N, int H, xggm_stream_t stream);
-int xggm_agg_dot_bf16(const float* M, const void* x, const void* dh, float* out, int B, int N, int H, xggm_stream_t stream);
+/* *out += sum_{b,i,c} dh[b,i,c] * (M @ x)[b,i,c]   (gradient of GIN's eps); ws: see XGGM_SUM_WS_FLOATS */
+int xggm_agg_dot_f32(const float* M, const void* x, const void* dh, float* out, int B, int N, int H, float* ws,
+                     xggm_stream_t stream);
+int xggm_agg_dot_bf16(const float* M, const void* x, const void* dh, float* out, int B, int N, int H, float* ws,
+                      xggm_stream_t stream);
 /* adjacency regeneration from S = x x^T: src/module/graph_generative_modeling.py:225-228.
  * adj[i][j] = sigmoid(S[i][j] / max_r S[r][i]), zero diagonal; colmax/argmax [B,N] saved
  * (argmax = first index of the column maximum, as torch.max). */
@@ -414,9 +424,16 @@ int xggm_dropout_bf16(const void* x, void* out, int64_t n, float p, const uint64
                       xggm_stream_t stream);
 
 /* ---- losses (scalars are device fp32; *loss must hold the running value, usually 0) ------
+ * Sums over the whole grid are taken WITHOUT floating-point atomics: every workgroup leaves its partial in `ws`, the
+ * workgroup that finishes last adds the partials in index order and updates *loss (same bits whatever the
+ * scheduling).  `ws`: XGGM_SUM_WS_FLOATS floats of device memory owned by the caller, ws[0] == 0 at launch (the
+ * kernels leave it 0, so one zeroed buffer serves every launch of a stream).
  * loss_func: src/vqa/vqacpv2.py:48-51.  *loss += coef * sum (s-g)^2; ds = gout*2*coef*(s-g) */
-int xggm_dsm_loss_fwd_f32(const void* s, const float* g, float* loss, int64_t n, float coef, xggm_stream_t stream);
-int xggm_dsm_loss_fwd_bf16(const void* s, const float* g, float* loss, int64_t n, float coef, xggm_stream_t stream);
+#define XGGM_SUM_WS_FLOATS 4104
+int xggm_dsm_loss_fwd_f32(const void* s, const float* g, float* loss, int64_t n, float coef, float* ws,
+                          xggm_stream_t stream);
+int xggm_dsm_loss_fwd_bf16(const void* s, const float* g, float* loss, int64_t n, float coef, float* ws,
+                           xggm_stream_t stream);
 int xggm_dsm_loss_bwd_f32(const void* s, const float* g, const float* gout, void* ds, int64_t n, float coef,
                           xggm_stream_t stream);
 int xggm_dsm_loss_bwd_bf16(const void* s, const float* g, const float* gout, void* ds, int64_t n, float coef,
@@ -424,11 +441,12 @@ int xggm_dsm_loss_bwd_bf16(const void* s, const float* g, const float* gout, voi
 /* compute_kl_loss: src/vqa/vqacpv2.py:54-61.  rows x W; *loss += coef * sum_rows f (NULL
  * skips); dx/dy (NULL ok) = [+] *gout * coef * df. */
 int xggm_symkl_f32(const void* x, const void* y, float* loss, const float* gout, void* dx, void* dy, int rows, int W,
-                   float coef, int accumulate, xggm_stream_t stream);
+                   float coef, int accumulate, float* ws, xggm_stream_t stream);
 int xggm_symkl_bf16(const void* x, const void* y, float* loss, const float* gout, void* dx, void* dy, int rows, int W,
-                    float coef, int accumulate, xggm_stream_t stream);
+                    float coef, int accumulate, float* ws, xggm_stream_t stream);
 /* nn.BCEWithLogitsLoss()(logit, target) * A: src/vqa/vqacpv2.py:131,173; logits fp32 */
-int xggm_bce_fwd(const float* logit, const float* target, float* loss, int64_t n, float coef, xggm_stream_t stream);
+int xggm_bce_fwd(const float* logit, const float* target, float* loss, int64_t n, float coef, float* ws,
+                 xggm_stream_t stream);
 int xggm_bce_bwd_f32(const float* logit, const float* target, const float* gout, void* dlogit, int64_t n, float coef,
                      xggm_stream_t stream);
 int xggm_bce_bwd_bf16(const float* logit, const float* target, const float* gout, void* dlogit, int64_t n, float coef,

@@ -13,6 +13,24 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+# Order for a `-x` run: the cheapest and most fundamental checks first.  Host-only files, then the per-kernel parity
+# cases, then the model-level golden / oracle comparisons, then the captured-engine tests; inside the engine file the
+# cases that spawn bench.py / torch.distributed.run subprocesses go last.  A failure in a late, composite test can then
+# never hide whether the kernels and the model match the oracle.
+_FILE_ORDER = ["test_oracle_golden", "test_abi_cpu", "test_data_cpu", "test_dist_cpu", "test_kernels_gpu", "test_model_gpu",
+               "test_engine_gpu"]
+_LATE = ("bench", "data_parallel", "rccl", "spawn")
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def key(it):
+        mod = it.module.__name__.rsplit(".", 1)[-1]
+        rank = _FILE_ORDER.index(mod) if mod in _FILE_ORDER else len(_FILE_ORDER)
+        late = mod == "test_engine_gpu" and any(w in it.name for w in _LATE)
+        return (rank, late)
+    items.sort(key=key)  # stable: the order inside a file is kept
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -129,9 +129,13 @@ template <typename T> __global__ __launch_bounds__(NT) void attn_fwd_kernel(Attn
 
 template <typename T>
 __global__ __launch_bounds__(NT) void attn_bwd_kernel(AttnArgs a, const T* d_out, T* dq, T* dk, T* dv, int64_t dq_rs,
-                                                      int64_t dk_rs, int64_t dv_rs, float* dbq, float* dbk, float* dbv) {
-    __shared__ float csum[3][D];  // column sums of dQ / dK / dV over this sample's rows (bias gradients)
-    if (threadIdx.x < 3 * D) (&csum[0][0])[threadIdx.x] = 0.f;
+                                                      int64_t dk_rs, int64_t dv_rs, float* dbq, float* dbk, float* dbv,
+                                                      int64_t db_bs) {
+    // column sums of dQ / dK / dV over this sample's rows (bias gradients): every thread keeps the sums of ITS column
+    // group over its rows (NT % 16 == 0: a thread's columns never change), the threads of a column group are added in
+    // index order through `red`, and the result is a partial row of this (sample, head) nobody else writes
+    __shared__ float red[NT / 16][D];
+    float cq[4] = {0.f, 0.f, 0.f, 0.f}, ck[4] = {0.f, 0.f, 0.f, 0.f}, cv[4] = {0.f, 0.f, 0.f, 0.f};
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
@@ -183,17 +187,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(AttnArgs a, const T* d_out
             o[3] += s * kk.w;
         }
         if (valid) store4(dq + ((int64_t)b * Sq + i) * dq_rs + h * D + c, o);
-        if (dbq) {
-            // lanes l, l+16, l+32, l+48 hold the same 4 columns of 4 consecutive rows: fold them
-            // with two shuffles, then one LDS atomic per column from the low 16 lanes
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t = o[e];
-                t += __shfl_xor(t, 16, 64);
-                t += __shfl_xor(t, 32, 64);
-                if ((tid & 63) < 16) atomicAdd(&csum[0][c + e], t);
-            }
-        }
+        for (int e = 0; e < 4; ++e) cq[e] += o[e];  // rows past the end contributed zeros
     }
     // dK[j][c] = sum_i dS[i][j] Q[i][c];  dV[j][c] = sum_i P[i][j] D[i][j] dO[i][c]
     for (int w = tid; w < ((Sk * 16 + 63) & ~63); w += NT) {
@@ -219,29 +214,26 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(AttnArgs a, const T* d_out
             store4(dk + ((int64_t)b * Sk + j) * dk_rs + h * D + c, ok);
             store4(dv + ((int64_t)b * Sk + j) * dv_rs + h * D + c, ov);
         }
-        if (dbk) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t1 = ok[e], t2 = ov[e];
-                t1 += __shfl_xor(t1, 16, 64);
-                t2 += __shfl_xor(t2, 16, 64);
-                t1 += __shfl_xor(t1, 32, 64);
-                t2 += __shfl_xor(t2, 32, 64);
-                if ((tid & 63) < 16) {
-                    atomicAdd(&csum[1][c + e], t1);
-                    atomicAdd(&csum[2][c + e], t2);
-                }
-            }
+        for (int e = 0; e < 4; ++e) {
+            ck[e] += ok[e];
+            cv[e] += ov[e];
         }
     }
-    if (dbq || dbk) {
-        // one fp32 atomic per column per (sample, head) workgroup: <= B adders per address
+    auto fold = [&](const float (&c4)[4], float* dst) {  // uniform: every thread of the workgroup calls it
         __syncthreads();
-        const int t = threadIdx.x;
-        if (t < D && dbq) atomicAdd(dbq + h * D + t, csum[0][t]);
-        else if (t >= D && t < 2 * D && dbk) atomicAdd(dbk + h * D + (t - D), csum[1][t - D]);
-        else if (t >= 2 * D && t < 3 * D && dbv) atomicAdd(dbv + h * D + (t - 2 * D), csum[2][t - 2 * D]);
-    }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[tid >> 4][(tid & 15) * 4 + e] = c4[e];
+        __syncthreads();
+        if (tid < D) {
+            float s = 0.f;
+            for (int g = 0; g < NT / 16; ++g) s += red[g][tid];  // fixed order
+            dst[(int64_t)b * db_bs + h * D + tid] = s;
+        }
+    };
+    if (dbq) fold(cq, dbq);
+    if (dbk) fold(ck, dbk);
+    if (dbv) fold(cv, dbv);
 }
 
 int check(const char* who, const AttnArgs& a, int head_dim) {
@@ -303,6 +295,9 @@ int attn_bwd_grouped(const xggm_attn_problem* probs, int n, int head_dim, const 
         XGGM_REQUIRE(q.d_out && q.dq && q.dk && q.dv, "xggm_attn_bwd: null pointer");
         XGGM_REQUIRE(q.dq_rs % 4 == 0 && q.dk_rs % 4 == 0 && q.dv_rs % 4 == 0, "xggm_attn_bwd: row strides must be multiples of 4");
         XGGM_REQUIRE((q.dbk == nullptr) == (q.dbv == nullptr), "xggm_attn_bwd: dbk and dbv go together");
+        XGGM_REQUIRE(!(q.dbq || q.dbk) || q.B == 1 || q.db_bs >= (int64_t)q.heads * D,
+                     "xggm_attn_bwd: the bias-gradient partial rows need a batch stride db_bs >= heads * 64 (got %lld)",
+                     (long long)q.db_bs);
         const bool grads8 = (reinterpret_cast<uintptr_t>(q.dq) | reinterpret_cast<uintptr_t>(q.dk) | reinterpret_cast<uintptr_t>(q.dv)) % 8 == 0;
         if (sizeof(T) == 2 && grads8 && mfma_ok(q.q, q.k, q.v, q.d_out, q.q_rs, q.k_rs, q.v_rs, q.o_rs)) {  // 8-byte gradient stores
             pend[np++] = q;
@@ -314,7 +309,7 @@ int attn_bwd_grouped(const xggm_attn_problem* probs, int n, int head_dim, const 
         }
         const size_t lds = sizeof(float) * ((size_t)(2 * q.Sq + 2 * q.Sk) * LD + 3 * (size_t)q.Sq * (q.Sk + 1));
         hipLaunchKernelGGL((attn_bwd_kernel<T>), dim3(q.B * q.heads), dim3(NT), lds, st, a, (const T*)q.d_out, (T*)q.dq, (T*)q.dk,
-                           (T*)q.dv, q.dq_rs, q.dk_rs, q.dv_rs, q.dbq, q.dbk, q.dbv);
+                           (T*)q.dv, q.dq_rs, q.dk_rs, q.dv_rs, q.dbq, q.dbk, q.dbv, q.db_bs);
         if (int e = xggm_check_launch("xggm_attn_bwd")) return e;
     }
     if (np) return xggm_attn_bwd_mfma_group(pend, np, rng, st);
@@ -337,7 +332,7 @@ template <typename T>
 int attn_bwd(const void* q, const void* k, const void* v, const float* mask, const void* d_out, void* dq, void* dk, void* dv,
              int B, int heads, int Sq, int Sk, int head_dim, int64_t q_rs, int64_t k_rs, int64_t v_rs, int64_t o_rs,
              int64_t dq_rs, int64_t dk_rs, int64_t dv_rs, float scale, float p, const uint64_t* rng, uint32_t sid,
-             float* dbq, float* dbk, float* dbv, hipStream_t st) {
+             float* dbq, float* dbk, float* dbv, int64_t db_bs, hipStream_t st) {
     xggm_attn_problem pr{};
     pr.q = q; pr.k = k; pr.v = v; pr.mask = mask;
     pr.B = B; pr.heads = heads; pr.Sq = Sq; pr.Sk = Sk;
@@ -345,7 +340,7 @@ int attn_bwd(const void* q, const void* k, const void* v, const float* mask, con
     pr.scale = scale; pr.p = p; pr.sid = sid;
     pr.d_out = d_out; pr.dq = dq; pr.dk = dk; pr.dv = dv;
     pr.dq_rs = dq_rs; pr.dk_rs = dk_rs; pr.dv_rs = dv_rs;
-    pr.dbq = dbq; pr.dbk = dbk; pr.dbv = dbv;
+    pr.dbq = dbq; pr.dbk = dbk; pr.dbv = dbv; pr.db_bs = db_bs;
     return attn_bwd_grouped<T>(&pr, 1, head_dim, rng, st);
 }
 
@@ -362,9 +357,10 @@ int attn_bwd(const void* q, const void* k, const void* v, const float* mask, con
                                        void* dq, void* dk, void* dv, int B, int heads, int Sq, int Sk, int head_dim,      \
                                        int64_t q_rs, int64_t k_rs, int64_t v_rs, int64_t o_rs, int64_t dq_rs,             \
                                        int64_t dk_rs, int64_t dv_rs, float scale, float p, const uint64_t* rng,           \
-                                       uint32_t sid, float* dbq, float* dbk, float* dbv, hipStream_t st) {                \
+                                       uint32_t sid, float* dbq, float* dbk, float* dbv, int64_t db_bs,                  \
+                                       hipStream_t st) {                                                                  \
         return attn_bwd<T>(q, k, v, mask, d_out, dq, dk, dv, B, heads, Sq, Sk, head_dim, q_rs, k_rs, v_rs, o_rs, dq_rs,    \
-                           dk_rs, dv_rs, scale, p, rng, sid, dbq, dbk, dbv, st);                                           \
+                           dk_rs, dv_rs, scale, p, rng, sid, dbq, dbk, dbv, db_bs, st);                                    \
     }                                                                                                                      \
     extern "C" int xggm_attn_fwd_grouped_##SUF(const xggm_attn_problem* probs, int n, int head_dim, const uint64_t* rng,   \
                                                hipStream_t st) {                                                          \

@@ -45,6 +45,7 @@ struct MSeg {
     bf16 *dq, *dk, *dv;
     int64_t dq_rs, dk_rs, dv_rs;
     float *dbq, *dbk, *dbv;
+    int64_t db_bs;
 };
 struct MGroup {
     MSeg s[2];
@@ -351,14 +352,15 @@ __device__ __forceinline__ void store_grad_tile(const float4_t& acc, bf16* dst, 
             s += dpp_move<0x4E>(s);
             s += dpp_move<0x141>(s);
             s += dpp_move<0x140>(s);  // every lane of the 16-lane row holds the column's sum over the tile's rows
-            if (fr == 0) atomicAdd(csum + col0 + 4 * fq + r, s);
+            if (fr == 0) csum[col0 + 4 * fq + r] = s;  // this row tile's own slot: no atomics, see the kernel's tail
         }
     }
 }
 
 __global__ __launch_bounds__(NT) void attn_bwd_mfma_kernel(MGroup G) {
-    __shared__ float csum[3][D];
-    if (threadIdx.x < 3 * D) (&csum[0][0])[threadIdx.x] = 0.f;
+    // bias gradients: column sums of dQ / dK / dV, one slot per 16-row tile (<= 4: S <= 64), written by the wave that
+    // owns the tile and added in tile order at the end -- the same bits whatever the scheduling
+    __shared__ float csum[3][4][D];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int si = (int)blockIdx.x >= G.start1 ? 1 : 0;
     const MSeg sg = G.s[si];
@@ -489,26 +491,30 @@ __global__ __launch_bounds__(NT) void attn_bwd_mfma_kernel(MGroup G) {
             const int ti = t >> 2, tc = t & 3;  // dQ = dS K: k = j
             for (int ks = 0; ks < RK; ks += 32)
                 acc = MFMA(frag_tr(Ks, LDT, ks, tc * 16, lane), frag_rows(dSb, LDP, ti * 16, ks, lane), acc);
-            store_grad_tile(acc, dq + h * D, dq_rs, b * Sq, Sq, ti * 16, tc * 16, dbq ? csum[0] : nullptr, lane);
+            store_grad_tile(acc, dq + h * D, dq_rs, b * Sq, Sq, ti * 16, tc * 16, dbq ? csum[0][ti] : nullptr, lane);
         } else if (t < n_dq + n_dk) {
             const int u = t - n_dq, tj = u >> 2, tc = u & 3;  // dK = dS^T Q: k = i
             for (int ks = 0; ks < RQ; ks += 32)
                 acc = MFMA(frag_tr(Qs, LDT, ks, tc * 16, lane), frag_tr(dSb, LDP, ks, tj * 16, lane), acc);
-            store_grad_tile(acc, dk + h * D, dk_rs, b * Sk, Sk, tj * 16, tc * 16, dbk ? csum[1] : nullptr, lane);
+            store_grad_tile(acc, dk + h * D, dk_rs, b * Sk, Sk, tj * 16, tc * 16, dbk ? csum[1][tj] : nullptr, lane);
         } else {
             const int u = t - n_dq - n_dk, tj = u >> 2, tc = u & 3;  // dV = (P D)^T dO: k = i
             for (int ks = 0; ks < RQ; ks += 32)
                 acc = MFMA(frag_tr(dOs, LDT, ks, tc * 16, lane), frag_tr(Pdb, LDP, ks, tj * 16, lane), acc);
-            store_grad_tile(acc, dv + h * D, dv_rs, b * Sk, Sk, tj * 16, tc * 16, dbv ? csum[2] : nullptr, lane);
+            store_grad_tile(acc, dv + h * D, dv_rs, b * Sk, Sk, tj * 16, tc * 16, dbv ? csum[2][tj] : nullptr, lane);
         }
     }
     ASTAMP(stp, 5);
     if (dbq || dbk) {
         __syncthreads();
-        const int t = threadIdx.x;
-        if (t < D && dbq) atomicAdd(dbq + h * D + t, csum[0][t]);
-        else if (t >= D && t < 2 * D && dbk) atomicAdd(dbk + h * D + (t - D), csum[1][t - D]);
-        else if (t >= 2 * D && t < 3 * D && dbv) atomicAdd(dbv + h * D + (t - 2 * D), csum[2][t - 2 * D]);
+        const int t = threadIdx.x, kind = t / D, c = t - kind * D;
+        float* dst = kind == 0 ? dbq : kind == 1 ? dbk : kind == 2 ? dbv : nullptr;
+        if (dst) {
+            const int nt = kind == 0 ? tq : tk;
+            float s = csum[kind][0][c];
+            for (int u = 1; u < nt; ++u) s += csum[kind][u][c];
+            dst[(int64_t)b * sg.db_bs + h * D + c] = s;  // partial row of this sample: summed over the batch by the reduce launch
+        }
     }
 }
 
@@ -532,7 +538,7 @@ MSeg make_seg(const xggm_attn_problem& q, const uint64_t* rng) {
     g.d_out = (const bf16*)q.d_out;
     g.dq = (bf16*)q.dq; g.dk = (bf16*)q.dk; g.dv = (bf16*)q.dv;
     g.dq_rs = q.dq_rs; g.dk_rs = q.dk_rs; g.dv_rs = q.dv_rs;
-    g.dbq = q.dbq; g.dbk = q.dbk; g.dbv = q.dbv;
+    g.dbq = q.dbq; g.dbk = q.dbk; g.dbv = q.dbv; g.db_bs = q.db_bs;
     return g;
 }
 }  // namespace

@@ -228,5 +228,44 @@ struct Q8 {
     }
 };
 
+// ---------------------------------------------------------------- grid-wide sums without floating-point atomics
+// A scalar that many workgroups contribute to (a loss, GIN's eps gradient) used to be one atomicAdd per workgroup: the
+// order of the adds, and with it the last bits of the sum, depended on which workgroup finished first.  Instead every
+// workgroup leaves its partial in ws[XGGM_SUM_WS_HEAD + flat block id] and takes a ticket from the counter in ws[0];
+// the workgroup that draws the LAST ticket adds the partials in index order.  Same bits whatever the scheduling, one
+// launch.  (The release fence per workgroup is what DESIGN.md section 4.2 found too expensive for the gigabyte-sized
+// norm pass -- that one keeps its two launches -- but these kernels move a few megabytes at most.)
+// `ws`: XGGM_SUM_WS_FLOATS floats (xggm.h), ws[0] == 0 at launch; the kernel leaves it 0.
+// Call from EVERY thread of EVERY workgroup (barriers inside); `part` is read from thread 0.  Returns true on thread 0
+// of the finishing workgroup with `total` set.
+constexpr int SUM_WS_HEAD = 8;
+__device__ __forceinline__ bool ordered_grid_sum(float part, float* ws, int nblk, int blk, float& total) {
+    __shared__ int s_last;
+    __shared__ float s_red[16];
+    unsigned* counter = reinterpret_cast<unsigned*>(ws);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(ws + SUM_WS_HEAD + blk, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();  // release: the partial is visible device-wide before the ticket is
+        const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == (unsigned)nblk - 1u) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return false;
+    __threadfence();  // acquire: every other workgroup's partial
+    float t = 0.f;
+    for (int b = threadIdx.x; b < nblk; b += blockDim.x)  // thread-strided, then waves in index order: fixed
+        t += __hip_atomic_load(ws + SUM_WS_HEAD + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = wave_sum(t);
+    const int nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x != 0) return false;
+    float r = s_red[0];
+    for (int w = 1; w < nw; ++w) r += s_red[w];
+    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    total = r;
+    return true;
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

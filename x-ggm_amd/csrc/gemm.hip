@@ -32,7 +32,8 @@ struct GemmArgs {
     const void* residual;  // T, layout of C (same ldc / batch stride), or null
     void* preact;          // T, layout of C, or null: alpha*acc + bias before the activation
     const void* aux;       // T, layout of C: pre-activation u for act == GELU_GRAD
-    float* colsum;         // [N] or null: += column sums of the stored result (bias gradients)
+    float* colsum;         // or null: [batch][ceil(M/32)][N] partial column sums of the stored result, one row per block of 32
+                           // output rows, every element written once by exactly one workgroup (no atomics: see xggm.h)
     float* sqsum;          // or null: [ceil(M/64)][ceil(N/64)] sums of squares of the STORED fp32 values per 64 x 64 block
     unsigned char* c8;     // or null: e4m3 copy of the stored result (layout of C), scaled by *c8_qscale
     const float* c8_qscale;
@@ -168,8 +169,8 @@ template <typename T> __device__ __forceinline__ float act_apply(int act, float 
 
 // one 16x16 accumulator tile -> C: lane holds column `col`, rows row0 .. row0+3
 template <typename T>
-__device__ __forceinline__ void epilogue_tile(const GemmArgs& g, const float4_t& acc, int row0, int col, int bz) {
-    if (col >= g.N) return;
+__device__ __forceinline__ float epilogue_tile(const GemmArgs& g, const float4_t& acc, int row0, int col, int bz) {
+    if (col >= g.N) return 0.f;
     const int64_t coff = (int64_t)bz * g.c_bs;
     const float bias = g.bias ? g.bias[col] : 0.0f;
     float csum = 0.f;
@@ -197,7 +198,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& g, const float4_t&
         }
         csum += v;
     }
-    if (g.colsum) atomicAdd(g.colsum + col, csum);
+    return csum;  // this lane's column over its (valid) rows: folded per 32-row block by the caller
 }
 
 template <typename T> __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
@@ -260,9 +261,20 @@ template <typename T> __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs
 
     // epilogue: C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j) {
+        float cs = 0.f;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) epilogue_tile<T>(g, acc[i][j], m0 + wm + i * 16 + fq * 4, n0 + wn + j * 16 + fr, bz);
+        for (int i = 0; i < 2; ++i) cs += epilogue_tile<T>(g, acc[i][j], m0 + wm + i * 16 + fq * 4, n0 + wn + j * 16 + fr, bz);
+        if (g.colsum) {
+            // a wave owns one block of 32 output rows: its column sums are folded over the four row groups (fixed
+            // order) and stored by ONE lane per column -- a partial row nobody else writes
+            cs += __shfl_xor(cs, 16, 64);
+            cs += __shfl_xor(cs, 32, 64);
+            const int col = n0 + wn + j * 16 + fr, slot = (m0 + wm) >> 5;
+            if (fq == 0 && col < g.N && m0 + wm < g.M)
+                g.colsum[((int64_t)bz * ((g.M + 31) >> 5) + slot) * g.N + col] = cs;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -585,12 +597,18 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, const float4_
         lds_barrier();  // every chunk of the staged half has been read (and parked back for colsum)
         if (h == 0) STAMP(g, 3);
         if (g.colsum) {
-            // bias gradient: column sums of this half tile's stored values, one atomic per column
-            const int rows = min(HALF, g.M - (m0 + h * HALF));
-            if (tid < BN && n0 + tid < g.N && rows > 0) {
+            // bias gradient: column sums of this half tile's stored values per block of 32 output rows, each written
+            // by one thread in a fixed order into a partial row of its own (summed over the row blocks by
+            // xggm_partial_reduce_batch): no floating-point atomics, the same bits whatever the scheduling
+            constexpr int SUB = HALF / 32;
+            static_assert(HALF % 32 == 0 && SUB * BN <= NT, "column sums: 32-row blocks");
+            const int sub = tid / BN, cl = tid - sub * BN;
+            const int r0 = m0 + h * HALF + sub * 32;
+            if (sub < SUB && n0 + cl < g.N && r0 < g.M) {
+                const int rows = min(32, g.M - r0);
                 float sacc = 0.f;
-                for (int r = 0; r < rows; ++r) sacc += stage[r * LDS_LD + tid];
-                atomicAdd(g.colsum + n0 + tid, sacc);
+                for (int r = 0; r < rows; ++r) sacc += stage[(sub * 32 + r) * LDS_LD + cl];
+                g.colsum[((int64_t)bz * ((g.M + 31) >> 5) + (r0 >> 5)) * g.N + n0 + cl] = sacc;
             }
             lds_barrier();
         }

@@ -216,10 +216,10 @@ __global__ __launch_bounds__(NT) void aggregate_bf16_kernel(const float* __restr
     }
 }
 
-// d eps of GIN: sum_{b,i,c} dh[b,i,c] * (A @ x)[b,i,c]  -> one scalar (atomic)
+// d eps of GIN: sum_{b,i,c} dh[b,i,c] * (A @ x)[b,i,c]  -> one scalar
 template <typename T, int NP>
 __global__ __launch_bounds__(NT) void agg_dot_kernel(const float* __restrict__ Mx, const T* __restrict__ x,
-                                                     const T* __restrict__ dh, float* out, int N, int H) {
+                                                     const T* __restrict__ dh, float* out, int N, int H, float* ws) {
     __shared__ __attribute__((aligned(16))) float Mt[NP * NP];
     __shared__ float red[NT / 64];
     const int b = blockIdx.y, tid = threadIdx.x;
@@ -249,7 +249,10 @@ __global__ __launch_bounds__(NT) void agg_dot_kernel(const float* __restrict__ M
     total = wave_sum(total);
     if ((tid & 63) == 0) red[tid >> 6] = total;
     __syncthreads();
-    if (tid == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+    // the workgroups' sums are added in index order by the one that finishes last (ordered_grid_sum): no float atomics
+    float sum;
+    if (ordered_grid_sum((red[0] + red[1]) + (red[2] + red[3]), ws, gridDim.x * gridDim.y, blockIdx.y * gridDim.x + blockIdx.x, sum))
+        *out += sum;
 }
 
 // ------------------------------------------------------------------------------- adjacency regeneration
@@ -455,13 +458,15 @@ int aggregate(const float* M, const void* x, void* out, int B, int N, int H, int
 }
 
 template <typename T>
-int agg_dot(const float* M, const void* x, const void* dh, float* out, int B, int N, int H, hipStream_t st) {
-    XGGM_REQUIRE(M && x && dh && out && B > 0 && N > 0 && N <= 64 && H > 0 && B <= 65535, "xggm_agg_dot: bad arguments");
+int agg_dot(const float* M, const void* x, const void* dh, float* out, int B, int N, int H, float* ws, hipStream_t st) {
+    XGGM_REQUIRE(M && x && dh && out && ws && B > 0 && N > 0 && N <= 64 && H > 0 && B <= 65535, "xggm_agg_dot: bad arguments");
     dim3 grid(ceil_div(H, NT), B);
+    XGGM_REQUIRE((int64_t)grid.x * grid.y <= XGGM_SUM_WS_FLOATS - 8, "xggm_agg_dot: %lld workgroups exceed the sum workspace",
+                 (long long)grid.x * grid.y);
     if (N <= 40)
-        hipLaunchKernelGGL((agg_dot_kernel<T, 40>), grid, dim3(NT), 0, st, M, (const T*)x, (const T*)dh, out, N, H);
+        hipLaunchKernelGGL((agg_dot_kernel<T, 40>), grid, dim3(NT), 0, st, M, (const T*)x, (const T*)dh, out, N, H, ws);
     else
-        hipLaunchKernelGGL((agg_dot_kernel<T, 64>), grid, dim3(NT), 0, st, M, (const T*)x, (const T*)dh, out, N, H);
+        hipLaunchKernelGGL((agg_dot_kernel<T, 64>), grid, dim3(NT), 0, st, M, (const T*)x, (const T*)dh, out, N, H, ws);
     return xggm_check_launch("xggm_agg_dot");
 }
 
@@ -520,8 +525,8 @@ extern "C" int xggm_triu_index(int k, int N, int* i_out, int* j_out) {
         return aggregate<T>(M, x, out, B, N, H, mode, scale, scale_ptr, self_w, accumulate, st);                          \
     }                                                                                                                      \
     extern "C" int xggm_agg_dot_##SUF(const float* M, const void* x, const void* dh, float* out, int B, int N, int H,     \
-                                      hipStream_t st) {                                                                   \
-        return agg_dot<T>(M, x, dh, out, B, N, H, st);                                                                    \
+                                      float* ws, hipStream_t st) {                                                        \
+        return agg_dot<T>(M, x, dh, out, B, N, H, ws, st);                                                                \
     }                                                                                                                      \
     extern "C" int xggm_feature_noise_##SUF(const void* x, const float* randn, void* out, float* gradlog, int64_t n,      \
                                             float sigma, const uint64_t* rng, uint32_t sid, hipStream_t st) {             \

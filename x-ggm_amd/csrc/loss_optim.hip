@@ -31,14 +31,15 @@ inline int grid1d(int64_t n, int cap = 1024) { return (int)std::min<int64_t>(cei
 // ------------------------------------------------------------------------------- DSM
 template <typename T>
 __global__ __launch_bounds__(NT) void dsm_fwd_kernel(const T* __restrict__ s, const float* __restrict__ g, float* loss,
-                                                     int64_t n, float coef) {
+                                                     int64_t n, float coef, float* ws) {
     float acc = 0.f;
     for (int64_t t = (int64_t)blockIdx.x * NT + threadIdx.x; t < n; t += (int64_t)gridDim.x * NT) {
         const float d = to_f32(s[t]) - g[t];
         acc += d * d;
     }
     acc = block_sum(acc);
-    if (threadIdx.x == 0) atomicAdd(loss, acc * coef);
+    float total;
+    if (ordered_grid_sum(acc, ws, gridDim.x, blockIdx.x, total)) *loss += total * coef;
 }
 template <typename T>
 __global__ __launch_bounds__(NT) void dsm_bwd_kernel(const T* __restrict__ s, const float* __restrict__ g,
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(NT) void dsm_bwd_kernel(const T* __restrict__ s, co
 template <typename T, int NV>
 __global__ __launch_bounds__(NT) void symkl_kernel(const T* __restrict__ x, const T* __restrict__ y, float* loss,
                                                    const float* __restrict__ gout, T* dx, T* dy, int rows, int W, float coef,
-                                                   int accumulate) {
+                                                   int accumulate, float* ws) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const float gk = coef * ((dx || dy) && gout ? *gout : 1.f);
     float total = 0.f;
@@ -123,20 +124,22 @@ __global__ __launch_bounds__(NT) void symkl_kernel(const T* __restrict__ x, cons
     }
     if (loss) {
         total = block_sum(total);
-        if (threadIdx.x == 0) atomicAdd(loss, total * coef);
+        float sum;
+        if (ordered_grid_sum(total, ws, gridDim.x, blockIdx.x, sum)) *loss += sum * coef;
     }
 }
 
 // ------------------------------------------------------------------------------- BCE with logits
 __global__ __launch_bounds__(NT) void bce_fwd_kernel(const float* __restrict__ l, const float* __restrict__ t, float* loss,
-                                                     int64_t n, float coef) {
+                                                     int64_t n, float coef, float* ws) {
     float acc = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
         const float z = l[i];
         acc += fmaxf(z, 0.f) - z * t[i] + log1pf(__expf(-fabsf(z)));
     }
     acc = block_sum(acc);
-    if (threadIdx.x == 0) atomicAdd(loss, acc * coef);
+    float total;
+    if (ordered_grid_sum(acc, ws, gridDim.x, blockIdx.x, total)) *loss += total * coef;
 }
 template <typename T>
 __global__ __launch_bounds__(NT) void bce_bwd_kernel(const float* __restrict__ l, const float* __restrict__ t,
@@ -483,15 +486,16 @@ __global__ __launch_bounds__(NT) void normal_kernel(float* out, int64_t n, const
 
 template <typename T>
 int symkl(const void* x, const void* y, float* loss, const float* gout, void* dx, void* dy, int rows, int W, float coef,
-          int accumulate, hipStream_t st) {
+          int accumulate, float* ws, hipStream_t st) {
     XGGM_REQUIRE(x && y && rows > 0 && W > 0, "xggm_symkl: bad arguments");
+    XGGM_REQUIRE(!loss || ws, "xggm_symkl: the loss sum needs its workspace (XGGM_SUM_WS_FLOATS floats, ws[0] == 0)");
     XGGM_REQUIRE(W <= 64 * 16, "xggm_symkl: row width %d > 1024", W);
     XGGM_REQUIRE(loss || dx || dy, "xggm_symkl: nothing to compute");
     const int grid = std::min(ceil_div(rows, 4), 1024);
     const int nv = ceil_div(W, 64);
 #define SYMKL_LAUNCH(NV)                                                                                               \
     hipLaunchKernelGGL((symkl_kernel<T, NV>), dim3(grid), dim3(NT), 0, st, (const T*)x, (const T*)y, loss, gout, (T*)dx, \
-                       (T*)dy, rows, W, coef, accumulate)
+                       (T*)dy, rows, W, coef, accumulate, ws)
     if (nv <= 1) SYMKL_LAUNCH(1);
     else if (nv <= 2) SYMKL_LAUNCH(2);
     else if (nv <= 4) SYMKL_LAUNCH(4);
@@ -505,10 +509,10 @@ int symkl(const void* x, const void* y, float* loss, const float* gout, void* dx
 }  // namespace
 
 #define LOSS_API(SUF, T)                                                                                                   \
-    extern "C" int xggm_dsm_loss_fwd_##SUF(const void* s, const float* g, float* loss, int64_t n, float coef,             \
+    extern "C" int xggm_dsm_loss_fwd_##SUF(const void* s, const float* g, float* loss, int64_t n, float coef, float* ws,  \
                                            hipStream_t st) {                                                              \
-        XGGM_REQUIRE(s && g && loss && n > 0, "xggm_dsm_loss_fwd: bad arguments");                                         \
-        hipLaunchKernelGGL((dsm_fwd_kernel<T>), dim3(grid1d(n)), dim3(NT), 0, st, (const T*)s, g, loss, n, coef);         \
+        XGGM_REQUIRE(s && g && loss && ws && n > 0, "xggm_dsm_loss_fwd: bad arguments");                                   \
+        hipLaunchKernelGGL((dsm_fwd_kernel<T>), dim3(grid1d(n)), dim3(NT), 0, st, (const T*)s, g, loss, n, coef, ws);     \
         return xggm_check_launch("xggm_dsm_loss_fwd");                                                                    \
     }                                                                                                                      \
     extern "C" int xggm_dsm_loss_bwd_##SUF(const void* s, const float* g, const float* gout, void* ds, int64_t n,         \
@@ -518,8 +522,8 @@ int symkl(const void* x, const void* y, float* loss, const float* gout, void* dx
         return xggm_check_launch("xggm_dsm_loss_bwd");                                                                    \
     }                                                                                                                      \
     extern "C" int xggm_symkl_##SUF(const void* x, const void* y, float* loss, const float* gout, void* dx, void* dy,     \
-                                    int rows, int W, float coef, int accumulate, hipStream_t st) {                        \
-        return symkl<T>(x, y, loss, gout, dx, dy, rows, W, coef, accumulate, st);                                         \
+                                    int rows, int W, float coef, int accumulate, float* ws, hipStream_t st) {             \
+        return symkl<T>(x, y, loss, gout, dx, dy, rows, W, coef, accumulate, ws, st);                                     \
     }                                                                                                                      \
     extern "C" int xggm_bce_bwd_##SUF(const float* l, const float* t, const float* gout, void* dl, int64_t n, float coef, \
                                       hipStream_t st) {                                                                   \
@@ -531,9 +535,9 @@ int symkl(const void* x, const void* y, float* loss, const float* gout, void* dx
 LOSS_API(f32, float)
 LOSS_API(bf16, bf16)
 
-extern "C" int xggm_bce_fwd(const float* l, const float* t, float* loss, int64_t n, float coef, hipStream_t st) {
-    XGGM_REQUIRE(l && t && loss && n > 0, "xggm_bce_fwd: bad arguments");
-    hipLaunchKernelGGL(bce_fwd_kernel, dim3(grid1d(n)), dim3(NT), 0, st, l, t, loss, n, coef);
+extern "C" int xggm_bce_fwd(const float* l, const float* t, float* loss, int64_t n, float coef, float* ws, hipStream_t st) {
+    XGGM_REQUIRE(l && t && loss && ws && n > 0, "xggm_bce_fwd: bad arguments");
+    hipLaunchKernelGGL(bce_fwd_kernel, dim3(grid1d(n)), dim3(NT), 0, st, l, t, loss, n, coef, ws);
     return xggm_check_launch("xggm_bce_fwd");
 }
 

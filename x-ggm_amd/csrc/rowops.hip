@@ -625,22 +625,120 @@ __global__ __launch_bounds__(NT) void embed_fwd_kernel(const int64_t* __restrict
     }
 }
 
-// scatter-add of dz rows into the three fp32 embedding gradients; row 0 of every table is
-// nn.Embedding's padding_idx and never receives gradient (modeling.py:284-290).
-template <typename T>
+// The gradients of the three embedding tables: table row k receives the sum of the dz rows that looked it up; row 0 of
+// every table is nn.Embedding's padding_idx and never receives gradient (modeling.py:284-290).
+// No scatter, no atomics -- an OWNER gathers: one wave per candidate (word: every row of the batch; type: every row,
+// when there are segment ids; position: every position).  The wave of row r owns table row ids[r] iff no earlier row
+// looked up the same id; it then lists the rows r' >= r with that id (ballot + prefix count into LDS), adds their dz
+// rows IN ROW ORDER, eight loads in flight at a time, and adds the sum to the table gradient (one owner per address:
+// a plain read-modify-write).  The sum's order is fixed by the data, not by the scheduling: same inputs, same bits.
+// ([CLS] / [SEP] occur once per sample: 32 serial atomics per address before, four rounds of eight loads now.)
+constexpr int ES_CAP = 512;  // list entries per wave; longer lists are summed in several rounds
+template <typename T, int NV>
 __global__ __launch_bounds__(NT) void embed_scatter_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ seg,
                                                            const T* __restrict__ dz, float* dword, float* dpos, float* dtype,
                                                            int M, int Tlen, int H) {
+    __shared__ int list[WPB][ES_CAP];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    for (int row = blockIdx.x * WPB + wid; row < M; row += gridDim.x * WPB) {
-        const int64_t wi = ids[row], pi = row % Tlen, ti = seg ? seg[row] : 0;
-        for (int c = lane; c < H; c += 64) {
-            const float g = to_f32(dz[(int64_t)row * H + c]);
-            if (wi != 0) atomicAdd(dword + wi * H + c, g);
-            if (pi != 0) atomicAdd(dpos + pi * H + c, g);
-            if (ti != 0) atomicAdd(dtype + ti * H + c, g);
-        }
+    const int task = blockIdx.x * WPB + wid;  // wave-uniform
+    const int n_word = M, n_type = seg ? M : 0;
+    if (task >= n_word + n_type + Tlen) return;
+    int cc[NV];
+    bool ok[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int c = (v * 64 + lane) * 4;
+        ok[v] = c < H;
+        cc[v] = ok[v] ? c : H - 4;
     }
+    float acc[NV][4];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[v][i] = 0.f;
+    int* mine = list[wid];
+    // the list is written and read by the lanes of ONE wave: order its LDS traffic, no workgroup barrier (waves of a
+    // workgroup return at different points)
+    auto wsync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    // add the dz rows mine[0 .. cnt) in list order, eight rows' loads issued before the first add
+    auto add_listed = [&](int cnt) {
+        for (int i0 = 0; i0 < cnt; i0 += 8) {
+            typename Raw4<T>::type raw[8][NV];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int row = mine[min(i0 + u, cnt - 1)];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) raw[u][v] = load_raw4<T>(dz + (int64_t)row * H + cc[v]);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + u < cnt) {
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        float t4[4];
+                        cvt4(raw[u][v], t4);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[v][i] += t4[i];
+                    }
+                }
+        }
+    };
+    float* target = nullptr;
+    if (task < n_word + n_type) {
+        const bool is_word = task < n_word;
+        const int r = is_word ? task : task - n_word;
+        const int64_t* key = is_word ? ids : seg;
+        const int64_t k = key[r];
+        if (k == 0) return;  // padding_idx
+        // owner = first row with this key
+        bool seen = false;
+        for (int q0 = 0; q0 < r && !seen; q0 += 64) {
+            const int q = q0 + lane;
+            seen = __ballot(q < r && key[q] == k) != 0ull;
+        }
+        if (seen) return;
+        int cnt = 0;
+        for (int q0 = r & ~63; q0 < M; q0 += 64) {
+            const int q = q0 + lane;
+            const bool hit = q >= r && q < M && key[q] == k;
+            const unsigned long long m = __ballot(hit);
+            if (hit) mine[cnt + __popcll(m & ((1ull << lane) - 1ull))] = q;
+            cnt += __popcll(m);
+            if (cnt > ES_CAP - 64) {  // wave-uniform
+                wsync();
+                add_listed(cnt);
+                wsync();
+                cnt = 0;
+            }
+        }
+        wsync();
+        add_listed(cnt);
+        target = (is_word ? dword : dtype) + k * H;
+    } else {
+        const int t = task - n_word - n_type;
+        if (t == 0) return;  // padding_idx of the position table
+        const int B = M / Tlen;
+        for (int b0 = 0; b0 < B; b0 += ES_CAP) {
+            const int n = min(ES_CAP, B - b0);
+            for (int i = lane; i < n; i += 64) mine[i] = (b0 + i) * Tlen + t;
+            wsync();
+            add_listed(n);
+            wsync();
+        }
+        target = dpos + (int64_t)t * H;
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+        if (ok[v]) {
+            float o[4];
+            load4(target + cc[v], o);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] += acc[v][i];
+            store4(target + cc[v], o);
+        }
 }
 
 // ------------------------------------------------------------------------------- visual embedding
@@ -1004,8 +1102,10 @@ int embed_bwd(const int64_t* ids, const int64_t* seg, const void* dy, const void
     if (int e = ln_bwd<T>(dy, z, stats, gamma, dz_ws, nullptr, dgamma, dbeta, nullptr, M, H, 0.f, p, rng, 0, sid, 1.0f, 0,
                           nullptr, ws, ws_bytes, st))
         return e;
-    hipLaunchKernelGGL((embed_scatter_kernel<T>), dim3(rows_grid(M, 1024)), dim3(NT), 0, st, ids, seg, (const T*)dz_ws,
-                       dword, dpos, dtype, M, Tlen, H);
+    XGGM_REQUIRE(Tlen > 0 && M % Tlen == 0, "xggm_embed_bwd: M=%d is not a multiple of T=%d", M, Tlen);
+    const int tasks = M + (seg ? M : 0) + Tlen;  // one wave per candidate owner, see embed_scatter_kernel
+    DISPATCH_NV(H, hipLaunchKernelGGL((embed_scatter_kernel<T, NV>), dim3(ceil_div(tasks, WPB)), dim3(NT), 0, st, ids, seg,
+                                       (const T*)dz_ws, dword, dpos, dtype, M, Tlen, H));
     return xggm_check_launch("xggm_embed_bwd(scatter)");
 }
 

@@ -31,6 +31,7 @@ class Runtime:
     def __init__(self, arena, seed=9595):
         self.arena = arena
         self.rng = ops.make_rng(seed, arena.device)
+        ops.sum_ws(arena.device)  # the ordered-sum workspace must exist before a graph capture can need it
         self.training = True
         self.p_hidden = 0.1   # config.hidden_dropout_prob (src/lxrt/modeling.py:196)
         self.p_attn = 0.1     # config.attention_probs_dropout_prob
@@ -100,7 +101,7 @@ class Runtime:
             # cross-attention module is applied twice per layer) waits for the next launch
             seen, now, later = set(), [], []
             for j in jobs:
-                key = tuple(t.data_ptr() for t in j[3] if t is not None)
+                key = tuple(t.data_ptr() for t in j[4] if t is not None)
                 if seen.isdisjoint(key):
                     seen.update(key)
                     now.append(j)
@@ -326,7 +327,7 @@ def g_attn_bwd(rt, saved, dy, defer_wgrad=False, link=None):
         gb = a.atomic_target([bq, bk, bv])  # q/k/v bias gradients come out of the attention backward
         yield ops.AttnBwdReq(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], mask, d_c, dqkv[:, :H], dqkv[:, H:2 * H],
                              dqkv[:, 2 * H:], B, heads, Sq, Sk, p_att, rt.rng, att._sid + salt, gb[:H], gb[H:2 * H],
-                             gb[2 * H:])
+                             gb[2 * H:], defer=rt.defer_list())
         pdx, dxq = ops.p_dgrad(dqkv, a.fused([wq, wk, wv]), residual=d_res)
         dxkv = None
         if defer_wgrad:
@@ -339,7 +340,7 @@ def g_attn_bwd(rt, saved, dy, defer_wgrad=False, link=None):
         dkv = torch.empty_like(kv)
         gbq, gbkv = a.atomic_target(bq), a.atomic_target([bk, bv])
         yield ops.AttnBwdReq(qkv, kv[:, :H], kv[:, H:], mask, d_c, dq, dkv[:, :H], dkv[:, H:], B, heads, Sq, Sk, p_att,
-                             rt.rng, att._sid + salt, gbq, gbkv[:H], gbkv[H:])
+                             rt.rng, att._sid + salt, gbq, gbkv[:H], gbkv[H:], defer=rt.defer_list())
         if defer_wgrad and link is not None and "dxq" in link:
             # second direction: its gradient w.r.t. its query input is the other direction's key/value input
             # and vice versa -- accumulate there, one round after the first direction wrote them
@@ -415,7 +416,8 @@ def g_ffn_bwd(rt, saved, dy):
     yield lb
     d_h, d_res = lb.d_in, lb.d_res
     # d_u = (d_h W_2) * gelu'(u); its column sums (= grad of b_1) are taken in the same epilogue
-    pd, d_u = ops.p_dgrad(d_h, a.w(outm.dense.weight), gelu_aux=u, colsum=a.atomic_target(inter.dense.bias))
+    pd, d_u = ops.p_dgrad(d_h, a.w(outm.dense.weight), gelu_aux=u, colsum=a.atomic_target(inter.dense.bias),
+                          defer=rt.defer_list())
     yield [_p_wgrad(rt, d_h, act, outm.dense.weight), pd]
     pdx, dx = ops.p_dgrad(d_u, a.w(inter.dense.weight), residual=d_res)
     yield [_p_wgrad(rt, d_u, x, inter.dense.weight), pdx]

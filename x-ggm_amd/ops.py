@@ -41,6 +41,9 @@ def _c(t, dt=None, name="tensor"):
 def gemm_raw(dt, A, B, C, M, N, K, a_rs, a_ks, b_ns, b_ks, ldc, batch=1, a_bs=0, b_bs=0, c_bs=0,
              bias=None, residual=None, preact=None, aux=None, act=ACT_NONE, c_f32=False,
              accumulate=False, alpha=1.0, colsum=None):
+    """``colsum``: fp32 [batch * ceil(M/32), N] partial rows (see xggm.h), overwritten"""
+    if colsum is not None:
+        assert colsum.dtype == F32 and colsum.numel() >= batch * colsum_rows(M) * N
     call("xggm_gemm_" + sfx(dt), ptr(A), ptr(B), ptr(C), M, N, K, a_rs, a_ks, b_ns, b_ks, ldc, batch,
          a_bs, b_bs, c_bs, ptr(bias), ptr(residual), ptr(preact), ptr(aux), ptr(colsum), act, int(c_f32),
          int(accumulate), float(alpha), stream())
@@ -250,10 +253,13 @@ def gemm_group8(problems):
         call("xggm_gemm_grouped_fp8e4m3", _ct.cast(arr, _ct.c_void_p), len(chunk), stream())
 
 
-def p_dgrad(dy, w, residual=None, gelu_aux=None, colsum=None, into=None):
+def p_dgrad(dy, w, residual=None, gelu_aux=None, colsum=None, into=None, defer=None):
     """problem for dx = dy @ w (+ residual) (* gelu'(aux)); ``colsum`` (fp32 [K]) += column sums of dx
-    (the bias gradient of the Linear that produced the activation); ``into``: an existing gradient of the
-    same input, the result is ADDED to it (second consumer of one tensor); returns (problem, dx)."""
+    (the bias gradient of the Linear that produced the activation) -- the epilogue leaves one partial row per 32
+    output rows, a reduce job adds them to ``colsum`` in a fixed order: appended to ``defer`` (the backward pass's
+    list, see functional.Runtime.defer_list) or, without one, run by ``gemm_group`` right behind the launch;
+    ``into``: an existing gradient of the same input, the result is ADDED to it (second consumer of one tensor);
+    returns (problem, dx)."""
     M, N, a_rs = _rows(_chk(dy))
     K = w.shape[1]
     assert w.shape[0] == N and w.dtype == dy.dtype and w.is_contiguous()
@@ -262,11 +268,22 @@ def p_dgrad(dy, w, residual=None, gelu_aux=None, colsum=None, into=None):
         assert gelu_aux is None and colsum is None
         return _problem(dy, w, into, M, K, N, a_rs, 1, 1, K, K, residual=residual, accumulate=True), into
     dx = torch.empty((M, K), device=dy.device, dtype=dy.dtype)
+    part = job = None
     if colsum is not None:
         _c(colsum, F32, "colsum")
         assert colsum.numel() == K
-    return _problem(dy, w, dx, M, K, N, a_rs, 1, 1, K, K, residual=residual, aux=gelu_aux,
-                    act=ACT_GELU_GRAD if gelu_aux is not None else ACT_NONE, colsum=colsum), dx
+        if K % 4:
+            raise RuntimeError("p_dgrad: column sums need a width that is a multiple of 4 (got %d)" % K)
+        part = torch.empty((colsum_rows(M), K), device=dy.device, dtype=F32)
+        job = (part, colsum_rows(M), 1, K, (colsum,))
+    p = _problem(dy, w, dx, M, K, N, a_rs, 1, 1, K, K, residual=residual, aux=gelu_aux,
+                 act=ACT_GELU_GRAD if gelu_aux is not None else ACT_NONE, colsum=part)
+    if job is not None:
+        if defer is not None:
+            defer.append(job)
+        else:
+            p.post = job
+    return p, dx
 
 
 def p_wgrad(dy, x, gw, accumulate, sqsum=None):
@@ -291,6 +308,7 @@ def gemm_group(dt, problems):
         chunk = problems[i:i + 4]
         arr = (GemmProblem * len(chunk))(*chunk)
         call("xggm_gemm_grouped_" + sfx(dt), _ct.cast(arr, _ct.c_void_p), len(chunk), stream())
+        reduce_batch([p.post for p in chunk if getattr(p, "post", None) is not None])  # column sums nobody deferred
 
 
 def colsum(x, out):
@@ -333,6 +351,19 @@ def attn_fwd(q, k, v, mask, B, heads, Sq, Sk, p, rng, sid):
     return out
 
 
+def _bias_partials(B, H, dev, dbq, dbk, dbv):
+    """workspace [B][3][H] the attention backward leaves the per-sample column sums of dq / dk / dv in, and the reduce
+    job that adds them into the q / k / v bias gradients (fixed order: no atomics)"""
+    if dbq is None and dbk is None:
+        return None, None
+    for t in (dbq, dbk, dbv):
+        if t is not None:
+            _c(t, F32, "bias gradient")
+            assert t.numel() == H
+    ws = torch.empty((B, 3, H), device=dev, dtype=F32)
+    return ws, (ws, B, 3, H, (dbq, dbk, dbv))
+
+
 def attn_bwd(q, k, v, mask, d_out, dq, dk, dv, B, heads, Sq, Sk, p, rng, sid, dbq=None, dbk=None, dbv=None):
     """dbq/dbk/dbv: fp32 [heads*64] accumulators of the query/key/value bias gradients"""
     d = 64
@@ -342,9 +373,15 @@ def attn_bwd(q, k, v, mask, d_out, dq, dk, dv, B, heads, Sq, Sk, p, rng, sid, db
     for t, S in ((dq, Sq), (dk, Sk), (dv, Sk)):
         if t.dim() != 2 or t.shape[0] != B * S or t.shape[1] != H or t.stride(1) != 1 or t.dtype != q.dtype:
             raise RuntimeError("attn_bwd: bad gradient buffer %s" % (tuple(t.shape),))
+    ws, job = _bias_partials(B, H, q.device, dbq, dbk, dbv)
     call("xggm_attn_bwd_" + sfx(q.dtype), ptr(q), ptr(k), ptr(v), ptr(mask), ptr(d_out), ptr(dq), ptr(dk),
          ptr(dv), B, heads, Sq, Sk, d, q.stride(0), k.stride(0), v.stride(0), H, dq.stride(0),
-         dk.stride(0), dv.stride(0), 0.125, float(p), ptr(rng), sid, ptr(dbq), ptr(dbk), ptr(dbv), stream())
+         dk.stride(0), dv.stride(0), 0.125, float(p), ptr(rng), sid,
+         ptr(ws[0, 0]) if (ws is not None and dbq is not None) else None,
+         ptr(ws[0, 1]) if (ws is not None and dbk is not None) else None,
+         ptr(ws[0, 2]) if (ws is not None and dbv is not None) else None, 3 * H, stream())
+    if job is not None:
+        reduce_batch([job])
 
 
 class AttnProblem(_ct.Structure):
@@ -355,7 +392,7 @@ class AttnProblem(_ct.Structure):
                 ("scale", _ct.c_float), ("p", _ct.c_float), ("sid", _ct.c_uint32),
                 ("d_out", _ct.c_void_p), ("dq", _ct.c_void_p), ("dk", _ct.c_void_p), ("dv", _ct.c_void_p),
                 ("dq_rs", _ct.c_int64), ("dk_rs", _ct.c_int64), ("dv_rs", _ct.c_int64),
-                ("dbq", _ct.c_void_p), ("dbk", _ct.c_void_p), ("dbv", _ct.c_void_p),
+                ("dbq", _ct.c_void_p), ("dbk", _ct.c_void_p), ("dbv", _ct.c_void_p), ("db_bs", _ct.c_int64),
                 ("out8", _ct.c_void_p), ("qscale", _ct.c_void_p), ("amax", _ct.c_void_p), ("amax_slots", _ct.c_int)]
 
 
@@ -391,7 +428,11 @@ class AttnFwdReq:
 class AttnBwdReq:
     """attention core backward; gradients are written into the caller's dq/dk/dv views."""
 
-    def __init__(self, q, k, v, mask, d_out, dq, dk, dv, B, heads, Sq, Sk, p, rng, sid, dbq=None, dbk=None, dbv=None):
+    def __init__(self, q, k, v, mask, d_out, dq, dk, dv, B, heads, Sq, Sk, p, rng, sid, dbq=None, dbk=None, dbv=None,
+                 defer=None):
+        """``dbq / dbk / dbv``: the fp32 [heads*64] gradients of the query / key / value biases (+=); the kernel leaves
+        per-sample partial rows and a reduce job adds them: appended to ``defer`` (the running backward's list) or kept in
+        ``self.post`` for ``launch_row_requests`` to run right behind the launch"""
         d = 64
         H = heads * d
         _c(d_out)
@@ -401,10 +442,20 @@ class AttnBwdReq:
                 raise RuntimeError("attn_bwd: bad gradient buffer %s" % (tuple(t.shape),))
         self.key = ("attn_bwd", q.dtype)
         self.rng = rng
-        self.keep = (q, k, v, mask, d_out, dq, dk, dv, dbq, dbk, dbv)
+        ws, job = _bias_partials(B, H, q.device, dbq, dbk, dbv)
+        self.post = None
+        if job is not None:
+            if defer is not None:
+                defer.append(job)
+            else:
+                self.post = job
+        self.keep = (q, k, v, mask, d_out, dq, dk, dv, dbq, dbk, dbv, ws)
         self.prob = AttnProblem(ptr(q), ptr(k), ptr(v), ptr(mask), None, B, heads, Sq, Sk, q.stride(0), k.stride(0),
                                 v.stride(0), H, 0.125, float(p), sid, ptr(d_out), ptr(dq), ptr(dk), ptr(dv), dq.stride(0),
-                                dk.stride(0), dv.stride(0), ptr(dbq), ptr(dbk), ptr(dbv))
+                                dk.stride(0), dv.stride(0),
+                                ptr(ws[0, 0]) if (ws is not None and dbq is not None) else None,
+                                ptr(ws[0, 1]) if (ws is not None and dbk is not None) else None,
+                                ptr(ws[0, 2]) if (ws is not None and dbv is not None) else None, 3 * H)
 
 
 ROW_REQUESTS = ()  # filled below: the request classes ``functional.drive`` recognises
@@ -512,7 +563,7 @@ class LnBwdReq:
         ws, nb = _ws(_lib.lib.xggm_ln_bwd_workspace_bytes(M, H), dy.device)
         now = (dgamma, dbeta, dbias)
         if defer is not None and any(t is not None for t in now):
-            defer.append((ws, nb // (12 * H), H, now))
+            defer.append((ws, nb // (12 * H), 3, H, now))
             now = (None, None, None)
         self.keep = (dy, z, stats, gamma, ws)
         self.prob = LnBwdProblem(ptr(dy), ptr(z), ptr(stats), ptr(gamma), ptr(self.d_in), ptr(self.d_res), ptr(now[0]),
@@ -529,6 +580,7 @@ def launch_row_requests(reqs):
             arr = (AttnProblem * len(rs))(*[r.prob for r in rs])
             call("xggm_%s_grouped_%s" % (key[0], sfx(key[1])), _ct.cast(arr, _ct.c_void_p), len(rs), 64, ptr(rs[0].rng),
                  stream())
+            reduce_batch([r.post for r in rs if getattr(r, "post", None) is not None])
         elif key[0] == "ln_fwd":
             _, dt, H, eps, p = key
             arr = (LnFwdProblem * len(rs))(*[r.prob for r in rs])
@@ -551,13 +603,24 @@ class ReduceJob(_ct.Structure):
 
 
 def reduce_batch(jobs):
-    """second stage of deferred LN backwards: ``jobs`` = [(ws, nblk, H, (dgamma, dbeta, dbias))]."""
+    """second stage of the two-stage parameter-gradient sums: ``jobs`` = [(ws, nblk, K, H, targets)] with ``ws`` fp32
+    [nblk][K][H] partial rows and ``targets`` a tuple of K fp32 [H] gradient vectors (None = not wanted):
+    targets[k] += sum_b ws[b][k][:], blocks added in index order.  The producers: LayerNorm backwards (K = 3: dgamma,
+    dbeta, dbias), GEMM epilogue column sums (K = 1: a bias gradient), attention backwards (K = 3: q / k / v bias)."""
+    if not jobs:
+        return
     arr = (ReduceJob * len(jobs))()
-    for a, (ws, nblk, H, tg) in zip(arr, jobs):
-        a.ws, a.nblk, a.K, a.H = ptr(ws), nblk, 3, H
+    for a, (ws, nblk, K, H, tg) in zip(arr, jobs):
+        assert 1 <= K <= 3 and len(tg) == K and ws.dtype == F32 and ws.numel() >= nblk * K * H
+        a.ws, a.nblk, a.K, a.H = ptr(ws), nblk, K, H
         for k in range(3):
-            a.target[k] = ptr(tg[k])
+            a.target[k] = ptr(tg[k]) if k < K else None
     call("xggm_partial_reduce_batch", _ct.cast(arr, _ct.c_void_p), len(jobs), stream())
+
+
+def colsum_rows(M):
+    """partial rows the GEMM epilogue writes per column-sum request: one per block of 32 output rows (xggm.h)"""
+    return (M + 31) // 32
 
 
 def ln_bwd(dy, z, stats, gamma, dgamma, dbeta, dbias, want_din=True, want_dres=False, d_res=None,
@@ -583,7 +646,7 @@ def ln_bwd(dy, z, stats, gamma, dgamma, dbeta, dbias, want_din=True, want_dres=F
     ws, nb = _ws(_lib.lib.xggm_ln_bwd_workspace_bytes(M, H), dy.device)
     now = (dgamma, dbeta, dbias)
     if defer is not None and any(t is not None for t in now):
-        defer.append((ws, nb // (12 * H), H, now))
+        defer.append((ws, nb // (12 * H), 3, H, now))
         now = (None, None, None)
     call("xggm_ln_bwd_" + sfx(dy.dtype), ptr(dy), ptr(z), ptr(stats), ptr(gamma), ptr(d_in), ptr(d_res),
          ptr(now[0]), ptr(now[1]), ptr(now[2]), M, H, float(p_pre), float(p_post), ptr(rng), sid_pre, sid_post,
@@ -671,7 +734,7 @@ def agg_dot(Mx, x, dh, out):
     B, N, H = x.shape
     _c(Mx, F32), _c(x), _c(dh, x.dtype), _c(out, F32)
     assert tuple(Mx.shape) == (B, N, N) and dh.shape == x.shape
-    call("xggm_agg_dot_" + sfx(x.dtype), ptr(Mx), ptr(x), ptr(dh), ptr(out), B, N, H, stream())
+    call("xggm_agg_dot_" + sfx(x.dtype), ptr(Mx), ptr(x), ptr(dh), ptr(out), B, N, H, ptr(sum_ws(x.device)), stream())
 
 
 def adj_regen_fwd(S):
@@ -777,11 +840,30 @@ def _scalar(out, device):
     return out.view(()) if out is not None else zeros_f32(1, device).view(())
 
 
+SUM_WS_FLOATS = 4104  # XGGM_SUM_WS_FLOATS (include/xggm.h)
+_SUM_WS = {}
+
+
+def sum_ws(device):
+    """workspace of the grid-wide sums without atomics (losses, GIN's eps gradient): per-workgroup partials + an
+    arrival counter every kernel leaves at zero, so ONE zeroed buffer per device serves every launch -- the package
+    launches all its kernels on one stream, and launches of one stream run in order.  Created on first use;
+    ``functional.Runtime`` touches it at construction so that it exists before any graph capture."""
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    ws = _SUM_WS.get(device)
+    if ws is None:
+        ws = _SUM_WS[device] = torch.zeros(SUM_WS_FLOATS, device=device, dtype=F32)
+    return ws
+
+
 def dsm_fwd(s, g, coef, out=None):
     _c(s), _c(g, F32, "grad_log_noise")
     assert s.shape == g.shape
     loss = _scalar(out, s.device)
-    call("xggm_dsm_loss_fwd_" + sfx(s.dtype), ptr(s), ptr(g), ptr(loss), s.numel(), float(coef), stream())
+    call("xggm_dsm_loss_fwd_" + sfx(s.dtype), ptr(s), ptr(g), ptr(loss), s.numel(), float(coef), ptr(sum_ws(s.device)),
+         stream())
     return loss
 
 
@@ -797,7 +879,7 @@ def symkl_fwd(x, y, coef, out=None):
     W = x.shape[-1]
     loss = _scalar(out, x.device)
     call("xggm_symkl_" + sfx(x.dtype), ptr(x), ptr(y), ptr(loss), None, None, None, x.numel() // W, W,
-         float(coef), 0, stream())
+         float(coef), 0, ptr(sum_ws(x.device)), stream())
     return loss
 
 
@@ -806,7 +888,7 @@ def symkl_bwd(x, y, gout, coef, need_x, need_y):
     dx = torch.empty_like(x) if need_x else None
     dy = torch.empty_like(y) if need_y else None
     call("xggm_symkl_" + sfx(x.dtype), ptr(x), ptr(y), None, ptr(gout), ptr(dx), ptr(dy), x.numel() // W, W,
-         float(coef), 0, stream())
+         float(coef), 0, None, stream())
     return dx, dy
 
 
@@ -814,7 +896,7 @@ def bce_fwd(logit, target, coef, out=None):
     _c(logit, F32, "logit"), _c(target, F32, "target")
     assert logit.shape == target.shape
     loss = _scalar(out, logit.device)
-    call("xggm_bce_fwd", ptr(logit), ptr(target), ptr(loss), logit.numel(), float(coef), stream())
+    call("xggm_bce_fwd", ptr(logit), ptr(target), ptr(loss), logit.numel(), float(coef), ptr(sum_ws(logit.device)), stream())
     return loss
 
 

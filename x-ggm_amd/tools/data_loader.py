@@ -14,8 +14,10 @@ while the consumer trains on batch k.  Iterating yields the reference's tuple
 ``(ques_id, feats, boxes, sent, target, adj)`` -- with ``device`` set the tensors are device tensors whose copies
 the current stream has been made to wait for (the trainer's own ``.cuda()`` calls become no-ops), and ``sent`` is
 the ``(input_ids, input_mask, segment_ids)`` triple the encoder accepts in place of strings when a batcher was
-given.  A slot of the ring is rewritten only after the consumer has asked for the next batch AND the work it
-queued on the buffers has passed an event -- however far the host runs ahead.
+given.  A slot of the ring is rewritten only after the consumer has asked for the next batch AND, on the device side,
+the work it queued on the slot's device buffer has passed an event (the next copy into it waits for that event on the
+copy stream), AND, on the host side, the slot's previous host-to-device copy has actually RUN (the producer blocks on
+that copy's event before it writes the pinned buffer again) -- however far the host runs ahead of the GPU.
 """
 import queue
 import threading
@@ -69,6 +71,7 @@ class DataLoaderX:
             self.host.append(hv)
             self.dev.append(dv)
         self.copy_stream = torch.cuda.Stream(device=self.device)
+        self._copied = [None] * depth  # per slot: event of the last H2D copy out of its pinned buffer (all iterators)
 
     def __len__(self):
         n = len(self.ds)
@@ -99,6 +102,7 @@ class _Iter:
         for f in self.free:
             f.set()
         self.released = [None] * L.depth                         # CUDA event: consumer's work on the slot is queued
+        self.copied = getattr(L, "_copied", [None] * L.depth)    # CUDA event: the slot's last host-to-device copy
         self.stop = False
         self.err = None
         self.held = None
@@ -117,6 +121,12 @@ class _Iter:
                     return
                 self.free[slot].clear()
                 host = L.host[slot]
+                if self.copied[slot] is not None:
+                    # The previous copy OUT of this pinned buffer may still be queued: it waits on the copy stream for
+                    # the consumer's event, and with graph replays and no host synchronisation the host runs many
+                    # batches ahead of the GPU.  Writing the buffer now would hand the GPU a batch mixed from two
+                    # sample sets.  Block THIS (producer) thread until that copy has run.
+                    self.copied[slot].synchronize()
                 ids, sents, B = L.ds.collate(items, host)
                 sent = sents
                 ev = None
@@ -132,6 +142,7 @@ class _Iter:
                         L.dev_flat[slot].copy_(L.host_flat[slot], non_blocking=True)  # the whole batch: one copy
                         ev = torch.cuda.Event()
                         ev.record(L.copy_stream)
+                    self.copied[slot] = ev
                     out = {k: v[:B] for k, v in dev.items() if k != "ids"}
                 else:
                     out = {k: v[:B] for k, v in host.items()}
