@@ -71,6 +71,9 @@ class DataLoaderX:
             self.host.append(hv)
             self.dev.append(dv)
         self.copy_stream = torch.cuda.Stream(device=self.device)
+        # the device buffers were zero-filled on the CURRENT stream just now: the first copies into them must not
+        # overtake that fill (seen: a busy compute stream ran the fill after the first two batches had landed)
+        self.copy_stream.wait_stream(torch.cuda.current_stream(self.device))
         self._copied = [None] * depth  # per slot: event of the last H2D copy out of its pinned buffer (all iterators)
 
     def __len__(self):
