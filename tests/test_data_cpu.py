@@ -19,9 +19,9 @@ def _records():
     return meta, raw
 
 
-def _write_shard(path, meta, raw, with_adj=True, string_ids=False):
+def _write_shard(path, meta, raw, with_adj=True, string_ids=False, feat_dtype="bf16"):
     from xggm_amd.tools.shards import ShardWriter
-    w = ShardWriter(path, n_objects=36, feat_dim=64)
+    w = ShardWriter(path, n_objects=36, feat_dim=64, feat_dtype=feat_dtype)
     for inf in meta["info"]:
         i = inf["img_id"]
         w.add("img%d" % i if string_ids else i, raw["feats_%d" % i], np.asarray(meta["raw_boxes"][str(i)], dtype=np.float32),
@@ -108,6 +108,33 @@ def test_shard_round_trip_and_dataset_items_equal_the_reference(tmp_path, string
     out = str(tmp_path / "res.json")
     ev.dump_result({1: "a"}, out)
     assert json.load(open(out)) == [{"question_id": 1, "answer": "a"}]
+
+
+def test_float32_shard_hands_out_the_reference_items_exactly(tmp_path):
+    """a bf16 shard rounds the features, so an fp32 parity run would not see the reference's inputs.  A shard
+    written with feat_dtype="float32" returns the reference's ``__getitem__`` features bit for bit, and gathers them
+    into a bf16 batch buffer as their bf16 rounding (what the bf16 shard stores)."""
+    from xggm_amd.tools.shards import ShardReader
+    from xggm_amd.vqa.vqacpv2_data import VQADataset, VQATorchDataset
+    g = load_golden("dataset")
+    meta, raw = _records()
+    rd = ShardReader(_write_shard(str(tmp_path / "train_obj36.xgs"), meta, raw, feat_dtype="float32"))
+    assert rd.feat_dtype == "float32"
+    a2l = {a: i for i, a in enumerate(meta["label2ans"])}
+    ts = VQATorchDataset(VQADataset("train", data=meta["vqa"], ans2label=a2l, label2ans=meta["label2ans"]), shard=rd)
+    for k in range(len(ts)):
+        qid, feats, boxes, sent, target, adj = ts[k]
+        assert feats.dtype == np.float32 and np.array_equal(feats, g["vqa_feats"][k])  # exact, not rounded
+        assert np.array_equal(boxes, g["vqa_boxes"][k]) and np.array_equal(adj, g["vqa_adj"][k])
+    out = ts.alloc(4, False)
+    ids, sents, B = ts.collate([0, 2, 1], out)
+    assert B == 3 and ids == [meta["vqa"][i]["question_id"] for i in (0, 2, 1)]
+    for b, k in enumerate((0, 2, 1)):
+        assert np.array_equal(out["feats"][b].float().numpy(), _bf16(g["vqa_feats"][k]))
+        assert np.array_equal(out["boxes"][b].numpy(), g["vqa_boxes"][k])
+    with pytest.raises(ValueError, match="feat_dtype"):
+        from xggm_amd.tools.shards import ShardWriter
+        ShardWriter(str(tmp_path / "x.xgs"), feat_dtype="float16")
 
 
 def test_shard_writer_rejects_bad_records(tmp_path):

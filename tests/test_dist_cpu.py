@@ -205,18 +205,27 @@ def _sharded_worker(rank, world, port, q):
         for run in z.runs:
             o0, o1 = z.own(run)
             a.shadow[o0:o1] = 50.0 + rank
+        ok &= z.stale is False
         z.gather()
+        ok &= z.stale is True  # an update has run: the other ranks' slices of the fp32 state are out of date here
         for run in z.runs:
             c = (run[1] - run[0]) // world
             for r in range(world):
                 ok &= bool((a.shadow[run[0] + r * c:run[0] + (r + 1) * c] == 50.0 + r).all())
         ok &= bool((a.shadow[1024:1280] == rank + 1).all())  # nothing outside the runs is touched
-        z.gather_state()
+        # what a checkpoint / shadow refresh does first (ParamArena.gather_sharded_state): gather iff stale
+        from xggm_amd.arena import ParamArena
+        a.zero1 = z
+        ParamArena.gather_sharded_state(a)
+        ok &= z.stale is False
         for run in z.runs:
             c = (run[1] - run[0]) // world
             for r in range(world):
                 sl = slice(run[0] + r * c, run[0] + (r + 1) * c)
                 ok &= bool((a.params[sl] == r + 1).all()) and bool((a.m[sl] == 10.0 * (r + 1)).all()) and bool((a.v[sl] == 100.0 * (r + 1)).all())
+        a.params[:] = -1.0
+        ParamArena.gather_sharded_state(a)  # nothing updated since: no second gather
+        ok &= bool((a.params == -1.0).all())
         z.reset()
         ok &= z.runs == []
         # the plain in-place exchange (no sharding) on the same arena
@@ -304,6 +313,45 @@ def _sparse_table_worker(rank, world, port, q):
             both = [torch.empty_like(got) for _ in range(world)]
             dist.all_gather(both, got)
             ok &= bool(torch.equal(both[0][t0:t0 + V * H], both[1][t0:t0 + V * H]))
+
+            def next_pass(ids_now):
+                """a new backward: the table gradient holds only this pass's rows; returns the dense reference table"""
+                if cls is ShardedUpdate:
+                    gs.reset()
+                a.grads[t0:t0 + V * H] = 0
+                for i in ids_now.reshape(-1).tolist():
+                    tab[i] += torch.randn(H, generator=gen)
+                d = a.grads[t0:t0 + V * H].to(torch.bfloat16)
+                dist.all_reduce(d, op=dist.ReduceOp.SUM)
+                return d.view(V, H).float()
+
+            # second pass, OTHER tokens: the wire's table is written only through the row path (cast_vectors skips it),
+            # so the rows of the first pass must have been put back to zero
+            ids2 = torch.tensor([[1, 7, 30, 0]]) if rank == 0 else torch.tensor([[31, 1, 0, 0]])
+            ids = ids2
+            d2 = next_pass(ids2)
+            gs.sync([(0, a.groups["g0"].end)])
+            gt = a.wire[t0:t0 + V * H].view(V, H).float()
+            now = {0, 1, 7, 30, 31}
+            ok &= bool(((gt - d2).abs() <= 1e-2 * d2.abs() + 1e-6).all())
+            ok &= float(gt[[r for r in range(V) if r not in now]].abs().max()) == 0.0 and float(gt[[1, 7, 30, 31]].abs().min(1)[0].min()) >= 0.0
+            ok &= float(gt[[3, 11, 39, 5, 20, 2]].abs().max()) == 0.0  # touched in the first pass only
+            # third pass: the table was looked up twice since zero_grad (gradient accumulation): the last ids do not
+            # cover every touched row -> the whole table goes the dense way
+            a.emb_uses = 2
+            ids = torch.tensor([[9, 0, 0, 0]])
+            d3 = next_pass(torch.tensor([[9, 17, 25, 0]]) if rank == 0 else torch.tensor([[18, 9, 0, 0]]))
+            gs.sync([(0, a.groups["g0"].end)])
+            gt = a.wire[t0:t0 + V * H].view(V, H).float()
+            ok &= bool(((gt - d3).abs() <= 1e-2 * d3.abs() + 1e-6).all()) and float(gt[[17, 25, 18]].abs().max()) > 0.0
+            # fourth pass, sparse again: what the dense pass left in the table is cleared first
+            a.emb_uses = 1
+            ids = torch.tensor([[4, 0, 0, 0]]) if rank == 0 else torch.tensor([[6, 4, 0, 0]])
+            d4 = next_pass(ids)
+            gs.sync([(0, a.groups["g0"].end)])
+            gt = a.wire[t0:t0 + V * H].view(V, H).float()
+            ok &= bool(((gt - d4).abs() <= 1e-2 * d4.abs() + 1e-6).all())
+            ok &= float(gt[[r for r in range(V) if r not in (0, 4, 6)]].abs().max()) == 0.0
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

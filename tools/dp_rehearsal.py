@@ -39,9 +39,14 @@ def run(overlap, rank, use_graph=True, iters=("rel", "node", "rel"), layers=(2, 
     arena = m.arena()
     if want == "shadow":  # what the GEMMs read: must be identical on every rank after the all-gather
         return arena.shadow.float().clone()
+    # what a checkpoint writes: under the sharded update state_dict() first gathers the fp32 masters of the other ranks'
+    # slices (runtime._gather_before_state_dict -> ParamArena.gather_sharded_state; a collective, both ranks are here)
     if zero1:
-        arena.zero1.gather_state()  # the fp32 masters of the other ranks' slices (as before a checkpoint)
-    return torch.cat([p.detach().float().flatten() for p in m.parameters()])
+        assert arena.zero1.stale
+    sd = m.state_dict()
+    if zero1:
+        assert not arena.zero1.stale
+    return torch.cat([sd[n].detach().float().flatten() for n, _ in m.named_parameters()])
 
 
 def report(v, rank, tag):

@@ -146,6 +146,7 @@ class ParamArena:
         self.lr_host = [None] * len(order)
         self.group_index = {g: i for i, g in enumerate(order)}
         self.pending_clip = None  # max_norm registered by clip_grad_norm_, consumed by BertAdam.step
+        self.emb_uses = 0
         self.zero1 = None         # dist.ShardedUpdate when the update is sharded over data-parallel ranks
         self.touched = set()
         self.vec_zeroed = False
@@ -190,8 +191,21 @@ class ParamArena:
         """False when someone re-allocated the parameters (e.g. model.cuda() afterwards)."""
         return all(self.named[n].data_ptr() == self._ptrs[n] for n in self._probe)
 
+    def gather_sharded_state(self):
+        """ZeRO-1 (dist.ShardedUpdate): after a sharded update every rank holds fresh fp32 masters and moments only for
+        the slices it owns.  Anything that READS the masters as a whole -- a checkpoint, a shadow refresh -- first
+        brings the other ranks' slices over.  Collective when it has something to do (every rank must get here); a
+        no-op without the sharded update or when nothing has been updated since the last gather."""
+        z = self.zero1
+        if z is not None and z.stale:
+            z.gather_state()
+
     def sync_shadow(self):
-        """refresh the bf16 shadow weights from the fp32 masters (after init / load_state_dict)."""
+        """refresh the bf16 shadow weights from the fp32 masters (after init / load_state_dict).  Under the sharded
+        update the masters are made whole first (after a load_state_dict that every rank ran, the owners' slices hold
+        the loaded values, so the gather hands out exactly those; tensors the load did not cover get their owners'
+        fresh values instead of this rank's stale ones)."""
+        self.gather_sharded_state()  # never build the shadow of all weights from stale slices
         if self.shadow is not None:
             ops.cast_bf16(self.params, self.shadow)
         if self.fp8 is not None:
@@ -248,6 +262,7 @@ class ParamArena:
         """called by zero_grad(): every ``.grad`` is None again, so the atomically accumulated
         ranges can be cleared with one fill per group at the next backward."""
         self.vec_zeroed = False
+        self.emb_uses = 0  # look-ups of the word table since zero_grad() (dist.GradSync: the sparse exchange needs exactly one)
         self.pending_clip = None
         self.sq_covered.clear()
         self.sq_clean = False

@@ -123,7 +123,9 @@ __global__ __launch_bounds__(NT) void partial_reduce_kernel(const float* __restr
 }
 
 // the same reduction for a batch of workspaces (deferred second stage of many LN backwards)
-constexpr int MAX_JOBS = 40;
+// 72 jobs: 3.7 KB of kernel arguments (the limit is 4 KB).  A backward pass of the full model leaves ~90 jobs (one per
+// LayerNorm, per attention block, per FFN bias): two launches
+constexpr int MAX_JOBS = 72;
 struct BatchJobs {
     xggm_reduce_job j[MAX_JOBS];
     int start[MAX_JOBS + 1];  // first workgroup of each job

@@ -67,9 +67,15 @@ class GradSync:
                     out.append((a, b))
         return out
 
-    def cast_vectors(self, ranges):
+    def cast_vectors(self, ranges, skip_table=False):
+        """fp32 vector gradients -> the bf16 wire.  ``skip_table``: leave the word-embedding table out (94 MB read and
+        47 MB written per pass for the ~640 rows that matter): its rows go on the wire through ``_finish_table``."""
         a = self.arena
-        for s, e in self.vec_parts(ranges):
+        parts = self.vec_parts(ranges)
+        if skip_table:
+            o, e_t = self.table[0], self.table[0] + self.table[1] * self.table[2]
+            parts = [q for s, e in parts for q in ((s, min(e, o)), (max(s, e_t), e)) if q[1] > q[0]]
+        for s, e in parts:
             if a.wire.is_cuda:
                 from . import ops
                 ops.cast_bf16(a.grads[s:e], a.wire[s:e])
@@ -91,6 +97,11 @@ class GradSync:
         t = getattr(self, "table", None)
         if t is None or self.arena is None or self.world == 1 and not self.force:
             return ranges, False
+        if getattr(self.arena, "emb_uses", 1) != 1:
+            # the table was looked up more than once since zero_grad() (gradient accumulation, a second forward): the ids
+            # of the LAST forward do not cover every touched row -- dense exchange of the whole table
+            self._table_dirty = True
+            return ranges, False
         o, e = t[0], t[0] + t[1] * t[2]
         out, hit = [], False
         for s, f in ranges:
@@ -98,6 +109,7 @@ class GradSync:
                 out.append((s, f))
                 continue
             if s > o or f < e:
+                self._table_dirty = True
                 return ranges, False  # only part of the table in these ranges: no special path
             hit = True
             if s < o:
@@ -105,6 +117,17 @@ class GradSync:
             if f > e:
                 out.append((e, f))
         return out, hit
+
+    def _table_path(self, ranges):
+        """``_without_table`` + the bookkeeping of the wire's table: after a pass that went the dense way (the whole
+        table was cast onto the wire) the next sparse pass clears the table once, because its row-wise zeroing only
+        knows the rows of the previous SPARSE pass"""
+        dense, sparse = self._without_table(ranges)
+        if sparse and getattr(self, "_table_dirty", False):
+            o, V, H, _ = self.table
+            self.arena.wire[o:o + V * H].zero_()
+            self._table_dirty, self._prev_ids = False, None
+        return dense, sparse
 
     def _begin_table(self):
         o, V, H, ids_of = self.table
@@ -130,11 +153,21 @@ class GradSync:
         work.wait()
         o, V, H, _ = self.table
         w = self.arena.wire[o:o + V * H].view(V, H)
+        # the wire's table is written ONLY here (cast_vectors skips it): the rows the previous pass touched go back to
+        # zero first, then this pass's summed rows land; every other row has been zero since the arena was built
+        prev = getattr(self, "_prev_ids", None)
         if w.is_cuda:
             from . import ops
+            if prev is not None:
+                if getattr(self, "_zero_rows", None) is None or self._zero_rows.shape[0] < prev.numel():
+                    self._zero_rows = torch.zeros((prev.numel(), H), device=w.device, dtype=w.dtype)
+                ops.scatter_rows(self._zero_rows[:prev.numel()], prev, w)
             ops.scatter_rows(rows, ids_all, w)
         else:
+            if prev is not None:
+                w[prev] = 0
             w[ids_all] = rows
+        self._prev_ids = ids_all
 
     @staticmethod
     def merged(ranges):
@@ -151,9 +184,9 @@ class GradSync:
     def _begin_inplace(self, ranges):
         # SUM, not AVG: the norm pass and the update take the average (``arena.grad_scale`` = 1 / world) on the way
         # in.  Same bytes on the links and no pre-multiply kernel (on a one-rank group RCCL then launches nothing).
-        self.cast_vectors(ranges)  # (the table included: its untouched rows are zeros on every rank)
+        dense, sparse = self._table_path(ranges)
+        self.cast_vectors(ranges, skip_table=sparse)
         w = self.arena.wire
-        dense, sparse = self._without_table(ranges)
         tab = self._begin_table() if sparse else None
         rs = self.merged(dense)
         works = [dist.all_reduce(w[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for s, e in rs]
@@ -290,6 +323,8 @@ class ShardedUpdate(GradSync):
             raise RuntimeError("sharded update: world size %d must divide 256" % self.world)
         self.runs = []  # matrix runs (start, end) exchanged in this pass, in exchange order
         self.all_runs = set()  # every run any pass has exchanged (gather_state)
+        self.stale = False  # a sharded update has run since the last gather_state: the other ranks' slices of the
+        # fp32 masters / moments on THIS rank are out of date (only the bf16 shadow is gathered after an update)
 
     def reset(self):
         self.runs = []
@@ -315,11 +350,11 @@ class ShardedUpdate(GradSync):
         return a + self.rank * c, a + (self.rank + 1) * c
 
     def _begin_inplace(self, ranges):
-        self.cast_vectors(ranges)
+        dense, sparse = self._table_path(ranges)
+        self.cast_vectors(ranges, skip_table=sparse)
         w = self.arena.wire
         nccl = self.backend == "nccl"
         op = dist.ReduceOp.SUM  # the average is taken by the norm pass and the update (arena.grad_scale)
-        dense, sparse = self._without_table(ranges)
         tab = self._begin_table() if sparse else None
         mats, vecs = self.split(dense)
         works = []
@@ -360,6 +395,7 @@ class ShardedUpdate(GradSync):
 
     def gather(self):
         """all-gather the bf16 shadow weights of this pass's matrix runs from their owners"""
+        self.stale = True
         if self.world == 1 and not self.force:
             return
         sh = self.arena.shadow
@@ -379,7 +415,11 @@ class ShardedUpdate(GradSync):
     @torch.no_grad()
     def gather_state(self):
         """fp32 masters and BertAdam moments of EVERY matrix range from their owners (before state_dict / a
-        checkpoint), run by run as the passes exchanged them"""
+        checkpoint), run by run as the passes exchanged them.  A COLLECTIVE: every rank of the group calls it (through
+        ``ParamArena.gather_sharded_state``: model.state_dict(), BertAdam.state_dict(), save_training_state, VQA.save
+        and sync_shadow all do, so under the sharded update those are collective calls too -- as a sharded framework's
+        state_dict is)."""
+        self.stale = False
         if self.world == 1:
             return
         for run in sorted(self.all_runs):

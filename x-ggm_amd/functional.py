@@ -148,6 +148,7 @@ class EmbedFn(Function):
         ctx.rt, ctx.mod, ctx.p = rt, mod, rt.p(rt.p_hidden)
         ctx.saved = (ids, seg, z, stats)
         rt.emb_ids = ids  # the rows of the word table this pass touches (data parallel: dist.GradSync.set_sparse_table)
+        a.emb_uses = getattr(a, "emb_uses", 0) + 1  # ... valid only if this is the ONE look-up since zero_grad()
         return out
 
     @staticmethod

@@ -162,6 +162,7 @@ class BertAdam(Optimizer):
             if getattr(self, "_pending_state", None) is not None:
                 sd['state'] = self._pending_state
             return sd
+        arena.gather_sharded_state()  # ZeRO-1: the moments of the other ranks' slices (collective, see dist.ShardedUpdate)
         steps = arena.steps.tolist()
         state, idx = {}, 0
         for pg in self.param_groups:

@@ -25,6 +25,16 @@ def _mark_shadow_dirty(module, incompatible_keys):
         object.__setattr__(root, "_xg_shadow_dirty", True)
 
 
+def _gather_before_state_dict(module, prefix, keep_vars):
+    """state_dict pre-hook (any sub-module): under the sharded update (ZeRO-1) the fp32 masters of the other ranks'
+    slices are stale on this rank -- gather them first (a collective: call state_dict() on every rank)."""
+    ref = getattr(module, "_xg_root", None)
+    root = ref() if ref is not None else None
+    rt = getattr(root, "_xg_rt", None) if root is not None else None
+    if rt is not None:
+        rt.arena.gather_sharded_state()
+
+
 def bind_root(root, compute_dtype=None):
     """(re)bind all sub-modules of ``root``; the outermost model calls this last, so nested
     roots (an encoder inside a VQAModel) end up pointing at the outermost one."""
@@ -34,6 +44,7 @@ def bind_root(root, compute_dtype=None):
         object.__setattr__(m, "_sid", 16 * (i + 1))
         if not getattr(m, "_xg_hooked", False):
             m.register_load_state_dict_post_hook(_mark_shadow_dirty)
+            m.register_state_dict_pre_hook(_gather_before_state_dict)
             object.__setattr__(m, "_xg_hooked", True)
     if compute_dtype is not None:
         object.__setattr__(root, "compute_dtype", compute_dtype)

@@ -8,6 +8,9 @@ same information the way the GPU consumes it:
 
     <name>.xgs      4096-byte header (magic, JSON) followed by 4096-byte-aligned arrays
         feats   [n, N, F]  bf16   region features, already in the storage type of the encoder's first GEMM
+                                  (``ShardWriter(feat_dtype="float32")`` keeps the reference's exact fp32 values instead,
+                                  for parity runs in fp32 execution: twice the bytes, rounded to bf16 only when a batch
+                                  is gathered into a bf16 buffer)
         boxes   [n, N, 4]  f32    ALREADY normalised to 0..1 by (img_w, img_h), range-checked once at write time
                                   (vqacpv2_data.py:113-117)
         adj     [n, N, N]  f32    attribute-class cosine adjacency (absent for splits that have none)
@@ -47,8 +50,10 @@ class ShardWriter:
     """collects per-image records and writes one shard.  ``add`` takes what the reference's h5 group and info
     json hold for an image; ``adj`` may be None for every record (splits without adjacency)."""
 
-    def __init__(self, path, n_objects=36, feat_dim=2048):
-        self.path, self.N, self.F = path, n_objects, feat_dim
+    def __init__(self, path, n_objects=36, feat_dim=2048, feat_dtype="bf16"):
+        if feat_dtype not in ("bf16", "float32"):
+            raise ValueError("feat_dtype: 'bf16' or 'float32', got %r" % (feat_dtype,))
+        self.path, self.N, self.F, self.fdt = path, n_objects, feat_dim, feat_dtype
         self.ids, self.feats, self.boxes, self.adj = [], [], [], []
 
     def add(self, img_id, feats, boxes, img_w, img_h, adj=None):
@@ -61,7 +66,7 @@ class ShardWriter:
         if self.ids and (adj is None) != (not self.adj):
             raise ValueError("either every record of a shard has an adjacency or none has")
         nb = normalize_boxes(boxes, img_w, img_h)  # may raise: nothing of a bad record is kept
-        fb = _bf16_bits(feats)
+        fb = _bf16_bits(feats) if self.fdt == "bf16" else feats.copy()
         self.ids.append(img_id)
         self.feats.append(fb)
         self.boxes.append(nb)
@@ -82,7 +87,8 @@ class ShardWriter:
             arrays.append(("img_id", np.asarray(self.ids, dtype=np.int64)))
         off, table = HEADER, {}
         for name, a in arrays:
-            table[name] = {"offset": off, "shape": list(a.shape), "dtype": "bf16" if name == "feats" else str(a.dtype)}
+            table[name] = {"offset": off, "shape": list(a.shape),
+                           "dtype": "bf16" if (name == "feats" and self.fdt == "bf16") else str(a.dtype)}
             off = (off + a.nbytes + ALIGN - 1) // ALIGN * ALIGN
         head = {"n": n, "n_objects": self.N, "feat_dim": self.F, "arrays": table,
                 "ids": None if numeric else [str(i) for i in self.ids]}
@@ -129,7 +135,9 @@ class ShardReader:
         def mm(name, dtype):
             return np.memmap(path, mode="r", dtype=dtype, offset=t[name]["offset"], shape=tuple(t[name]["shape"]))
 
-        self.feats_bits = mm("feats", np.uint16)       # bf16 bit patterns
+        self.feat_dtype = t["feats"]["dtype"]
+        self.feats_bits = mm("feats", np.uint16) if self.feat_dtype == "bf16" else None  # bf16 bit patterns
+        self.feats_f = mm("feats", np.float32) if self.feat_dtype != "bf16" else None     # or the exact fp32 values
         self.boxes = mm("boxes", np.float32)
         self.adj = mm("adj", np.float32) if "adj" in t else None
         if ids is None:
@@ -141,7 +149,10 @@ class ShardReader:
         return self.n
 
     def feats_f32(self, row):
-        """features of one image as fp32 (exactly the bf16 values): what ``Dataset.__getitem__`` hands out"""
+        """features of one image as fp32 (exactly the stored values: bf16-rounded, or the reference's own fp32 ones in
+        a float32 shard): what ``Dataset.__getitem__`` hands out"""
+        if self.feats_f is not None:
+            return np.array(self.feats_f[row])
         return (self.feats_bits[row].astype(np.uint32) << 16).view(np.float32)
 
     def gather(self, rows, out):
@@ -149,6 +160,17 @@ class ShardReader:
         out['adj'] f32 (when the shard has one).  Sequential row runs are one slice copy each."""
         rows = np.asarray(rows, dtype=np.int64)
         B = len(rows)
+        if self.feats_f is not None:  # float32 shard (parity runs): exact rows into an fp32 buffer, rounded into a bf16 one
+            fo = out["feats"][:B]
+            for b, r in enumerate(rows):
+                if fo.dtype == torch.float32:
+                    fo[b].numpy()[:] = self.feats_f[r]
+                else:
+                    fo[b].view(torch.int16).numpy().view(np.uint16)[:] = _bf16_bits(np.array(self.feats_f[r]))
+                out["boxes"][b].numpy()[:] = self.boxes[r]
+                if self.adj is not None and "adj" in out:
+                    out["adj"][b].numpy()[:] = self.adj[r]
+            return B
         fb = out["feats"][:B].view(torch.int16).numpy().view(np.uint16)
         if B and np.all(np.diff(rows) == 1):
             s = slice(int(rows[0]), int(rows[0]) + B)

@@ -285,8 +285,14 @@ def save_training_state(path, model, optim, **extra):
     out: BertAdam moments and step counters (reference state layout), the dropout / noise Philox state, the host
     branch-choice generator, and whatever the caller adds (epoch, iteration, best score)."""
     rt = runtime_of(model)
-    torch.save({"model": model.state_dict(), "optimizer": optim.state_dict(), "rng": rt.rng.cpu(),
-                "python_random": random.getstate(), "extra": extra}, path)
+    # under the sharded update (ZeRO-1) this is a collective: every rank calls it (they all hold the gathered state
+    # afterwards; let one of them pass a real ``path`` and the others ``None`` to write a single file)
+    rt.arena.gather_sharded_state()
+    ck = {"model": model.state_dict(), "optimizer": optim.state_dict(), "rng": rt.rng.cpu(),
+          "python_random": random.getstate(), "extra": extra}
+    if path is not None:
+        torch.save(ck, path)
+    return ck
 
 
 def load_training_state(path, model, optim):

@@ -54,7 +54,10 @@ class VQADataset:
 
 class VQATorchDataset(Dataset):
     """ref :55-127.  ``shard``: path of ``<split>_obj36.xgs`` (features, normalised boxes, adjacency) or an open
-    ``ShardReader``.  Only data whose image is in the shard are kept (:82-85)."""
+    ``ShardReader``.  Only data whose image is in the shard are kept (:82-85).
+    One difference from the reference's items: the shard stores the features as bf16 (half the bytes per sample; the
+    benchmark dtype), so ``__getitem__`` returns the bf16-ROUNDED values as fp32 -- a parity run in fp32 execution
+    that wants the reference's exact fp32 inputs writes its shard with ``ShardWriter(..., feat_dtype="float32")``."""
 
     def __init__(self, dataset, shard=None, imgfeat_root=MSCOCO_IMGFEAT_ROOT, tiny=False, fast=False):
         super().__init__()
@@ -64,10 +67,10 @@ class VQATorchDataset(Dataset):
         self.shard = shard if isinstance(shard, ShardReader) else ShardReader(shard)
         key = dataset.img_key
         self.data = [d for d in dataset.data if d[key] in self.shard.row_of]
+        # as the reference: only ``tiny`` truncates (src/vqa/vqacpv2_data.py:84-85); ``fast`` sets a top-k there that is
+        # never applied (:62-63), so it is accepted and changes nothing here either
         if tiny:
             self.data = self.data[:TINY_IMG_NUM]
-        elif fast:
-            self.data = self.data[:FAST_IMG_NUM]
         self.rows = np.asarray([self.shard.row_of[d[key]] for d in self.data], dtype=np.int64)
         print("Use %d data in torch dataset" % (len(self.data)))
 
