@@ -24,6 +24,9 @@ Extra objects on the line:
                      sample of the same workload (N = 1 only)
   value_with_loader  the same steps with the loader boundary inside the timed region: a fresh host batch every
                      step (tokenised strings + pinned feature buffers), H2D on a copy stream, double-buffered
+  value_ref_batch    the same iteration at the batch size the reference's own scripts train with (92 for VQA-CP v2,
+                     script/vqacpv2.sh:10,23; 96 for GQA-OOD, script/gqa_ood.sh:10,24) -- never `value`, whose
+                     configuration (32 samples per GPU) is BASELINE.json's
 """
 import argparse
 import json
@@ -58,6 +61,7 @@ def parse(argv=None):
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-timing", action="store_true")
     p.add_argument("--no-loader", action="store_true", help="skip the loader-inclusive leg")
+    p.add_argument("--no-ref-batch", action="store_true", help="skip the leg at the reference's own training batch size")
     p.add_argument("--wire", default="bf16", choices=["bf16", "f32"], help="gradient all-reduce dtype")
     p.add_argument("--zero1", type=int, default=None, help="1: shard the update over the ranks (reduce-scatter -> "
                    "BertAdam on the shard -> all-gather of the weights); default: off (see DESIGN.md section 6)")
@@ -134,7 +138,7 @@ def build(args, device):
     batch = {k: torch.from_numpy(v).to(device) for k, v in b.items() if k != "randn_adj"}
     if dt == torch.bfloat16:
         batch["feats"] = batch["feats"].to(torch.bfloat16)  # as the shard format stores them (tools/shards.py)
-    n_iters = args.steps + args.warmup + 64
+    n_iters = 2 * args.steps + args.warmup + 128  # the timed steps, the loader leg and the diagnostic legs behind them
     lr = 5e-6 if args.order == "gqa" else 1e-6  # script/gqa_ood.sh:27, script/vqacpv2.sh:26; t_total = 2 * iterations
     optim = make_optimizer(model, lr, 2 * n_iters)
     return model, optim, batch
@@ -622,6 +626,35 @@ def main():
                                "hand-over to the captured graphs' input buffers" % args.batch}
         log("with loader: %.3f ms/step" % with_loader["ms_per_step"])
 
+    # the reference's own training batch size (script/vqacpv2.sh:10,23: 92; script/gqa_ood.sh:10,24: 96): row counts
+    # that are no multiple of any GEMM tile (1840 / 3312 and 1920 / 3456 rows).  A second captured trainer on the same
+    # model and optimiser; an extra key, never `value`.
+    ref_batch = None
+    if world == 1 and not force_dp and not args.no_ref_batch:
+        from xggm_amd import synth
+        Bref = 96 if args.order == "gqa" else 92
+        nb = synth.vqa_batch(Bref, A=args.answers, seed=2000)
+        bref = {k: torch.from_numpy(v).to(device) for k, v in nb.items() if k != "randn_adj"}
+        if args.dtype != "f32":
+            bref["feats"] = bref["feats"].to(torch.bfloat16)
+        tr_ref = CapturedTrainer(model, optim, bref, sigma=1.0, order=args.order, use_graph=not args.no_graph, warmup_iters=1)
+        n_ref = max(5, min(args.steps, 10))
+        for _ in range(2):
+            tr_ref.iteration(branch())
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(n_ref):
+            tr_ref.iteration(branch())
+        barrier()
+        dtr = time.perf_counter() - t1
+        ref_batch = {"batch": Bref, "value": round(Bref * n_ref / dtr, 2), "unit": "samples/s",
+                     "ms_per_step": round(1000.0 * dtr / n_ref, 3), "steps": n_ref,
+                     "what": "the same iteration at the reference's training batch size (%s)"
+                             % ("script/gqa_ood.sh:10,24" if args.order == "gqa" else "script/vqacpv2.sh:10,23")}
+        log("reference batch %d: %.3f ms/step, %.1f samples/s" % (Bref, ref_batch["ms_per_step"], ref_batch["value"]))
+        del tr_ref, bref
+        torch.cuda.empty_cache()
+
     # per-branch step time (diagnostic; not part of the timed region)
     per_branch = {}
     for br in ("rel", "node"):
@@ -673,6 +706,7 @@ def main():
                        "world_size": world, "backend": backend, "zero1": zero1,
                        "hip_graph": not args.no_graph, "grad_wire": args.wire if (world > 1 or force_dp) else None},
             "ms_per_step_by_branch": per_branch, "ms_per_pass": per_pass, "value_with_loader": with_loader,
+            "value_ref_batch": ref_batch,
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
