@@ -325,13 +325,18 @@ typedef struct xggm_reduce_job {
 } xggm_reduce_job;
 int xggm_partial_reduce_batch(const xggm_reduce_job* jobs, int n, xggm_stream_t stream);
 /* BertEmbeddings: src/lxrt/modeling.py:298-313.  ids/seg: int64 [M] (M = B*Tlen), tables T.
- * backward scatter-adds into the fp32 table gradients; row 0 (padding_idx) gets none. */
+ * forward: out8 (or NULL; bf16 storage only) = e4m3 copy of `out` scaled by *qscale, *amax raised to max |out|
+ * (amax_slots as in xggm_gemm_problem): the operand of the first fp8 product, written by its producer.
+ * backward: the table gradients are GATHERED by an owner per table row (the first batch row that looked it up adds
+ * the dz rows of every look-up in row order): no atomics, a fixed summation order; row 0 (padding_idx) gets none. */
 int xggm_embed_fwd_f32(const int64_t* ids, const int64_t* seg, const void* word, const void* pos, const void* type,
                        const float* gamma, const float* beta, void* out, void* z_out, float* stats, int M, int Tlen, int H,
-                       float eps, float p, const uint64_t* rng, uint32_t sid, xggm_stream_t stream);
+                       float eps, float p, const uint64_t* rng, uint32_t sid, void* out8, const float* qscale, float* amax,
+                       int amax_slots, xggm_stream_t stream);
 int xggm_embed_fwd_bf16(const int64_t* ids, const int64_t* seg, const void* word, const void* pos, const void* type,
                         const float* gamma, const float* beta, void* out, void* z_out, float* stats, int M, int Tlen, int H,
-                        float eps, float p, const uint64_t* rng, uint32_t sid, xggm_stream_t stream);
+                        float eps, float p, const uint64_t* rng, uint32_t sid, void* out8, const float* qscale, float* amax,
+                        int amax_slots, xggm_stream_t stream);
 int xggm_embed_bwd_f32(const int64_t* ids, const int64_t* seg, const void* dy, const void* z, const float* stats,
                        const float* gamma, void* dz_ws, float* dword, float* dpos, float* dtype, float* dgamma,
                        float* dbeta, int M, int Tlen, int H, float p, const uint64_t* rng, uint32_t sid, float* ws,
@@ -345,11 +350,11 @@ int xggm_embed_bwd_bf16(const int64_t* ids, const int64_t* seg, const void* dy, 
 int xggm_visn_embed_fwd_f32(const void* u, const float* bf, const void* boxes, const float* Wb, const float* bb,
                             const float* g1, const float* b1, const float* g2, const float* b2, void* out, void* z1,
                             void* z2, float* stats, int M, int H, float eps, float p, const uint64_t* rng, uint32_t sid,
-                            xggm_stream_t stream);
+                            void* out8, const float* qscale, float* amax, int amax_slots, xggm_stream_t stream);
 int xggm_visn_embed_fwd_bf16(const void* u, const float* bf, const void* boxes, const float* Wb, const float* bb,
                              const float* g1, const float* b1, const float* g2, const float* b2, void* out, void* z1,
                              void* z2, float* stats, int M, int H, float eps, float p, const uint64_t* rng, uint32_t sid,
-                             xggm_stream_t stream);
+                             void* out8, const float* qscale, float* amax, int amax_slots, xggm_stream_t stream);
 int xggm_visn_embed_bwd_f32(const void* dy, const void* z1, const void* z2, const float* stats, const void* boxes,
                             const float* g1, const float* g2, void* du, float* dbf, float* dg1, float* db1, float* dWb,
                             float* dbb, float* dg2, float* db2, int M, int H, float p, const uint64_t* rng, uint32_t sid,

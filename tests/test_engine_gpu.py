@@ -171,6 +171,7 @@ def test_two_data_parallel_ranks_on_one_gpu_stay_identical():
     assert r.stdout.count("bf16 weights identical on both ranks: True") == 3
     assert "sharded == replicated update bit for bit (clip not binding), 3 iterations: True" in r.stdout
     assert "sharded vs replicated update, one pass with the clip binding" in r.stdout
+    assert "fp8 forward: sharded == replicated update bit for bit (clip not binding), 3 iterations: True" in r.stdout
 
 
 def test_bench_on_a_one_rank_rccl_group():
@@ -240,6 +241,14 @@ def test_bench_gqa_order_line():
     assert line["n_gpus"] == 1 and line["config"]["order"] == "gqa" and "A=1842" in line["config"]["workload"]
     assert "GGM pass first" in line["config"]["workload"] and line["value"] > 0
     assert line["roofline"]["frac"] > 0 and line["value_with_loader"]["value"] > 0
+
+
+def test_bench_fp8_line():
+    """BASELINE configs[4] per GPU: e4m3 operands in the forward QKV / attention-output / FFN products, bf16 GNN and
+    backward (src/lxrt/modeling.py:345-347, 428-431, 441-445 are the products that change type)"""
+    line = _run_bench(["--dtype", "fp8", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-loader", "--no-ref-batch"])
+    assert line["dtype"] == "fp8" and line["n_gpus"] == 1 and line["value"] > 0 and "fp8" in line["config"]["workload"]
+    assert "xggm_gemm_grouped_fp8e4m3" in line["kernels"] or any("fp8" in k for k in line["kernels"]), line["kernels"]
 
 
 def test_bench_c4_stress_line():

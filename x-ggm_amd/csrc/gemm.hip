@@ -114,7 +114,7 @@ int g_single_grouped = 1;      // single problems with whole k-tiles also take t
                                // (same-box A/B 11.33 / 11.05 / 11.06 vs 11.01 / 11.00 / 11.03); xggm_gemm_set_tile(variant | 0x8000) turns it off
 int g_no_8w = 0;               // test hook: xggm_gemm_set_tile(variant | 0x4000): no 8-wave 128 x 128 tile
 int g_glds = 1;                // test hook: xggm_gemm_set_tile(variant | 0x400) keeps k-major pairs on the register-staged k-loop
-int g_group_tile = 0;          // test hook: 0 heuristic, 1: 64x64, 2: 128x64, 3: 128x128
+int g_group_tile = 0;          // test hook: 0 heuristic, 1: 64x64, 2: 128x64, 3: 128x128, 4: 128x128 on 8 waves, 5: 128x256 / 6: 256x128 on 8 waves
 
 // stage a [64 rows][BK] operand tile into LDS (k contiguous).  elem(r,k) = base[r*rs + k*ks]
 template <typename T>
@@ -665,8 +665,10 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, const float4_
 // instructions per 16 x 16 block, for what the step launches most -- and the staged, feature-complete walk for the rest:
 //   kind 0: C = alpha * acc + bias, bf16 or fp32 (weight gradients: non-temporal, optional norm slots)
 //   kind 1: pre = bf16(alpha * acc + bias), C = gelu(pre), optional e4m3 copy          (the FFN's first product)
-__device__ __forceinline__ int epilogue_kind(const GemmArgs& g, int bz) {
+template <int BM, int BN, int W> __device__ __forceinline__ int epilogue_kind(const GemmArgs& g, int bz) {
     const int64_t coff = (int64_t)bz * g.c_bs;
+    // the register epilogue adds a wave's squares into ONE norm slot: its tile must lie inside one 64 x 64 block
+    if (g.sqsum && !(BM / (W / 2) <= 64 && BN / 2 <= 64)) return 2;
     auto al = [](const void* q, uintptr_t a) { return reinterpret_cast<uintptr_t>(q) % a == 0; };
     if (g.N % 4 || g.ldc % 4 || coff % 4 || g.colsum || g.residual || g.accumulate || !al(g.C, g.c_f32 ? 16 : 8) ||
         (int64_t)g.M * g.ldc >= (1ll << 31) || (g.sqsum && !g.c_f32))
@@ -746,7 +748,6 @@ __device__ __forceinline__ void epilogue_direct(const GemmArgs& g, const float4_
     if (KIND == 0 && g.sqsum) {
         // norm slots (see epilogue_staged): a wave's tile lies inside ONE 64 x 64 block of the output; the waves of
         // a block are added in a fixed order
-        static_assert(BM / (W / 2) <= 64 && BN / 2 <= 64, "a wave's tile inside one 64 x 64 block");
         constexpr int RS = BM >= 64 ? BM / 64 : 1, CS = BN >= 64 ? BN / 64 : 1;
         const float ws = wave_sum(sq);
         if (lane == 0) stage[wid] = ws;
@@ -758,6 +759,7 @@ __device__ __forceinline__ void epilogue_direct(const GemmArgs& g, const float4_
                 float t = 0.f;
 #pragma unroll
                 for (int w = 0; w < W; ++w) {
+                    // (epilogue_kind sends tiles whose waves straddle 64 x 64 blocks to the staged walk)
                     const int wr = (w >> 1) * (BM / (W / 2)) / 64, wc = (w & 1) * (BN / 2) / 64;
                     if (wr == r && wc == c) t += stage[w];
                 }
@@ -1064,7 +1066,7 @@ __device__ __forceinline__ void gemm_finish(const GemmArgs& g, int tile_m, int t
         if (keep == 123.456f) reinterpret_cast<float*>(g.C)[threadIdx.x] = keep;
         return;
     }
-    const int kind = epilogue_kind(g, bz);
+    const int kind = epilogue_kind<BM, BN, W>(g, bz);
     if (kind == 0) epilogue_direct<BM, BN, TM, TN, W, 0>(g, acc, m0, n0, bz, reinterpret_cast<float*>(fsm), wm, wn);
     else if (kind == 1) epilogue_direct<BM, BN, TM, TN, W, 1>(g, acc, m0, n0, bz, reinterpret_cast<float*>(fsm), wm, wn);
     else epilogue_staged<BM, BN, TM, TN, W>(g, acc, m0, n0, bz, reinterpret_cast<float*>(fsm), wm, wn);
@@ -1273,7 +1275,8 @@ template <int BM, int BN, int W = 4> int launch_grouped_tile(GroupArgs& ga, hipS
 // The grouped launch with e4m3 operands (forward products of both modality streams of one layer): every problem
 // is k-major on both sides, so there is ONE k-loop instantiation; the per-problem dequantisation factor
 // scale_a * scale_b is folded into alpha before the (shared) epilogue.
-template <int BM, int BN> __global__ __launch_bounds__(NT, (min_waves<BM, BN>())) void gemm_grouped_fp8_kernel(GroupArgs ga) {
+template <int BM, int BN, int W = 4>
+__global__ __launch_bounds__(64 * W, (W == 8 ? 2 : min_waves<BM, BN>())) void gemm_grouped_fp8_kernel(GroupArgs ga) {
     extern __shared__ __attribute__((aligned(16))) bf16 fsm[];
     const int b = blockIdx.x;
     int i = 0, t0 = 0, t1 = ga.tile_start[1];
@@ -1293,18 +1296,18 @@ template <int BM, int BN> __global__ __launch_bounds__(NT, (min_waves<BM, BN>())
         tile_n = lt - tile_m * gx;
     }
     constexpr int DK = (BM * BN <= 64 * 64) ? 4 : 2;
-    float4_t acc[BM / 32][BN / 32];
+    float4_t acc[BM / (8 * W)][BN / 32];
     if (glds_ok<true>(g)) {  // K a whole number of 128-element k-tiles: the LDS-DMA k-loop (same bytes per k-tile as bf16)
-        if (ga.stages == 3) gemm_kloop_glds<BM, BN, true, true, true, 4, 3>(g, tile_m, tile_n, bz, fsm, acc);
-        else gemm_kloop_glds<BM, BN, true, true, true, 4, 2>(g, tile_m, tile_n, bz, fsm, acc);
+        if (ga.stages == 3) gemm_kloop_glds<BM, BN, true, true, true, W, 3>(g, tile_m, tile_n, bz, fsm, acc);
+        else gemm_kloop_glds<BM, BN, true, true, true, W, 2>(g, tile_m, tile_n, bz, fsm, acc);
     } else {
-        gemm_kloop<BM, BN, true, true, DK, true>(g, tile_m, tile_n, bz, fsm, acc);
+        gemm_kloop<BM, BN, true, true, DK, true, W>(g, tile_m, tile_n, bz, fsm, acc);
     }
     g.alpha *= (g.scale_a ? *g.scale_a : 1.f) * (g.scale_b ? *g.scale_b : 1.f);
-    gemm_finish<BM, BN>(g, tile_m, tile_n, bz, fsm, acc);
+    gemm_finish<BM, BN, W>(g, tile_m, tile_n, bz, fsm, acc);
 }
 
-template <int BM, int BN> int launch_grouped_fp8_tile(GroupArgs& ga, hipStream_t stream) {
+template <int BM, int BN, int W = 4> int launch_grouped_fp8_tile(GroupArgs& ga, hipStream_t stream) {
     int total = 0;
     for (int i = 0; i < ga.nprob; ++i) {
         ga.tile_start[i] = total;
@@ -1313,7 +1316,7 @@ template <int BM, int BN> int launch_grouped_fp8_tile(GroupArgs& ga, hipStream_t
     ga.tile_start[ga.nprob] = total;
     // k-major images of 128 bytes per row (128 e4m3 values), double buffered; the staged epilogue needs
     // (BM / 2) x (BN + 4) floats of the same memory
-    ga.stages = g_glds_stages ? std::min(g_glds_stages, 3) : (BM * BN == 128 * 128) ? 2 : 3;
+    ga.stages = g_glds_stages ? std::min(g_glds_stages, 3) : (BM * BN == 128 * 128 && W == 4) ? 2 : 3;
     bool glds = true;
     for (int i = 0; i < ga.nprob; ++i) glds = glds && glds_ok<true>(ga.p[i]);
     const size_t lds = std::max((glds ? ga.stages : 2) * sizeof(bf16) * (OpLds<BM, true>::ELEMS + OpLds<BN, true>::ELEMS),
@@ -1322,11 +1325,11 @@ template <int BM, int BN> int launch_grouped_fp8_tile(GroupArgs& ga, hipStream_t
                                         sizeof(float) * (BM / 2) * (BN + 4));
     static bool attr_set = false;
     if (lds_max > 48 * 1024 && !attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_grouped_fp8_kernel<BM, BN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_grouped_fp8_kernel<BM, BN, W>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_grouped_fp8_kernel<BM, BN>), dim3(total), dim3(NT), lds, stream, ga);
+    hipLaunchKernelGGL((gemm_grouped_fp8_kernel<BM, BN, W>), dim3(total), dim3(64 * W), lds, stream, ga);
     return xggm_check_launch("xggm_gemm_grouped_fp8e4m3");
 }
 
@@ -1600,6 +1603,8 @@ template <typename T> int grouped(const xggm_gemm_problem* probs, int n, hipStre
         }
         if (kmaj && t128 > 200 && t128 <= 256 && nkmin >= 12 && !g_no_8w) v = 4;
     }
+    if (v == 5) return launch_grouped_tile<128, 256, 8>(ga, stream);
+    if (v == 6) return launch_grouped_tile<256, 128, 8>(ga, stream);
     if (v == 4) return launch_grouped_tile<128, 128, 8>(ga, stream);
     if (v == 3) return launch_grouped_tile<128, 128>(ga, stream);
     if (v == 2) return launch_grouped_tile<128, 64>(ga, stream);
@@ -1637,7 +1642,16 @@ extern "C" int xggm_gemm_grouped_fp8e4m3(const xggm_gemm_problem* probs, int n, 
     }
     for (int i = 1; i < n; ++i)  // longest k-loops first
         for (int j = i; j > 0 && ga.p[j].K > ga.p[j - 1].K; --j) std::swap(ga.p[j], ga.p[j - 1]);
-    const int v = pick_group_tile(ga, n, 128);
+    int v = pick_group_tile(ga, n, 128);
+    if (g_group_tile == 0) {
+        // 128 x 128 on eight waves where ONE round of such tiles covers the chip (the fused QKV pair: 252 tiles), as
+        // for the bf16 products -- XGGM_FP8_8W=0 turns it off (same-box A/B hook)
+        static const bool use8 = !(getenv("XGGM_FP8_8W") && atoi(getenv("XGGM_FP8_8W")) == 0);
+        int64_t t128 = 0;
+        for (int i = 0; i < n; ++i) t128 += (int64_t)ceil_div(ga.p[i].M, 128) * ceil_div(ga.p[i].N, 128) * ga.p[i].batch;
+        if (use8 && t128 > 200 && t128 <= 256 && !g_no_8w) v = 4;
+    }
+    if (v == 4) return launch_grouped_fp8_tile<128, 128, 8>(ga, stream);
     if (v == 3) return launch_grouped_fp8_tile<128, 128>(ga, stream);
     if (v == 2) return launch_grouped_fp8_tile<128, 64>(ga, stream);
     return launch_grouped_fp8_tile<64, 64>(ga, stream);

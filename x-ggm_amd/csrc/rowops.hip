@@ -557,16 +557,40 @@ __global__ __launch_bounds__(LN_BWD_W * 64) void ln_bwd_kernel(LnBwdGroup G, int
 }
 
 // ------------------------------------------------------------------------------- embeddings
+// e4m3 copy of a row kernel's output (fp8 forward, BASELINE configs[4]): the two encoder inputs leave their producers
+// as e4m3 next to the bf16 form, like every other operand of an fp8 product -- no quantisation launch in the step
+struct Emit8 {
+    unsigned char* out8;  // or null
+    const float* qscale;
+    float* amax;
+    int slots;
+};
+template <int W> __device__ __forceinline__ void emit8_record(const Emit8& e8, const Q8& qs, float amax8, int lane, int wid) {
+    __shared__ float red8[W];
+    const float wv = wave_max(amax8);
+    if (lane == 0) red8[wid] = wv;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float bm = red8[0];
+#pragma unroll
+        for (int w = 1; w < W; ++w) bm = fmaxf(bm, red8[w]);
+        if (bm > qs.thr) amax_record(e8.amax, e8.slots, (int)blockIdx.x, bm);  // one atomic per workgroup, spread over the slots
+    }
+}
+
 template <typename T, int NV>
 __global__ __launch_bounds__(NT) void embed_fwd_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ seg,
                                                        const T* __restrict__ word, const T* __restrict__ pos,
                                                        const T* __restrict__ type, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, T* out, T* z_out, float* stats, int M,
-                                                       int Tlen, int H, float eps, DropArgs d) {
+                                                       int Tlen, int H, float eps, DropArgs d, Emit8 e8) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     uint64_t seed, off;
     rng_load(d.rng, seed, off);
     const float ik_post = d.p_post > 0.f ? 1.f / (1.f - d.p_post) : 1.f;
+    unsigned char* out8 = sizeof(T) == 2 ? e8.out8 : nullptr;
+    const Q8 qs(out8 ? e8.qscale : nullptr);
+    float amax8 = 0.f;
     for (int row = blockIdx.x * WPB + wid; row < M; row += gridDim.x * WPB) {
         const int64_t rb = (int64_t)row * H;
         const int64_t wi = ids[row], pi = row % Tlen, ti = seg ? seg[row] : 0;
@@ -622,9 +646,14 @@ __global__ __launch_bounds__(NT) void embed_fwd_kernel(const int64_t* __restrict
                     for (int i = 0; i < 4; ++i) y[i] *= s4[i];
                 }
                 store4(out + rb + c, y);
+                if (out8) {
+                    amax8 = fmaxf(fmaxf(amax8, fmaxf(fabsf(y[0]), fabsf(y[1]))), fmaxf(fabsf(y[2]), fabsf(y[3])));
+                    *reinterpret_cast<int*>(out8 + rb + c) = pack4_e4m3(y[0], y[1], y[2], y[3], qs.q);
+                }
             }
         }
     }
+    if (out8 && e8.amax) emit8_record<WPB>(e8, qs, amax8, lane, wid);
 }
 
 // The gradients of the three embedding tables: table row k receives the sum of the dz rows that looked it up; row 0 of
@@ -753,11 +782,14 @@ __global__ __launch_bounds__(NT) void visn_embed_fwd_kernel(const T* u, const fl
                                                             const float* __restrict__ bb, const float* __restrict__ g1,
                                                             const float* __restrict__ b1, const float* __restrict__ g2,
                                                             const float* __restrict__ b2, T* out, T* z1_out, T* z2_out,
-                                                            float* stats, int M, int H, float eps, DropArgs d) {
+                                                            float* stats, int M, int H, float eps, DropArgs d, Emit8 e8) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     uint64_t seed, off;
     rng_load(d.rng, seed, off);
     const float ik_post = d.p_post > 0.f ? 1.f / (1.f - d.p_post) : 1.f;
+    unsigned char* out8 = sizeof(T) == 2 ? e8.out8 : nullptr;
+    const Q8 qs(out8 ? e8.qscale : nullptr);
+    float amax8 = 0.f;
     for (int row = blockIdx.x * WPB + wid; row < M; row += gridDim.x * WPB) {
         const int64_t rb = (int64_t)row * H;
         float bx[4];
@@ -825,9 +857,14 @@ __global__ __launch_bounds__(NT) void visn_embed_fwd_kernel(const T* u, const fl
                     for (int i = 0; i < 4; ++i) y[i] *= s4[i];
                 }
                 store4(out + rb + c, y);
+                if (out8) {
+                    amax8 = fmaxf(fmaxf(amax8, fmaxf(fabsf(y[0]), fabsf(y[1]))), fmaxf(fabsf(y[2]), fabsf(y[3])));
+                    *reinterpret_cast<int*>(out8 + rb + c) = pack4_e4m3(y[0], y[1], y[2], y[3], qs.q);
+                }
             }
         }
     }
+    if (out8 && e8.amax) emit8_record<WPB>(e8, qs, amax8, lane, wid);
 }
 
 // backward: du (grad of the GEMM output u, T), and atomically accumulated fp32 grads of
@@ -1083,15 +1120,19 @@ int ln_bwd(const void* dy, const void* z, const float* stats, const float* gamma
 template <typename T>
 int embed_fwd(const int64_t* ids, const int64_t* seg, const void* word, const void* pos, const void* type,
               const float* gamma, const float* beta, void* out, void* z_out, float* stats, int M, int Tlen, int H,
-              float eps, float p, const uint64_t* rng, uint32_t sid, hipStream_t st) {
+              float eps, float p, const uint64_t* rng, uint32_t sid, void* out8, const float* qscale, float* amax,
+              int amax_slots, hipStream_t st) {
     if (int e = check_row_shape("xggm_embed_fwd", M, H)) return e;
+    XGGM_REQUIRE(!out8 || (sizeof(T) == 2 && reinterpret_cast<uintptr_t>(out8) % 4 == 0),
+                 "xggm_embed_fwd: the e4m3 output copy needs bf16 storage and a 4-byte aligned buffer");
+    const Emit8 e8{reinterpret_cast<unsigned char*>(out8), qscale, amax, amax_slots > 1 ? amax_slots : 1};
     XGGM_REQUIRE(ids && word && pos && type && gamma && beta && out && z_out && stats, "xggm_embed_fwd: null pointer");
     XGGM_REQUIRE(Tlen > 0 && M % Tlen == 0, "xggm_embed_fwd: M=%d is not a multiple of T=%d", M, Tlen);
     XGGM_REQUIRE(p == 0.f || rng, "xggm_embed_fwd: dropout needs an rng state");
     DropArgs d{0.f, p, rng, 0, sid};
     DISPATCH_NV(H, hipLaunchKernelGGL((embed_fwd_kernel<T, NV>), dim3(rows_grid(M, 4096)), dim3(NT), 0, st, ids, seg,
                                        (const T*)word, (const T*)pos, (const T*)type, gamma, beta, (T*)out, (T*)z_out, stats,
-                                       M, Tlen, H, eps, d));
+                                       M, Tlen, H, eps, d, e8));
     return xggm_check_launch("xggm_embed_fwd");
 }
 
@@ -1114,15 +1155,19 @@ int embed_bwd(const int64_t* ids, const int64_t* seg, const void* dy, const void
 template <typename T>
 int visn_fwd(const void* u, const float* bf, const void* boxes, const float* Wb, const float* bb, const float* g1,
              const float* b1, const float* g2, const float* b2, void* out, void* z1, void* z2, float* stats, int M, int H,
-             float eps, float p, const uint64_t* rng, uint32_t sid, hipStream_t st) {
+             float eps, float p, const uint64_t* rng, uint32_t sid, void* out8, const float* qscale, float* amax,
+             int amax_slots, hipStream_t st) {
     if (int e = check_row_shape("xggm_visn_embed_fwd", M, H)) return e;
+    XGGM_REQUIRE(!out8 || (sizeof(T) == 2 && reinterpret_cast<uintptr_t>(out8) % 4 == 0),
+                 "xggm_visn_embed_fwd: the e4m3 output copy needs bf16 storage and a 4-byte aligned buffer");
+    const Emit8 e8{reinterpret_cast<unsigned char*>(out8), qscale, amax, amax_slots > 1 ? amax_slots : 1};
     XGGM_REQUIRE(u && bf && boxes && Wb && bb && g1 && b1 && g2 && b2 && out && z1 && z2 && stats,
                  "xggm_visn_embed_fwd: null pointer");
     XGGM_REQUIRE(p == 0.f || rng, "xggm_visn_embed_fwd: dropout needs an rng state");
     DropArgs d{0.f, p, rng, 0, sid};
     DISPATCH_NV(H, hipLaunchKernelGGL((visn_embed_fwd_kernel<T, NV>), dim3(rows_grid(M, 4096)), dim3(NT), 0, st,
                                        (const T*)u, bf, (const T*)boxes, Wb, bb, g1, b1, g2, b2, (T*)out, (T*)z1, (T*)z2,
-                                       stats, M, H, eps, d));
+                                       stats, M, H, eps, d, e8));
     return xggm_check_launch("xggm_visn_embed_fwd");
 }
 
@@ -1209,8 +1254,10 @@ size_t ws_colsum(int M, int N) { return sizeof(float) * (size_t)ceil_div(M, CS_R
     extern "C" int xggm_embed_fwd_##SUF(const int64_t* ids, const int64_t* seg, const void* word, const void* pos,         \
                                         const void* type, const float* gamma, const float* beta, void* out, void* z_out,   \
                                         float* stats, int M, int Tlen, int H, float eps, float p, const uint64_t* rng,    \
-                                        uint32_t sid, hipStream_t st) {                                                   \
-        return embed_fwd<T>(ids, seg, word, pos, type, gamma, beta, out, z_out, stats, M, Tlen, H, eps, p, rng, sid, st);  \
+                                        uint32_t sid, void* out8, const float* qscale, float* amax, int amax_slots,       \
+                                        hipStream_t st) {                                                                 \
+        return embed_fwd<T>(ids, seg, word, pos, type, gamma, beta, out, z_out, stats, M, Tlen, H, eps, p, rng, sid, out8, \
+                            qscale, amax, amax_slots, st);                                                                 \
     }                                                                                                                       \
     extern "C" int xggm_embed_bwd_##SUF(const int64_t* ids, const int64_t* seg, const void* dy, const void* z,             \
                                         const float* stats, const float* gamma, void* dz_ws, float* dword, float* dpos,    \
@@ -1222,8 +1269,10 @@ size_t ws_colsum(int M, int N) { return sizeof(float) * (size_t)ceil_div(M, CS_R
     extern "C" int xggm_visn_embed_fwd_##SUF(const void* u, const float* bf, const void* boxes, const float* Wb,           \
                                              const float* bb, const float* g1, const float* b1, const float* g2,           \
                                              const float* b2, void* out, void* z1, void* z2, float* stats, int M, int H,   \
-                                             float eps, float p, const uint64_t* rng, uint32_t sid, hipStream_t st) {     \
-        return visn_fwd<T>(u, bf, boxes, Wb, bb, g1, b1, g2, b2, out, z1, z2, stats, M, H, eps, p, rng, sid, st);          \
+                                             float eps, float p, const uint64_t* rng, uint32_t sid, void* out8,           \
+                                             const float* qscale, float* amax, int amax_slots, hipStream_t st) {          \
+        return visn_fwd<T>(u, bf, boxes, Wb, bb, g1, b1, g2, b2, out, z1, z2, stats, M, H, eps, p, rng, sid, out8, qscale,   \
+                           amax, amax_slots, st);                                                                          \
     }                                                                                                                       \
     extern "C" int xggm_visn_embed_bwd_##SUF(const void* dy, const void* z1, const void* z2, const float* stats,           \
                                              const void* boxes, const float* g1, const float* g2, void* du, float* dbf,    \

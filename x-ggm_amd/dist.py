@@ -392,23 +392,33 @@ class ShardedUpdate(GradSync):
     def exchange_norm(self, sq):
         if self.world > 1 or self.force:
             dist.all_reduce(sq, op=dist.ReduceOp.SUM, group=self.group)
+            f8 = getattr(self.arena, "fp8", None)
+            if f8 is not None:
+                # fp8 forward: every rank quantises only its slices of the weights and records their maxima; the scale of
+                # an operand needs the maximum over ALL its slices -- one small MAX all-reduce of the weight entries of the
+                # scale table, once per pass, in front of the update that derives the new scales from it
+                dist.all_reduce(f8.weight_amax(), op=dist.ReduceOp.MAX, group=self.group)
 
     def gather(self):
         """all-gather the bf16 shadow weights of this pass's matrix runs from their owners"""
         self.stale = True
         if self.world == 1 and not self.force:
             return
-        sh = self.arena.shadow
+        f8 = getattr(self.arena, "fp8", None)
+        # what the products read: the bf16 shadow (backward, and forward without fp8) and, with the fp8 forward, the
+        # e4m3 copies the owners wrote in the same update
+        bufs = [self.arena.shadow] + ([f8.shadow8] if f8 is not None else [])
         works = []
-        for run in self.runs:
-            a, b = run
-            o0, o1 = self.own(run)
-            if self.backend == "nccl":
-                works.append(dist.all_gather_into_tensor(sh[a:b], sh[o0:o1], group=self.group, async_op=True))
-            else:
-                c = (b - a) // self.world
-                works.append(dist.all_gather([sh[a + i * c:a + (i + 1) * c] for i in range(self.world)], sh[o0:o1].clone(),
-                                             group=self.group, async_op=True))
+        for sh in bufs:
+            for run in self.runs:
+                a, b = run
+                o0, o1 = self.own(run)
+                if self.backend == "nccl":
+                    works.append(dist.all_gather_into_tensor(sh[a:b], sh[o0:o1], group=self.group, async_op=True))
+                else:
+                    c = (b - a) // self.world
+                    works.append(dist.all_gather([sh[a + i * c:a + (i + 1) * c] for i in range(self.world)], sh[o0:o1].clone(),
+                                                 group=self.group, async_op=True))
         for wk in works:
             wk.wait()
 

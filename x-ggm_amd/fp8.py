@@ -112,6 +112,11 @@ class Fp8State:
             k += p.numel()
         return self.shadow8[o0:o0 + k].view(-1, ps[0].shape[1]), self.dscale[e:e + 1]
 
+    def weight_amax(self):
+        """the maxima recorded for the weight operands (entries [0, n_w) of the table, AMAX_SLOTS floats each): what
+        the sharded update all-reduces (MAX) over the data-parallel ranks"""
+        return self.amax[:self.n_w * AMAX_SLOTS]
+
     def adam_w8(self, gname):
         """arguments of the e4m3 copy for the update of arena group ``gname`` (None: the group has none)"""
         if gname not in self.w_range:

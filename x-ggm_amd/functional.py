@@ -141,10 +141,17 @@ class EmbedFn(Function):
     def forward(ctx, rt, mod, ids, seg, *params):
         ctx.np = len(params)
         a = rt.arena
-        out, z, stats = ops.embed_fwd(ids, seg, a.w(mod.word_embeddings.weight),
-                                      a.w(mod.position_embeddings.weight),
-                                      a.w(mod.token_type_embeddings.weight), mod.LayerNorm.weight.data,
-                                      mod.LayerNorm.bias.data, 1e-12, rt.p(rt.p_hidden), rt.rng, mod._sid)
+        # fp8 forward: the embedding output is the A operand of the first language layer's e4m3 products -- it leaves
+        # this kernel as e4m3 too (no quantisation launch)
+        f8 = a.fp8 if a.w(mod.word_embeddings.weight).dtype == torch.bfloat16 else None
+        e8 = f8.emit(("emb", id(mod))) if f8 is not None else (None, None)
+        res = ops.embed_fwd(ids, seg, a.w(mod.word_embeddings.weight),
+                            a.w(mod.position_embeddings.weight),
+                            a.w(mod.token_type_embeddings.weight), mod.LayerNorm.weight.data,
+                            mod.LayerNorm.bias.data, 1e-12, rt.p(rt.p_hidden), rt.rng, mod._sid, emit8=e8[0])
+        out, z, stats = res[:3]
+        if f8 is not None:
+            f8.put(out, res[3], e8[1])
         ctx.rt, ctx.mod, ctx.p = rt, mod, rt.p(rt.p_hidden)
         ctx.saved = (ids, seg, z, stats)
         rt.emb_ids = ids  # the rows of the word table this pass touches (data parallel: dist.GradSync.set_sparse_table)
@@ -171,10 +178,15 @@ class VisnEmbedFn(Function):
         ctx.np = len(params)
         u, _ = ops.linear_fwd(feats, _w(rt, mod.visn_fc.weight), None)
         p = rt.p(rt.p_hidden)
-        out, z1, z2, stats = ops.visn_embed_fwd(
+        f8 = rt.arena.fp8 if u.dtype == torch.bfloat16 else None
+        e8 = f8.emit(("visn_emb", id(mod))) if f8 is not None else (None, None)
+        res = ops.visn_embed_fwd(
             u, mod.visn_fc.bias.data, boxes, mod.box_fc.weight.data, mod.box_fc.bias.data,
             mod.visn_layer_norm.weight.data, mod.visn_layer_norm.bias.data, mod.box_layer_norm.weight.data,
-            mod.box_layer_norm.bias.data, 1e-12, p, rt.rng, mod._sid)
+            mod.box_layer_norm.bias.data, 1e-12, p, rt.rng, mod._sid, emit8=e8[0])
+        out, z1, z2, stats = res[:4]
+        if f8 is not None:
+            f8.put(out, res[4], e8[1])
         ctx.rt, ctx.mod, ctx.p = rt, mod, p
         ctx.saved = (feats, boxes, z1, z2, stats)
         return out

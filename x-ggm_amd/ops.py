@@ -654,7 +654,17 @@ def ln_bwd(dy, z, stats, gamma, dgamma, dbeta, dbias, want_din=True, want_dres=F
     return d_in, d_res
 
 
-def embed_fwd(ids, seg, word, pos, typ, gamma, beta, eps, p, rng, sid):
+def _emit8_args(emit8, shape, device):
+    """(out8, qscale ptr, amax ptr, slots) of a row kernel that also writes its output as e4m3; ``emit8`` = (qscale,
+    amax) 1-element / slot-spread fp32 device tensors, or None"""
+    if emit8 is None:
+        return None, None, None, 0
+    out8 = torch.empty(shape, device=device, dtype=torch.uint8)
+    return out8, ptr(emit8[0]), ptr(emit8[1]), (emit8[1].numel() if emit8[1] is not None else 0)
+
+
+def embed_fwd(ids, seg, word, pos, typ, gamma, beta, eps, p, rng, sid, emit8=None):
+    """``emit8`` = (qscale, amax): the output is also written as e4m3 (returned as a 4th value)"""
     B, T = ids.shape
     _c(ids, torch.int64, "input_ids")
     if seg is not None:
@@ -668,8 +678,12 @@ def embed_fwd(ids, seg, word, pos, typ, gamma, beta, eps, p, rng, sid):
     out = torch.empty((B * T, H), device=word.device, dtype=word.dtype)
     z = torch.empty_like(out)
     stats = torch.empty((B * T, 2), device=word.device, dtype=F32)
+    out8, q, am, slots = _emit8_args(emit8 if word.dtype == BF16 else None, (B * T, H), word.device)
     call("xggm_embed_fwd_" + sfx(word.dtype), ptr(ids), ptr(seg), ptr(word), ptr(pos), ptr(typ), ptr(gamma),
-         ptr(beta), ptr(out), ptr(z), ptr(stats), B * T, T, H, float(eps), float(p), ptr(rng), sid, stream())
+         ptr(beta), ptr(out), ptr(z), ptr(stats), B * T, T, H, float(eps), float(p), ptr(rng), sid, ptr(out8), q, am, slots,
+         stream())
+    if emit8 is not None:
+        return out, z, stats, out8
     return out, z, stats
 
 
@@ -686,7 +700,8 @@ def embed_bwd(ids, seg, dy, z, stats, gamma, dword, dpos, dtyp, dgamma, dbeta, p
          ptr(ws), nb, stream())
 
 
-def visn_embed_fwd(u, bf, boxes, Wb, bb, g1, b1, g2, b2, eps, p, rng, sid):
+def visn_embed_fwd(u, bf, boxes, Wb, bb, g1, b1, g2, b2, eps, p, rng, sid, emit8=None):
+    """``emit8`` = (qscale, amax): the output is also written as e4m3 (returned as a 5th value)"""
     _c(u), _c(boxes, u.dtype, "boxes")
     M, H = u.shape
     assert tuple(boxes.shape) == (M, 4) and tuple(Wb.shape) == (H, 4)
@@ -695,9 +710,12 @@ def visn_embed_fwd(u, bf, boxes, Wb, bb, g1, b1, g2, b2, eps, p, rng, sid):
     out = torch.empty_like(u)
     z2 = torch.empty_like(u)
     stats = torch.empty((M, 4), device=u.device, dtype=F32)
+    out8, q, am, slots = _emit8_args(emit8 if u.dtype == BF16 else None, (M, H), u.device)
     call("xggm_visn_embed_fwd_" + sfx(u.dtype), ptr(u), ptr(bf), ptr(boxes), ptr(Wb), ptr(bb), ptr(g1),
          ptr(b1), ptr(g2), ptr(b2), ptr(out), ptr(u), ptr(z2), ptr(stats), M, H, float(eps), float(p), ptr(rng),
-         sid, stream())
+         sid, ptr(out8), q, am, slots, stream())
+    if emit8 is not None:
+        return out, u, z2, stats, out8
     return out, u, z2, stats
 
 
