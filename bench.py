@@ -194,8 +194,12 @@ def make_loader(model, args, device, n_batches=8):
     label2ans = ["a%d" % k for k in range(args.answers)]
     ds = VQADataset("train", data=data, ans2label={a: k for k, a in enumerate(label2ans)}, label2ans=label2ans)
     ts = VQATorchDataset(ds, shard=path)
+    # handover="inline": the producer fills pinned slots, the trainer ships a slot with ONE stream-ordered copy into its
+    # static inputs (CapturedTrainer.load_packed).  XGGM_LOADER_RING=1: the round-2 path (copy stream + device ring +
+    # per-field hand-over copies), kept for the same-box comparison
+    mode = "ring" if os.environ.get("XGGM_LOADER_RING") else "inline"
     loader = DataLoaderX(ts, args.batch, shuffle=True, drop_last=True, device=device, batcher=model.lxrt_encoder.batcher,
-                         depth=3, seed=args.seed + rank, epochs=None)
+                         depth=3, seed=args.seed + rank, epochs=None, handover=mode)
     host_bytes = args.batch * (36 * 2048 * 2 + 36 * 4 * 4 + args.answers * 4 + 36 * 36 * 4 + 3 * 20 * 8)
     return loader, host_bytes, tmp
 
@@ -547,7 +551,12 @@ def main():
         # Opt-in until that is measured on an 8-GPU node.
         zero1 = bool(args.zero1) if args.zero1 is not None else False
         enable_data_parallel(model, wire_dtype=torch.bfloat16 if args.wire == "bf16" else None, zero1=zero1)
-    trainer = CapturedTrainer(model, optim, batch, sigma=1.0, order=args.order, use_graph=not args.no_graph)
+    loader_parts = None
+    if not args.no_loader:
+        loader_parts = make_loader(model, args, device)  # before the trainer: its static inputs take the loader's slot layout
+    inline = loader_parts is not None and loader_parts[0].handover == "inline"
+    trainer = CapturedTrainer(model, optim, batch, sigma=1.0, order=args.order, use_graph=not args.no_graph,
+                              packed_spec=loader_parts[0].spec if inline else None)
     log("trainer ready (hip_graph=%s)" % (not args.no_graph))
     pyrng = random.Random(args.seed)  # identical draws on every rank (src/vqa/vqacpv2.py:192)
 
@@ -589,11 +598,18 @@ def main():
     with_loader = None
     if not args.no_loader:
         import shutil
-        loader, host_bytes, tmp = make_loader(model, args, device)
+        loader, host_bytes, tmp = loader_parts
         it = iter(loader)
+
+        def hand_over(item):
+            if inline:
+                trainer.load_packed(it)  # one host-to-device copy of the slot, stream-ordered
+            else:
+                trainer.load_batch(batch_of(item))
+
         try:
             for i in range(3):
-                trainer.load_batch(batch_of(next(it)))
+                hand_over(next(it))
                 trainer.iteration(branch())
             barrier()
             t1 = time.perf_counter()
@@ -602,11 +618,11 @@ def main():
                 # batch i was assembled, tokenised and copied to the device by the producer thread while step i - 1
                 # ran; load_batch hands it to the captured graphs' input buffers (device to device)
                 if dbg is None:
-                    trainer.load_batch(batch_of(next(it)))
+                    hand_over(next(it))
                     trainer.iteration(branch())
                 else:  # host-side time of the three calls
                     a = time.perf_counter(); item = next(it)
-                    b_ = time.perf_counter(); trainer.load_batch(batch_of(item))
+                    b_ = time.perf_counter(); hand_over(item)
                     c = time.perf_counter(); trainer.iteration(branch())
                     d = time.perf_counter()
                     dbg[0] += b_ - a; dbg[1] += c - b_; dbg[2] += d - c
@@ -622,8 +638,10 @@ def main():
                        "ms_per_step": round(1000.0 * dtl / args.steps, 3), "host_bytes_per_step": host_bytes,
                        "what": "a fresh batch every step through the package's input pipeline: memory-mapped shard "
                                "(bf16 features) -> pinned buffers -> cached WordPiece tokenisation of %d question "
-                               "strings -> H2D on a copy stream (producer thread, 3 batches in flight) -> device-side "
-                               "hand-over to the captured graphs' input buffers" % args.batch}
+                               "strings (producer thread, 3 pinned slots in flight) -> %s" % (args.batch,
+                               "ONE stream-ordered host-to-device copy of the slot into the captured graphs' input buffers"
+                               if inline else "H2D on a copy stream -> device-side hand-over to the captured graphs' input buffers"),
+                       "handover": "inline" if inline else "ring"}
         log("with loader: %.3f ms/step" % with_loader["ms_per_step"])
 
     # the reference's own training batch size (script/vqacpv2.sh:10,23: 92; script/gqa_ood.sh:10,24: 96): row counts

@@ -260,11 +260,14 @@ def test_bench_c4_stress_line():
     assert line["cpu_baseline"]["value"] > 0 and line["value"] > line["cpu_baseline"]["value"]
 
 
-def test_prefetching_loader_feeds_the_captured_trainer(tmp_path):
-    """shard -> VQATorchDataset -> DataLoaderX(device=cuda, batcher) -> CapturedTrainer.load_batch: what arrives in
-    the trainer's static input buffers equals the host items (features as their bf16 values), question strings have
-    become the tokenised triple, batches keep arriving while earlier ones are still in use on the GPU, and training
-    on loader batches gives the losses of the same batches fed as plain tensors."""
+@pytest.mark.parametrize("handover", ["ring", "inline"])
+def test_prefetching_loader_feeds_the_captured_trainer(tmp_path, handover):
+    """shard -> VQATorchDataset -> DataLoaderX(device=cuda, batcher) -> CapturedTrainer: what arrives in the trainer's
+    static input buffers equals the host items (features as their bf16 values), question strings have become the
+    tokenised triple, batches keep arriving while earlier ones are still in use on the GPU, and training on loader
+    batches leaves the engine in the state of a twin fed the same batches as plain tensors -- bit for bit.
+    ``ring``: the producer copies to a device ring on its copy stream, ``load_batch`` hands over field by field;
+    ``inline``: the producer fills pinned slots, ``load_packed`` ships a slot with ONE stream-ordered copy."""
     from xggm_amd.engine import CapturedTrainer
     from xggm_amd.tools.shards import ShardWriter
     from xggm_amd.tools.data_loader import DataLoaderX
@@ -295,21 +298,32 @@ def test_prefetching_loader_feeds_the_captured_trainer(tmp_path):
     batch0 = dict(feats=first[1].clone(), boxes=first[2].clone(), input_ids=first[3][0].clone(), input_mask=first[3][1].clone(),
                   segment_ids=first[3][2].clone(), target=first[4].clone(), adj_true=first[5].clone())
     it0.close()  # an abandoned iterator would keep its producer thread parked on the queue
-    tr = CapturedTrainer(m, opt, batch0, warmup_iters=1)
+    loader = DataLoaderX(ts, B, device=DEV, batcher=batcher, depth=2, handover=handover)
+    tr = CapturedTrainer(m, opt, batch0, warmup_iters=1, packed_spec=loader.spec if handover == "inline" else None)
     tr2 = CapturedTrainer(m2, opt2, batch0, warmup_iters=1)
     held, losses, losses2 = [], [], []
-    for k, item in enumerate(DataLoaderX(ts, B, device=DEV, batcher=batcher, depth=2)):
+    it = iter(loader)
+    for k, item in enumerate(it):
         qid, feats, boxes, sent, target, adj = item
-        assert feats.is_cuda and feats.dtype == torch.bfloat16 and sent[0].is_cuda
+        assert feats.dtype == torch.bfloat16 and feats.is_cuda == (handover == "ring") and sent[0].is_cuda == feats.is_cuda
         host = [ts[k * B + b] for b in range(B)]
         assert qid == [h[0] for h in host]
         assert torch.equal(feats.float().cpu(), torch.from_numpy(np.stack([h[1] for h in host])))
         assert torch.equal(boxes.cpu(), torch.from_numpy(np.stack([h[2] for h in host])))
         assert torch.equal(target.cpu(), torch.stack([h[4] for h in host]))
         assert torch.equal(adj.cpu(), torch.from_numpy(np.stack([h[5] for h in host])))
-        bt = dict(feats=feats, boxes=boxes, input_ids=sent[0], input_mask=sent[1], segment_ids=sent[2], target=target,
-                  adj_true=adj)
-        tr.load_batch(bt)
+        if handover == "ring":
+            bt = dict(feats=feats, boxes=boxes, input_ids=sent[0], input_mask=sent[1], segment_ids=sent[2], target=target,
+                      adj_true=adj)
+            tr.load_batch(bt)
+        else:
+            tr.load_packed(it)  # one copy of the pinned slot into the flat static buffer
+            bt = {kk: v.clone() for kk, v in tr.static.items()}
+            want = dict(feats=feats, boxes=boxes, input_ids=sent[0], input_mask=sent[1], segment_ids=sent[2], target=target,
+                        adj_true=adj)
+            for kk, v in want.items():  # (reads the pinned views: the slot is not rewritten before the next next())
+                assert torch.equal(bt[kk].cpu(), v), kk
+            feats = bt["feats"]
         (lp, _, _), (lg, _, _) = tr.iteration("rel")
         losses.append((float(lp), float(lg)))
         # the same batch as independent tensors through a second, identical engine
@@ -350,7 +364,8 @@ def _small_shard(tmp_path, n_img, F, A, vocab, seed=21):
                            shard=w.close())
 
 
-def test_loader_ring_survives_a_gpu_that_lags_the_host(tmp_path):
+@pytest.mark.parametrize("handover", ["ring", "inline"])
+def test_loader_ring_survives_a_gpu_that_lags_the_host(tmp_path, handover):
     """a slot's PINNED buffer must not be rewritten while the host-to-device copy out of it is still queued.
     The GPU is parked behind a ~80 ms spin kernel while the host races through every batch of a depth-2 ring (each
     batch is only cloned on the stream -- nothing synchronises); the clones, read after the GPU has caught up, must be
@@ -370,8 +385,21 @@ def test_loader_ring_survives_a_gpu_that_lags_the_host(tmp_path):
     torch.cuda.synchronize()
     torch.cuda._sleep(int(2e8))  # ~80 ms: every copy below queues up behind this
     got = []
-    for k, (qid, feats, boxes, sent, target, adj) in enumerate(DataLoaderX(ts, B, device=DEV, batcher=batcher, depth=2)):
-        got.append((feats.clone(), boxes.clone(), torch.stack(sent).clone(), target.clone(), adj.clone()))
+    if handover == "ring":
+        for k, (qid, feats, boxes, sent, target, adj) in enumerate(DataLoaderX(ts, B, device=DEV, batcher=batcher, depth=2)):
+            got.append((feats.clone(), boxes.clone(), torch.stack(sent).clone(), target.clone(), adj.clone()))
+    else:
+        # the consumer's own stream-ordered copy of the pinned slot (what CapturedTrainer.load_packed does): the slot
+        # must not be rewritten before that queued copy has run
+        from xggm_amd.tools.data_loader import packed_like
+        loader = DataLoaderX(ts, B, device=DEV, batcher=batcher, depth=2, handover="inline")
+        flat, view = packed_like(loader.spec, torch.device(DEV, torch.cuda.current_device()))
+        it = iter(loader)
+        for item in it:
+            flat.copy_(it.flat, non_blocking=True)
+            it.mark_copied()
+            got.append((view["feats"].clone(), view["boxes"].clone(), view["ids"].clone(), view["target"].clone(),
+                        view["adj"].clone()))
     torch.cuda.synchronize()
     assert len(got) == n_img // B
     for k, (feats, boxes, ids3, target, adj) in enumerate(got):

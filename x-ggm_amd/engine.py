@@ -39,12 +39,29 @@ class _quiet_gc:
 
 
 class CapturedTrainer:
-    def __init__(self, model, optim, batch, sigma=1.0, order="vqa", clip=5.0, use_graph=True, warmup_iters=2):
+    def __init__(self, model, optim, batch, sigma=1.0, order="vqa", clip=5.0, use_graph=True, warmup_iters=2,
+                 packed_spec=None):
         """``batch``: dict of DEVICE tensors feats, boxes, input_ids, input_mask, segment_ids,
-        target, adj_true; they become the static input buffers (``load_batch`` copies into them)."""
+        target, adj_true; they become the static input buffers (``load_batch`` copies into them).
+        ``packed_spec`` = ``DataLoaderX.spec`` of a loader with ``handover="inline"``: the static buffers are then
+        views of ONE flat device buffer laid out like the loader's pinned slots, and ``load_packed`` hands a batch over
+        with a single host-to-device copy on the compute stream."""
         self.model, self.optim = model, optim
         self.rt = runtime_of(model)
-        self.static = {k: v.clone() for k, v in batch.items() if torch.is_tensor(v)}
+        self.static_flat = None
+        if packed_spec is not None:
+            from .tools.data_loader import packed_like
+            dev = next(model.parameters()).device
+            self.static_flat, v = packed_like(packed_spec, dev)
+            self.static = dict(feats=v["feats"], boxes=v["boxes"], input_ids=v["ids"][0], input_mask=v["ids"][1],
+                               segment_ids=v["ids"][2], target=v["target"], adj_true=v["adj"])
+            for k, t in self.static.items():
+                if tuple(t.shape) != tuple(batch[k].shape) or t.dtype != batch[k].dtype:
+                    raise ValueError("packed_spec field %s is %s %s, the batch has %s %s"
+                                     % (k, tuple(t.shape), t.dtype, tuple(batch[k].shape), batch[k].dtype))
+                t.copy_(batch[k])
+        else:
+            self.static = {k: v.clone() for k, v in batch.items() if torch.is_tensor(v)}
         self.sigma, self.clip = sigma, clip
         self.kl_weight = 8.0 if order == "vqa" else 12.0
         self.order = order
@@ -227,6 +244,18 @@ class CapturedTrainer:
         for k, v in batch.items():
             if k in self.static:
                 self.static[k].copy_(v, non_blocking=True)
+
+    def load_packed(self, it):
+        """hand over the batch the loader iterator ``it`` (DataLoaderX(handover="inline")) has just yielded: ONE copy of
+        the slot's pinned flat buffer into the static inputs, in stream order on the compute stream (it runs between
+        the previous iteration's graphs and the next one's: no second stream, no event the graphs wait for, no
+        device-to-device copies), then the slot is marked so that the producer does not rewrite it under the copy"""
+        if self.static_flat is None:
+            raise RuntimeError("load_packed needs CapturedTrainer(packed_spec=loader.spec)")
+        if it.flat is None or it.flat.numel() != self.static_flat.numel():
+            raise ValueError("the iterator's slot does not have this trainer's layout (handover='inline', same batch size)")
+        self.static_flat.copy_(it.flat, non_blocking=True)
+        it.mark_copied()
 
     def run_pass(self, kind):
         if not self.use_graph:

@@ -38,14 +38,32 @@ def _packed(spec, device, pin):
     return flat, {k: flat[o:o + n].view(spec[k][1]).view(spec[k][0]) for k, (o, n) in offs.items()}
 
 
+def packed_like(spec, device):
+    """a DEVICE buffer in the layout of the loader's pinned slots (``DataLoaderX.spec``): ``engine.CapturedTrainer``
+    keeps its static input buffers as views of one, so that a batch is handed over by ONE host-to-device copy"""
+    return _packed(spec, device, False)
+
+
 class DataLoaderX:
     def __init__(self, dataset, batch_size, shuffle=False, drop_last=False, device=None, batcher=None, depth=3, seed=0,
-                 epochs=1):
+                 epochs=1, handover="ring"):
         """``dataset``: object with ``__len__``, ``alloc(batch_size, pin)`` and ``collate(items, out)``
         (vqa.vqacpv2_data.VQATorchDataset); ``batcher``: lxrt.entry.SentenceBatcher or None (strings are passed
-        through); ``depth``: batches in flight (>= 2); ``epochs``: passes over the data per ``iter`` (None: endless)."""
+        through); ``depth``: batches in flight (>= 2); ``epochs``: passes over the data per ``iter`` (None: endless).
+        ``handover`` (with a CUDA ``device``):
+          "ring"    the producer copies every batch to a ring of DEVICE buffers on its own copy stream; iterating yields
+                    device tensors (the reference loop's ``.cuda()`` calls become no-ops);
+          "inline"  the producer only fills the PINNED ring; iterating yields pinned host tensors and the consumer copies
+                    the slot's flat buffer itself, stream-ordered on the compute stream (``_Iter.flat`` ->
+                    ``CapturedTrainer.load_packed``): ONE host-to-device copy per batch, no second stream, no events in
+                    the compute stream, no device-to-device hand-over.  Measured on MI355X (tools/exp_loader_variants.py,
+                    32 samples, 5.2 MB per batch): a copy stream beside the replayed graphs costs the step +0.36 ms
+                    (+0.52 with the hand-over copies), the same bytes copied in stream order +0.2 ms."""
         if depth < 2:
             raise ValueError("depth >= 2: one batch is consumed while the next is produced")
+        if handover not in ("ring", "inline"):
+            raise ValueError("handover: 'ring' or 'inline'")
+        self.handover = handover
         self.ds, self.B, self.shuffle, self.drop_last = dataset, batch_size, shuffle, drop_last
         self.device = torch.device(device) if device is not None else None
         if self.device is not None and self.device.type == "cuda" and self.device.index is None:
@@ -62,19 +80,24 @@ class DataLoaderX:
         spec = {k: (tuple(v.shape), v.dtype) for k, v in dataset.alloc(batch_size, False).items()}
         if batcher is not None:
             spec["ids"] = ((3, batch_size, batcher.T), torch.long)
+        self.spec = spec
         self.host_flat, self.dev_flat, self.host, self.dev = [], [], [], []
         for _ in range(depth):
             hf, hv = _packed(spec, None, True)
-            df, dv = _packed(spec, self.device, False)
             self.host_flat.append(hf)
-            self.dev_flat.append(df)
             self.host.append(hv)
-            self.dev.append(dv)
+            if handover == "ring":
+                df, dv = _packed(spec, self.device, False)
+                self.dev_flat.append(df)
+                self.dev.append(dv)
+        self._copied = [None] * depth  # per slot: event of the last H2D copy out of its pinned buffer (all iterators)
+        if handover == "inline":
+            self.dev = None
+            return
         self.copy_stream = torch.cuda.Stream(device=self.device)
         # the device buffers were zero-filled on the CURRENT stream just now: the first copies into them must not
         # overtake that fill (seen: a busy compute stream ran the fill after the first two batches had landed)
         self.copy_stream.wait_stream(torch.cuda.current_stream(self.device))
-        self._copied = [None] * depth  # per slot: event of the last H2D copy out of its pinned buffer (all iterators)
 
     def __len__(self):
         n = len(self.ds)
@@ -109,13 +132,15 @@ class _Iter:
         self.stop = False
         self.err = None
         self.held = None
+        self.flat = None
+        self._marked = False
         self.t = threading.Thread(target=self._produce, daemon=True)
         self.t.start()
 
     def _produce(self):
         L = self.L
         try:
-            if L.dev is not None:
+            if L.device is not None and L.device.type == "cuda":
                 torch.cuda.set_device(L.device)
             slot = 0
             for items in L._batches():
@@ -147,6 +172,11 @@ class _Iter:
                         ev.record(L.copy_stream)
                     self.copied[slot] = ev
                     out = {k: v[:B] for k, v in dev.items() if k != "ids"}
+                elif getattr(L, "handover", "ring") == "inline" and "ids" in host:
+                    # pinned slot, token ids included: the consumer ships the whole slot with one copy (``flat``)
+                    host["ids"].numpy()[:, :B] = L.batcher.host_batch(sents).numpy()
+                    sent = (host["ids"][0, :B], host["ids"][1, :B], host["ids"][2, :B])
+                    out = {k: v[:B] for k, v in host.items() if k != "ids"}
                 else:
                     out = {k: v[:B] for k, v in host.items()}
                     if L.batcher is not None:
@@ -166,6 +196,10 @@ class _Iter:
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(self.L.device))
                 self.released[slot] = ev
+            elif self.flat is not None and not self._marked:
+                # "inline" hand-over and the consumer did not say when its copy was queued: whatever it queued on the
+                # current stream out of this pinned slot lies in front of an event recorded now
+                self.mark_copied()
             self.free[slot].set()
             self.held = None
 
@@ -183,9 +217,22 @@ class _Iter:
         if ev is not None:
             torch.cuda.current_stream(self.L.device).wait_event(ev)
         self.held = slot
+        # "inline" hand-over: the slot's flat pinned buffer, for the consumer's own single copy (then ``mark_copied``)
+        self.flat = self.L.host_flat[slot] if getattr(self.L, "handover", "ring") == "inline" else None
+        self._marked = False
         if "adj" in out:
             return ids, out["feats"], out["boxes"], sent, out["target"], out["adj"]
         return ids, out["feats"], out["boxes"], sent
+
+    def mark_copied(self, event=None):
+        """"inline" hand-over: the consumer has queued its host-to-device copy of the current batch's pinned slot;
+        ``event`` (default: one recorded now on the current stream) tells the producer when the slot may be rewritten"""
+        if self.held is not None and self.L.device is not None and self.L.device.type == "cuda":
+            if event is None:
+                event = torch.cuda.Event()
+                event.record(torch.cuda.current_stream(self.L.device))
+            self.copied[self.held] = event
+            self._marked = True
 
     def close(self):
         self.stop = True
