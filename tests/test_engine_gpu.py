@@ -209,18 +209,22 @@ def _run_bench(args, env_extra=None, timeout=1200):
     return json.loads(lines[0])
 
 
-def test_bench_gpus_2_spawns_two_ranks():
+@pytest.mark.parametrize("order,zero1", [("vqa", 1), ("gqa", 0)])
+def test_bench_gpus_2_spawns_two_ranks(order, zero1):
     """`python bench.py --gpus 2` with no launcher: the parent spawns the two ranks itself (before any GPU call) and
     rank 0 prints the line.  Here both ranks share the one GPU of the box and exchange over gloo (XGGM_SHARE_GPU,
     XGGM_DIST_BACKEND): the process group, the staged exchange, the max-over-ranks timing and the JSON are those
-    of the real N = 2 run, only the transport differs."""
+    of the real N = 2 run, only the transport differs.  ``gqa``: BASELINE configs[2]'s data-parallel workload
+    (GQA-OOD-shaped: GGM pass first, KL x 12, A = 1842) in its default configuration (replicated update)."""
+    extra = ["--order", "gqa"] if order == "gqa" else []
     line = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8", "--no-cpu-baseline",
-                       "--no-kernel-timing", "--zero1", "1"], {"XGGM_DIST_BACKEND": "gloo", "XGGM_SHARE_GPU": "1"})
+                       "--no-kernel-timing", "--zero1", str(zero1)] + extra, {"XGGM_DIST_BACKEND": "gloo", "XGGM_SHARE_GPU": "1"})
     assert line["n_gpus"] == 2 and line["config"]["world_size"] == 2 and line["config"]["backend"] == "gloo"
-    assert line["config"]["zero1"] is True
+    assert line["config"]["zero1"] is bool(zero1) and line["config"]["order"] == order
+    assert ("A=1842" in line["config"]["workload"]) == (order == "gqa")
     assert line["config"]["global_batch"] == 16 and line["config"]["parallelism"] == "dp2"
     assert line["value"] > 0 and line["scaling"] == "weak" and line["steps"] == 2
-    assert line["value_with_loader"]["value"] > 0
+    assert line["value_with_loader"]["value"] > 0 and line["value_ref_batch"] is None
 
 
 def test_bench_rejects_a_world_size_that_contradicts_gpus():
