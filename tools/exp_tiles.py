@@ -1,5 +1,5 @@
 """The grouped launches of one layer (both streams) under every pinned tile (xggm_gemm_set_group_tile: 0 heuristic,
-1: 64x64, 2: 128x64, 4: 128x128 on 8 waves, 5: 128x256 / 6: 256x128 on 8 waves); 40 launches per graph replay, hot."""
+1: 64x64, 2: 128x64, 3: 128x128 on 4 waves, 4: 128x128 on 8 waves); 40 launches per graph replay, hot."""
 import os
 import sys
 
@@ -66,7 +66,7 @@ def main():
     cases = [("QKV fwd", fwd(2304, H)), ("attn-out fwd", fwd(H, H)), ("FFN1 fwd + GELU", fwd(I, H, True)),
              ("FFN2 fwd split-K 3", splitk()), ("FFN2 bwd (gelu', colsum)", bwd(H, I, True)), ("FFN1 bwd", bwd(I, H)),
              ("QKV bwd", bwd(2304, H)), ("attn-out bwd", bwd(H, H))]
-    pins = (0, 1, 2, 4, 5, 6)
+    pins = (1, 2, 3, 4)
     print("%-28s" % "launch" + "".join("%9s" % ("tile %d" % p) for p in pins))
     for name, (probs, keep) in cases:
         row = []

@@ -114,7 +114,7 @@ int g_single_grouped = 1;      // single problems with whole k-tiles also take t
                                // (same-box A/B 11.33 / 11.05 / 11.06 vs 11.01 / 11.00 / 11.03); xggm_gemm_set_tile(variant | 0x8000) turns it off
 int g_no_8w = 0;               // test hook: xggm_gemm_set_tile(variant | 0x4000): no 8-wave 128 x 128 tile
 int g_glds = 1;                // test hook: xggm_gemm_set_tile(variant | 0x400) keeps k-major pairs on the register-staged k-loop
-int g_group_tile = 0;          // test hook: 0 heuristic, 1: 64x64, 2: 128x64, 3: 128x128, 4: 128x128 on 8 waves, 5: 128x256 / 6: 256x128 on 8 waves
+int g_group_tile = 0;          // test hook: 0 heuristic, 1: 64x64, 2: 128x64, 3: 128x128, 4: 128x128 on 8 waves
 
 // stage a [64 rows][BK] operand tile into LDS (k contiguous).  elem(r,k) = base[r*rs + k*ks]
 template <typename T>
@@ -439,9 +439,17 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, const float4_
     for (int e = 0; e < 8; ++e) bias[e] = (g.bias && col + e < g.N) ? g.bias[col + e] : 0.f;
     // sum of squares of what this thread stores, per 64-row block of the tile (gradient-norm slots, see the end)
     constexpr int RS = BM >= 64 ? BM / 64 : 1, CS = BN >= 64 ? BN / 64 : 1;
+    static_assert(BM % 64 == 0 || BM < 64, "norm slots: whole 64-row blocks per tile");
     float sq_acc[RS];
 #pragma unroll
     for (int r = 0; r < RS; ++r) sq_acc[r] = 0.f;
+    // 64-row block (of the tile) a chunk's row lies in: with HALF = 64 that is the half index; HALF = 96 (BM = 192) cuts
+    // the blocks differently
+    auto sq_add = [&](int tile_row, float v) {
+#pragma unroll
+        for (int r = 0; r < RS; ++r)
+            if (RS == 1 || (tile_row >> 6) == r) sq_acc[r] += v;
+    };
     const Q8 qs(g.c8 ? g.c8_qscale : nullptr);
     const float q8 = qs.q;
     float amax8 = 0.f;
@@ -543,8 +551,8 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, const float4_
                             o1.x += p1[b].x; o1.y += p1[b].y; o1.z += p1[b].z; o1.w += p1[b].w;
                         }
                         if (g.sqsum)
-                            sq_acc[RS == 1 ? 0 : h] += (o0.x * o0.x + o0.y * o0.y) + (o0.z * o0.z + o0.w * o0.w) +
-                                                       (o1.x * o1.x + o1.y * o1.y) + (o1.z * o1.z + o1.w * o1.w);
+                            sq_add(h * HALF + lr0 + (it0 + b) * RPI, (o0.x * o0.x + o0.y * o0.y) + (o0.z * o0.z + o0.w * o0.w) +
+                                                                         (o1.x * o1.x + o1.y * o1.y) + (o1.z * o1.z + o1.w * o1.w));
                         // fp32 outputs are weight gradients (860 MB per pass, next read by the norm / update
                         // passes from HBM anyway): non-temporal, so they do not evict activations and weights
                         // (same-box A/B against plain stores, tools/ab.sh: 12.26 vs 12.39 ms per iteration)
@@ -586,7 +594,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, const float4_
                         float* c = reinterpret_cast<float*>(g.C) + idx + e;
                         const float o = g.accumulate ? (*c + x) : x;
                         *c = o;
-                        if (g.sqsum) sq_acc[RS == 1 ? 0 : h] += o * o;
+                        if (g.sqsum) sq_add(h * HALF + lr, o * o);
                     } else {
                         bf16* c = reinterpret_cast<bf16*>(g.C) + idx + e;
                         *c = __float2bfloat16(g.accumulate ? (__bfloat162float(*c) + x) : x);
@@ -601,14 +609,16 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, const float4_
             // by one thread in a fixed order into a partial row of its own (summed over the row blocks by
             // xggm_partial_reduce_batch): no floating-point atomics, the same bits whatever the scheduling
             constexpr int SUB = HALF / 32;
-            static_assert(HALF % 32 == 0 && SUB * BN <= NT, "column sums: 32-row blocks");
-            const int sub = tid / BN, cl = tid - sub * BN;
-            const int r0 = m0 + h * HALF + sub * 32;
-            if (sub < SUB && n0 + cl < g.N && r0 < g.M) {
-                const int rows = min(32, g.M - r0);
-                float sacc = 0.f;
-                for (int r = 0; r < rows; ++r) sacc += stage[(sub * 32 + r) * LDS_LD + cl];
-                g.colsum[((int64_t)bz * ((g.M + 31) >> 5) + (r0 >> 5)) * g.N + n0 + cl] = sacc;
+            static_assert(HALF % 32 == 0 && NT % BN == 0, "column sums: 32-row blocks, whole column sets per pass");
+            const int cl = tid % BN;
+            for (int sub = tid / BN; sub < SUB; sub += NT / BN) {
+                const int r0 = m0 + h * HALF + sub * 32;
+                if (n0 + cl < g.N && r0 < g.M) {
+                    const int rows = min(32, g.M - r0);
+                    float sacc = 0.f;
+                    for (int r = 0; r < rows; ++r) sacc += stage[(sub * 32 + r) * LDS_LD + cl];
+                    g.colsum[((int64_t)bz * ((g.M + 31) >> 5) + (r0 >> 5)) * g.N + n0 + cl] = sacc;
+                }
             }
             lds_barrier();
         }
@@ -898,6 +908,10 @@ __device__ __forceinline__ void gemm_kloop(const GemmArgs& g, int tile_m, int ti
 // in eight different 32-byte bank groups (R = 128: 256-byte rows; R = 64: two k-rows per bank row, the parity of k
 // picks the half), i.e. conflict-free without padding.
 template <int R> __device__ __forceinline__ int glds_rx(int k) {
+    // R = 192 (384-byte k-rows, 24 chunks): the XOR has to stay below 8 so that a chunk stays inside its aligned group
+    // of eight; consecutive k-rows start 128 bytes apart modulo the 256-byte bank row, so k and k + 2 collide and the
+    // swizzle separates them by bits 1 and 3 of k as in the 64-row case, plus bit 0 for the half-row pairs
+    if (R % 128 != 0 && R >= 128) return (k & 1) | (((k >> 1) & 1) << 1) | (((k >> 3) & 1) << 2);
     return R >= 128 ? 2 * ((k & 3) | (((k >> 3) & 1) << 2)) : 2 * (((k >> 1) & 1) | (((k >> 3) & 1) << 1));
 }
 
@@ -1251,7 +1265,8 @@ template <int BM, int BN, int W = 4> int launch_grouped_tile(GroupArgs& ga, hipS
     // 128 x 64: 36.5 | 37.2 | 35.2 | 46.6 us (four stages = one workgroup per CU), 64 x 64: 15.3 | 17.9 | 14.6 | 15.4,
     // 128 x 128 on 8 waves: 18.1 | 20.6 | 17.4 | 17.5.  Three everywhere except the 4-wave 128 x 128 tile (3 x 64 KB
     // would leave one workgroup per CU where two fit).
-    ga.stages = g_glds_stages ? g_glds_stages : (BM * BN == 128 * 128 && W == 4) ? 2 : 3;
+    // four-wave tiles whose three stages would leave ONE workgroup per CU take two (128 x 128: 2 x 64 KB; 192 x 128: 2 x 80 KB)
+    ga.stages = g_glds_stages ? g_glds_stages : (W == 4 && 2 * 3 * sizeof(bf16) * (BM + BN) * 64 > 160 * 1024) ? 2 : 3;
     while (ga.stages > 2 && ga.stages * sizeof(bf16) * (BM + BN) * 64 > 160 * 1024) --ga.stages;
     // LDS of the largest operand images this group actually uses (r-major images carry padding)
     size_t lds = 0;
@@ -1603,8 +1618,10 @@ template <typename T> int grouped(const xggm_gemm_problem* probs, int n, hipStre
         }
         if (kmaj && t128 > 200 && t128 <= 256 && nkmin >= 12 && !g_no_8w) v = 4;
     }
-    if (v == 5) return launch_grouped_tile<128, 256, 8>(ga, stream);
-    if (v == 6) return launch_grouped_tile<256, 128, 8>(ga, stream);
+    // (measured and not kept, round 3: 128 x 256 and 256 x 128 on eight waves -- slower on every launch of the step;
+    // 192 x 128 on four waves of 96 x 64, the vendor library's tile for the FFN1 shape -- 2 us faster on the FFN1
+    // forward pair in isolation, never the fastest inside the step, 91 spilled registers.  The epilogues above stay
+    // general in the tile shape: whole 64-row blocks, 32-row column-sum blocks.)
     if (v == 4) return launch_grouped_tile<128, 128, 8>(ga, stream);
     if (v == 3) return launch_grouped_tile<128, 128>(ga, stream);
     if (v == 2) return launch_grouped_tile<128, 64>(ga, stream);

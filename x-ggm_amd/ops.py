@@ -302,12 +302,59 @@ def p_wgrad(dy, x, gw, accumulate, sqsum=None):
     return p
 
 
+# ---- measured tile choice -----------------------------------------------------------------------
+# The library picks the tile of a grouped launch from a fitted cost model (gemm.hip: pick_group_tile).  Where a
+# measurement on the hardware disagrees, the measurement wins: ``gemm_tiles_gfx950.json`` (written by tools/tune_gemm.py
+# from in-step timings of every distinct launch of the training iteration under every tile) maps a launch SIGNATURE --
+# shapes and operand layouts of its problems -- to the tile that was fastest; unknown signatures keep the model's choice.
+# The tile changes speed only: every tile walks k in the same order and the partial-sum granules (32-row column sums,
+# 64 x 64 norm slots) do not depend on it, so results are bit-identical whatever the table says (tests).
+def _load_tile_table():
+    import json
+    import os
+    path = os.environ.get("XGGM_TILE_TABLE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tiles_gfx950.json")
+    if os.environ.get("XGGM_TILE_TABLE") == "0" or not os.path.exists(path):
+        return {}
+    try:
+        return {k: int(v) for k, v in json.load(open(path)).get("tiles", {}).items()}
+    except (ValueError, OSError):
+        return {}
+
+
+TILE_TABLE = _load_tile_table()
+TILE_HOOK = None  # tools/tune_gemm.py: callable(dt, chunk, signature) -> tile pin (or None) run in front of every launch
+
+
+def gemm_signature(dt, chunk):
+    """what the tile choice of a grouped launch may depend on: per problem M x N x K (x batch), which operands have
+    the reduction index contiguous, fp32 output, the epilogue's extras"""
+    parts = []
+    for p in chunk:
+        ext = ("f" if p.c_f32 else "") + ("a" if p.accumulate else "") + ("r" if p.residual else "") + \
+              ("g" if p.act == ACT_GELU_GRAD else ("G" if p.act == ACT_GELU else "")) + ("c" if p.colsum else "")
+        parts.append("%dx%dx%d%s:%d%d%s" % (p.M, p.N, p.K, ("b%d" % p.batch) if p.batch != 1 else "", int(p.a_ks == 1),
+                                            int(p.b_ks == 1), ext))
+    return sfx(dt) + "|" + "+".join(parts)
+
+
 def gemm_group(dt, problems):
     """launch up to 4 independent products in one grid (more: consecutive groups of 4)."""
     for i in range(0, len(problems), 4):
         chunk = problems[i:i + 4]
         arr = (GemmProblem * len(chunk))(*chunk)
-        call("xggm_gemm_grouped_" + sfx(dt), _ct.cast(arr, _ct.c_void_p), len(chunk), stream())
+        pin = 0
+        if TILE_TABLE or TILE_HOOK is not None:
+            sig = gemm_signature(dt, chunk)
+            pin = TILE_TABLE.get(sig, 0)
+            if TILE_HOOK is not None:
+                pin = TILE_HOOK(dt, chunk, sig, arr) or pin
+        if pin:
+            _lib.lib.xggm_gemm_set_group_tile(pin)
+        try:
+            call("xggm_gemm_grouped_" + sfx(dt), _ct.cast(arr, _ct.c_void_p), len(chunk), stream())
+        finally:
+            if pin:
+                _lib.lib.xggm_gemm_set_group_tile(0)
         reduce_batch([p.post for p in chunk if getattr(p, "post", None) is not None])  # column sums nobody deferred
 
 
