@@ -1309,3 +1309,59 @@ def test_reductions_are_reproducible_bit_for_bit(ops, dt):
         again = once(k)
         for i, (a, b) in enumerate(zip(first, again)):
             assert torch.equal(a, b), (i, k, float((a.float() - b.float()).abs().max()))
+
+
+def test_tile_choice_changes_speed_only(ops):
+    """ops.gemm_group pins the tile of a launch from the measured table (gemm_tiles_gfx950.json).  Every tile walks k
+    in the same order and the column sums are taken per 32 output rows whatever the tile, so the heaviest launch of the
+    step -- FFN2 backward: dgrad * gelu'(u) + column sums, weight gradient -- gives the SAME BITS under every tile; the
+    64 x 64 norm slots are the same numbers summed in a tile-dependent (but fixed) order: equal to fp32 rounding.  The
+    table is part of the configuration: one table, one set of bits.  And the table really steers the launch."""
+    from xggm_amd import _lib
+    dt = torch.bfloat16
+    M, H, I = 640, 768, 3072
+    d_h, _ = rnd((M, H), dt, 1)
+    w2, _ = rnd((H, I), dt, 2, 0.05)
+    u, _ = rnd((M, I), dt, 3)
+    act, _ = rnd((M, I), dt, 4)
+
+    def run(pin):
+        _lib.lib.xggm_gemm_set_group_tile(pin)
+        try:
+            cs = torch.zeros(I, device=DEV)
+            gw = torch.empty(H, I, device=DEV)
+            sq = torch.zeros((H // 64) * (I // 64), device=DEV)
+            pd, dx = ops.p_dgrad(d_h, w2, gelu_aux=u, colsum=cs)
+            pw = ops.p_wgrad(d_h, act, gw, False, sqsum=sq)
+            saved, ops.TILE_TABLE = ops.TILE_TABLE, {}  # the explicit pin, not the table, chooses here
+            try:
+                ops.gemm_group(dt, [pw, pd])
+            finally:
+                ops.TILE_TABLE = saved
+            torch.cuda.synchronize()
+            return dx, cs, gw, sq
+        finally:
+            _lib.lib.xggm_gemm_set_group_tile(0)
+
+    ref = run(1)
+    for pin in (0, 2, 3, 4):
+        got = run(pin)
+        for a, b in zip(ref[:3], got[:3]):  # dx, column sums, weight gradient
+            assert torch.equal(a, b), pin
+        assert torch.allclose(ref[3], got[3], rtol=2e-6, atol=0), pin  # 4096 fp32 squares per slot, another order
+        assert torch.equal(got[3], run(pin)[3]), pin                   # ... and the same order every time
+    # the table: a signature that is in it reaches the library as a pin (seen through the hook), others do not
+    sig_seen = []
+    saved_t, saved_h = ops.TILE_TABLE, ops.TILE_HOOK
+    try:
+        cs = torch.zeros(I, device=DEV)
+        pd, _ = ops.p_dgrad(d_h, w2, gelu_aux=u, colsum=cs)
+        pw = ops.p_wgrad(d_h, act, torch.empty(H, I, device=DEV), False)
+        sig = ops.gemm_signature(dt, [pw, pd])
+        assert sig == "bf16|768x3072x640:00f+640x3072x768:10gc"
+        ops.TILE_TABLE = {sig: 1}
+        ops.TILE_HOOK = lambda dt_, chunk, s, arr: sig_seen.append((s, ops.TILE_TABLE.get(s, 0))) or 0
+        ops.gemm_group(dt, [pw, pd])
+        assert sig_seen == [(sig, 1)]
+    finally:
+        ops.TILE_TABLE, ops.TILE_HOOK = saved_t, saved_h

@@ -307,8 +307,10 @@ def p_wgrad(dy, x, gw, accumulate, sqsum=None):
 # measurement on the hardware disagrees, the measurement wins: ``gemm_tiles_gfx950.json`` (written by tools/tune_gemm.py
 # from in-step timings of every distinct launch of the training iteration under every tile) maps a launch SIGNATURE --
 # shapes and operand layouts of its problems -- to the tile that was fastest; unknown signatures keep the model's choice.
-# The tile changes speed only: every tile walks k in the same order and the partial-sum granules (32-row column sums,
-# 64 x 64 norm slots) do not depend on it, so results are bit-identical whatever the table says (tests).
+# The tile changes speed, not values: every tile walks k in the same order and the column sums are taken per 32 output
+# rows whatever the tile, so products, gradients and bias gradients are bit-identical under every tile (tests); only the
+# 64 x 64 norm slots add their squares in a tile-dependent -- fixed -- order, i.e. the clip norm can differ in its last
+# bit between two TABLES.  The table is part of the configuration: one table, one set of bits.
 def _load_tile_table():
     import json
     import os
