@@ -14,13 +14,18 @@ stats() {  # name, bench flags
     rm -f "$OUT/$name"/*/*kernel_trace.csv
     echo "$name: $(tail -1 "$OUT/$name.json" | cut -c1-40) ... $(tail -1 "$OUT/$name.json" | grep -o '"ms_per_step": [0-9.]*')"
 }
-python "$R/bench.py" > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.log"
-echo "plain: $(grep -o '"ms_per_step": [0-9.]*' "$OUT/bench_plain.json" | head -1)"
-stats bench
-stats bench_fp8 --dtype fp8 --no-cpu-baseline
+if [ -z "$PMC_ONLY" ]; then python "$R/bench.py" > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.log"; fi
+[ -n "$PMC_ONLY" ] || echo "plain: $(grep -o '"ms_per_step": [0-9.]*' "$OUT/bench_plain.json" | head -1)"
+# (--no-ref-batch: the leg at the reference's batch of 92 / 96 runs the same kernels on three times the rows and would
+# mix into the per-kernel averages; the un-profiled line above carries it)
+if [ -z "$PMC_ONLY" ]; then
+stats bench --no-ref-batch
+stats bench_fp8 --dtype fp8 --no-cpu-baseline --no-ref-batch
 stats bench_c4 --workload c4 --no-cpu-baseline
-stats bench_gqa --order gqa --no-cpu-baseline
-EAGER="--steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-kernel-timing --no-loader"
+stats bench_gqa --order gqa --no-cpu-baseline --no-ref-batch
+fi
+if [ -n "$STATS_ONLY" ]; then echo done; exit 0; fi
+EAGER="--steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-kernel-timing --no-loader --no-ref-batch"
 for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_$c" -- python "$R/bench.py" $EAGER > "$OUT/pmc_$c.log" 2>&1
     cp "$(ls "$OUT/pmc_$c"/*/*counter_collection.csv | head -1)" "$OUT/pmc_$c.csv"
