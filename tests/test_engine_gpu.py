@@ -484,6 +484,9 @@ def test_no_framework_kernel_inside_a_training_pass():
     and the node-generation pass of a small model run eagerly under torch.profiler -- no aten op may launch a kernel
     (at::native fills, adds, copies: F.pad of odd-width logit gradients, autograd's sums where a tensor feeds several
     consumers, select backward of the pooler, zero 'gradients' of non-differentiable outputs all used to)."""
+    import os
+    if os.environ.get("XGGM_POISON_EMPTY"):
+        pytest.skip("the poisoned torch.empty of conftest.py fills every buffer with a framework kernel")
     from torch.profiler import ProfilerActivity, profile
     from xggm_amd.engine import CapturedTrainer
     B, A = 4, 29

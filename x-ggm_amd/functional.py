@@ -96,19 +96,37 @@ class Runtime:
     def flush(self):
         self._task = -1
         jobs, self.pending = self.pending, []
-        while jobs:
-            # one writer per gradient vector and launch: a second job on the same targets (the shared
-            # cross-attention module is applied twice per layer) waits for the next launch
-            seen, now, later = set(), [], []
-            for j in jobs:
-                key = tuple(t.data_ptr() for t in j[4] if t is not None)
-                if seen.isdisjoint(key):
-                    seen.update(key)
-                    now.append(j)
-                else:
-                    later.append(j)
-            ops.reduce_batch(now)
-            jobs = later
+        # One writer per gradient vector and launch: a second job on the same targets (the shared cross-attention
+        # module is applied twice per layer) has to run in a LATER launch than the first.  A launch takes
+        # ops.REDUCE_JOBS_PER_LAUNCH jobs; a pass leaves ~90, i.e. two launches anyway -- so the first launch takes the
+        # first writers of every shared target (and fills up with others), the second the rest together with the second
+        # writers: two launches per pass instead of three.
+        rounds = []  # rounds[k] = jobs that are the (k+1)-th writer of some target
+        count = {}
+        for j in jobs:
+            key = [t.data_ptr() for t in j[4] if t is not None]
+            k = max([count.get(p, 0) for p in key], default=0)
+            for p in key:
+                count[p] = k + 1
+            while len(rounds) <= k:
+                rounds.append([])
+            rounds[k].append(j)
+        if not rounds:
+            return
+        shared = {p for p, c in count.items() if c > 1}
+        first = sorted(rounds[0], key=lambda j: 0 if any(t is not None and t.data_ptr() in shared for t in j[4]) else 1)
+        cap = ops.REDUCE_JOBS_PER_LAUNCH
+        n_first = max(sum(1 for j in first if any(t is not None and t.data_ptr() in shared for t in j[4])), min(len(first), cap))
+        n_first = min(n_first, len(first)) if len(first) <= cap else max(n_first, cap)
+        launches = [first[:n_first]]
+        rest = first[n_first:]
+        for k in range(1, len(rounds)):
+            launches.append(rest + rounds[k])
+            rest = []
+        if rest:
+            launches.append(rest)
+        for batch in launches:
+            ops.reduce_batch(batch)
 
     def p(self, p):
         return p if self.training else 0.0

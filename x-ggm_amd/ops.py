@@ -651,6 +651,9 @@ class ReduceJob(_ct.Structure):
                 ("target", _ct.c_void_p * 3)]
 
 
+REDUCE_JOBS_PER_LAUNCH = 72  # MAX_JOBS of rowops.hip: jobs one launch of xggm_partial_reduce_batch takes
+
+
 def reduce_batch(jobs):
     """second stage of the two-stage parameter-gradient sums: ``jobs`` = [(ws, nblk, K, H, targets)] with ``ws`` fp32
     [nblk][K][H] partial rows and ``targets`` a tuple of K fp32 [H] gradient vectors (None = not wanted):
