@@ -20,5 +20,5 @@ GROUPS = {
 
 if __name__ == "__main__":
     for name, shapes in GROUPS.items():
-        for code, tn in ((0, "auto"), (2, "128x64"), (3, "128x128"), (4, "128x128/8w")):
+        for code, tn in ((0, "auto"), (1, "64x64"), (2, "128x64"), (3, "128x128"), (4, "128x128/8w")):
             run(code, shapes, "%-18s %-7s" % (name, tn))

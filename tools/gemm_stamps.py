@@ -46,6 +46,15 @@ def run(tile_code, forms_shapes, label):
         for _, dlt in ev:
             live += dlt
             maxc = max(maxc, live)
+    # k-loop and whole-tile cycles by how many workgroups shared the tile's CU during the launch
+    cnt = {c: int((cu == c).sum()) for c in set(cu.tolist())}
+    share = torch.tensor([cnt[c] for c in cu.tolist()])
+    for n in sorted(set(share.tolist())):
+        sel = s[share == n]
+        per_cu = [(s[cu == c][:, 4].max() - s[cu == c][:, 0].min()).item() for c in cnt if cnt[c] == n]
+        print("   CUs holding %d tile(s): %4d tiles, k-loop %7.0f, entry->exit %7.0f per tile, first entry -> last exit on the CU %7.0f"
+              % (n, sel.shape[0], (sel[:, 2] - sel[:, 1]).mean().item(), (sel[:, 4] - sel[:, 0]).mean().item(),
+                 sum(per_cu) / len(per_cu)), flush=True)
     # the cycle counters of the eight XCDs are not synchronised: first entry -> last exit per XCD
     spans = [(s[xcc == x][:, 4].max() - s[xcc == x][:, 0].min()).item() for x in sorted(set(xcc.tolist()))]
     late = [(s[xcc == x][:, 0].max() - s[xcc == x][:, 0].min()).item() for x in sorted(set(xcc.tolist()))]

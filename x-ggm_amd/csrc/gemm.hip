@@ -86,7 +86,27 @@ int g_ablate = 0;
             q[6] = xcc;                                                                               \
         }                                                                                             \
     } while (0)
+// fine timeline of the workgroup's first wave (tools/gemm_trace.py): slot -> cycle counter, kept in LDS and copied to
+// stamp[XGGM_TRACE_BASE + 128 * workgroup ...] at the end of the tile.  s_memtime returns through lgkmcnt: every TRACE
+// point drains the wave's outstanding LDS reads first, so points sit where the wave would have waited anyway.
+#define XGGM_TRACE_BASE (8 * 8192)
+__shared__ long long xg_trace[128];
+#define TRACE(g, slot)                                                                                \
+    do {                                                                                              \
+        if (((g).ablate & 0x10000) && threadIdx.x == 0 && (slot) < 128) xg_trace[(slot)] = __builtin_readcyclecounter(); \
+    } while (0)
+#define TRACE_FLUSH(g)                                                                                \
+    do {                                                                                              \
+        if (((g).ablate & 0x10000) && threadIdx.x < 64) {                                                          \
+            long long* q = (g).stamp + XGGM_TRACE_BASE +                                              \
+                           (int64_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 128; \
+            q[threadIdx.x] = xg_trace[threadIdx.x];                                                   \
+            q[threadIdx.x + 64] = xg_trace[threadIdx.x + 64];                                         \
+        }                                                                                             \
+    } while (0)
 #else
+#define TRACE(g, slot)
+#define TRACE_FLUSH(g)
 #define STAMP_HW(g)
 #define ABLATE(g, bit) false
 #define KABLATE(g, bit) false
@@ -705,6 +725,10 @@ __device__ __forceinline__ void epilogue_direct(const GemmArgs& g, const float4_
     const Q8 qs(KIND == 1 && g.c8 ? g.c8_qscale : nullptr);
     const float q8 = qs.q, alpha = g.alpha;
     float amax8 = 0.f, sq = 0.f;
+#ifdef XGGM_STAMP
+    if (g.ablate & 0x10000) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trace: when the bias has arrived
+#endif
+    TRACE(g, 1);
     const int off0 = row0 * g.ldc + col0;  // 32-bit offsets from the (batch) base: epilogue_kind checked the range
     float* cf = reinterpret_cast<float*>(g.C) + coff;
     bf16* cb = reinterpret_cast<bf16*>(g.C) + coff;
@@ -712,6 +736,7 @@ __device__ __forceinline__ void epilogue_direct(const GemmArgs& g, const float4_
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         if (i == 1) STAMP(g, 3);
+        TRACE(g, 2 + i);
         if (row0 + i * 16 >= g.M) continue;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -1020,22 +1045,41 @@ __device__ __forceinline__ void gemm_kloop_glds(const GemmArgs& g, int tile_m, i
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) issue(s, s);
     STAMP(g, 1);
+    TRACE(g, 15);
     int stage = 0;
     for (int t = 0; t < nk; ++t) {
         // tile t has landed once at most the (NS - 2) younger tiles are still in flight
+        TRACE(g, 16 + 4 * t);
         if (NS == 2 || t + NS - 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * G) : "memory");
-        lds_barrier();  // every wave's part of tile t is visible; stage (t - 1) % NS has been read by everyone
-        if (t + NS - 1 < nk) issue(t + NS - 1, stage == 0 ? NS - 1 : stage - 1);
+        TRACE(g, 17 + 4 * t);
+        if (!KABLATE(g, 128)) lds_barrier();  // every wave's part of tile t is visible; stage (t - 1) % NS has been read by everyone
+        TRACE(g, 18 + 4 * t);
+        if (t + NS - 1 < nk && !KABLATE(g, 8)) issue(t + NS - 1, stage == 0 ? NS - 1 : stage - 1);
+        TRACE(g, 19 + 4 * t);
         const bf16* Ac = fsm + stage * STAGE;
         const bf16* Bc = Ac + AEL;
 #pragma unroll
         for (int ks = 0; ks < 64; ks += 32) {
             bf16x8_t a[TM], b[TN];
+            if (KABLATE(g, 256)) {  // no fragment reads at all: the matrix pipe on whatever the registers hold
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = glds_frag<BM, AK>(Ac, wm + i * 16, ks, lane);
+                for (int i = 0; i < TM; ++i) a[i] = __builtin_bit_cast(bf16x8_t, acc[i][0]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = glds_frag<BN, BKM>(Bc, wn + j * 16, ks, lane);
+                for (int j = 0; j < TN; ++j) b[j] = __builtin_bit_cast(bf16x8_t, acc[0][j]);
+            } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = glds_frag<BM, AK>(KABLATE(g, 64) ? fsm : Ac, KABLATE(g, 64) ? 0 : wm + i * 16, ks, lane);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = glds_frag<BN, BKM>(KABLATE(g, 64) ? fsm : Bc, KABLATE(g, 64) ? 0 : wn + j * 16, ks, lane);
+            }
+            if (KABLATE(g, 32)) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][0][0] += __builtin_bit_cast(float4_t, a[i])[0];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[0][j][1] += __builtin_bit_cast(float4_t, b[j])[0];
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1051,8 +1095,10 @@ __device__ __forceinline__ void gemm_kloop_glds(const GemmArgs& g, int tile_m, i
         }
         stage = stage + 1 == NS ? 0 : stage + 1;
     }
+    TRACE(g, 14);
     lds_barrier();  // every wave is done with the last stage: LDS is free for the epilogue
     STAMP(g, 2);
+    TRACE(g, 0);
 }
 
 // K a whole number of k-tiles (no partial chunk to zero on the way, no tile to skip), r-major rows readable in
@@ -1085,6 +1131,12 @@ __device__ __forceinline__ void gemm_finish(const GemmArgs& g, int tile_m, int t
     else if (kind == 1) epilogue_direct<BM, BN, TM, TN, W, 1>(g, acc, m0, n0, bz, reinterpret_cast<float*>(fsm), wm, wn);
     else epilogue_staged<BM, BN, TM, TN, W>(g, acc, m0, n0, bz, reinterpret_cast<float*>(fsm), wm, wn);
     STAMP(g, 4);
+    TRACE(g, 12);
+#ifdef XGGM_STAMP
+    if (g.ablate & 0x10000) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trace: when the tile's stores have been acknowledged
+#endif
+    TRACE(g, 13);
+    TRACE_FLUSH(g);
 }
 
 template <int BM, int BN, bool AK, bool BKM, int D>
@@ -1312,13 +1364,15 @@ __global__ __launch_bounds__(64 * W, (W == 8 ? 2 : min_waves<BM, BN>())) void ge
     }
     constexpr int DK = (BM * BN <= 64 * 64) ? 4 : 2;
     float4_t acc[BM / (8 * W)][BN / 32];
+    // the dequantisation factor is fetched before the k-loop, not in front of the epilogue
+    const float deq = (g.scale_a ? *g.scale_a : 1.f) * (g.scale_b ? *g.scale_b : 1.f);
     if (glds_ok<true>(g)) {  // K a whole number of 128-element k-tiles: the LDS-DMA k-loop (same bytes per k-tile as bf16)
         if (ga.stages == 3) gemm_kloop_glds<BM, BN, true, true, true, W, 3>(g, tile_m, tile_n, bz, fsm, acc);
         else gemm_kloop_glds<BM, BN, true, true, true, W, 2>(g, tile_m, tile_n, bz, fsm, acc);
     } else {
         gemm_kloop<BM, BN, true, true, DK, true, W>(g, tile_m, tile_n, bz, fsm, acc);
     }
-    g.alpha *= (g.scale_a ? *g.scale_a : 1.f) * (g.scale_b ? *g.scale_b : 1.f);
+    g.alpha *= deq;
     gemm_finish<BM, BN, W>(g, tile_m, tile_n, bz, fsm, acc);
 }
 
