@@ -64,7 +64,8 @@ def parse(argv=None):
     p.add_argument("--no-ref-batch", action="store_true", help="skip the leg at the reference's own training batch size")
     p.add_argument("--wire", default="bf16", choices=["bf16", "f32"], help="gradient all-reduce dtype")
     p.add_argument("--zero1", type=int, default=None, help="1: shard the update over the ranks (reduce-scatter -> "
-                   "BertAdam on the shard -> all-gather of the weights); default: off (see DESIGN.md section 6)")
+                   "BertAdam on the shard -> all-gather of the weights, stage by stage beside the next forward); "
+                   "default: on from 4 ranks, off below (see DESIGN.md section 6)")
     p.add_argument("--seed", type=int, default=9595)
     a = p.parse_args(argv)
     if a.answers is None:
@@ -115,6 +116,11 @@ def spawn_ranks(args):
 
 
 # ------------------------------------------------------------------------------------------ model / data
+def zero1_default(world):
+    """sharded update (ZeRO-1) unless --zero1 says otherwise: from 4 ranks (see the comment in ``main``)"""
+    return world >= 4
+
+
 def build(args, device):
     from xggm_amd import param, synth
     from xggm_amd.lxrt.modeling import BertConfig, VISUAL_CONFIG
@@ -546,10 +552,12 @@ def main():
     zero1 = False
     if world > 1 or force_dp:
         from xggm_amd.vqa.vqacpv2 import enable_data_parallel
-        # The sharded update trades 7/8 of the update's HBM traffic (0.75 ms per pass at 8 ranks) for an all-gather of
-        # the bf16 matrix weights (388 MB) that nothing overlaps yet: it pays only above ~450 GB/s of gather rate per GPU.
-        # Opt-in until that is measured on an 8-GPU node.
-        zero1 = bool(args.zero1) if args.zero1 is not None else False
+        # The sharded update trades (world - 1) / world of the update's HBM traffic (1.0 of 1.17 ms per pass at 8 ranks) for
+        # an all-gather of the bf16 matrix weights (388 MB) -- the same bytes on the links as the all-reduce it replaces,
+        # split into a reduce-scatter under the backward stages and a gather that now runs stage by stage under the NEXT
+        # pass's forward graphs (engine.CapturedTrainer).  At 2 ranks half of the update is too little to pay for the two
+        # extra graph boundaries and the norm's scalar exchange (+0.45 ms per iteration measured at one rank): on from 4.
+        zero1 = bool(args.zero1) if args.zero1 is not None else zero1_default(world)
         enable_data_parallel(model, wire_dtype=torch.bfloat16 if args.wire == "bf16" else None, zero1=zero1)
     loader_parts = None
     if not args.no_loader:

@@ -187,6 +187,12 @@ def _sharded_worker(rank, world, port, q):
         z.finish(h0)
         z.finish(h1)
         ok &= z.runs == [(0, 512), (512, 1024), (1280, 1792)]
+        # ... and per exchange call (= per backward stage): the staged all-gather walks these batches in REVERSE (the last
+        # backward stage holds the lowest layers, which the next forward reads first; ShardedUpdate.gather_begin)
+        ok &= z.batches == [[(0, 512)], [(512, 1024), (1280, 1792)]] and z.pending == []
+        z.begin([])  # a stage without gradients keeps its place
+        ok &= len(z.batches) == 3 and z.batches[2] == []
+        z.batches.pop()
         for run in z.runs:
             o0, o1 = z.own(run)
             ok &= (o1 - o0) * world == run[1] - run[0] and o0 == run[0] + rank * (o1 - o0)
@@ -240,6 +246,18 @@ def _sharded_worker(rank, world, port, q):
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
+
+
+def test_sharded_update_is_the_default_from_four_ranks():
+    """with the all-gather hidden under the next forward's stages the sharded update is what
+    ``bench.py --gpus N`` runs for N >= 4 (``--zero1 0 / 1`` overrides either way)"""
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    assert [bench.zero1_default(w) for w in (1, 2, 4, 8)] == [False, False, True, True]
+    assert bench.parse(["--zero1", "0"]).zero1 == 0 and bench.parse([]).zero1 is None
 
 
 def test_sharded_update_bookkeeping_world2():

@@ -1,7 +1,11 @@
 """Rehearsal of the data-parallel engine paths on ONE GPU: world size 2 over gloo, both ranks on cuda:0, a tiny
 model, DIFFERENT batches per rank.  Checks (a) replicas stay identical (the exchange really happens), (b) the
 overlapped three-graph path gives the same parameters as the plain two-graph path.
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 tools/dp_rehearsal.py"""
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 tools/dp_rehearsal.py
+XGGM_GATHER_DELAY_US=3000 holds every batch of the sharded update's staged all-gather back by 3 ms: the checks must still
+pass (the forward graphs wait for their batch).  XGGM_REHEARSE_NOWAIT=1 on top removes those waits -- a negative control
+for a box with a truly asynchronous backend (nccl, one rank per GPU): over gloo the host blocks inside every collective,
+the gather has always finished before the next graph is launched, and the control passes too (seen on the one-GPU box)."""
 import os
 import sys
 
@@ -39,6 +43,8 @@ def run(overlap, rank, use_graph=True, iters=("rel", "node", "rel"), layers=(2, 
             norms.append(float(out[2]))  # the clip norm of the pass
     torch.cuda.synchronize()
     run.norms = norms
+    g = tr.graphs.get("rel") if use_graph else None
+    run.n_fwd = g[5] if g is not None and g[0] == "staged" else 0  # forward graphs in front of the backward (sharded update)
     run.names = [(n, p.numel()) for n, p in m.named_parameters()]
     arena = m.arena()
     if want == "shadow":  # what the GEMMs read: must be identical on every rank after the all-gather
@@ -71,6 +77,11 @@ def main():
     rank = int(os.environ["RANK"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo")
+    if os.environ.get("XGGM_REHEARSE_NOWAIT"):
+        # negative control for the staged all-gather (run with XGGM_GATHER_DELAY_US=3000): the engine gets no events to wait
+        # for; with an asynchronous backend the forward graphs then read the weights of the previous step (docstring)
+        from xggm_amd.dist import ShardedUpdate
+        ShardedUpdate.take_pending = lambda self: []
     report(run(False, rank, use_graph=False, iters=("rel",)), rank, "eager, 1 iteration")
     for layers in ((2, 2, 1), (5, 4, 4)):  # two cuts (three backward stages) / four cuts (five stages)
         check(rank, layers)
@@ -105,9 +116,11 @@ def check_sharded(rank):
         dist.all_gather(other, sh)
         same = bool(torch.equal(other[0], other[1]))
         if rank == 0:
-            print("sharded update overlap=%s graphs=%s: bf16 weights identical on both ranks: %s" % (overlap, use_graph, same),
-                  flush=True)
+            print("sharded update overlap=%s graphs=%s: bf16 weights identical on both ranks: %s (forward cut into %d + 1 graphs)"
+                  % (overlap, use_graph, same, run.n_fwd), flush=True)
         assert same
+        # with the staged exchange the forward is cut too: the all-gather of stage i + 1 runs beside forward graph i
+        assert run.n_fwd == (4 if overlap and use_graph else 0), run.n_fwd
     # The sharded and the replicated update differ in ONE thing: the order the clip norm is summed in (slices' partial
     # norms, all-reduced, against one fixed-order sum over the buffer).  Everything else is element-wise on the same
     # averaged gradients.  So (a) with a clip that does not bind (coefficient exactly 1 in both) three iterations must

@@ -197,6 +197,8 @@ class ParamArena:
         brings the other ranks' slices over.  Collective when it has something to do (every rank must get here); a
         no-op without the sharded update or when nothing has been updated since the last gather."""
         z = self.zero1
+        if z is not None:
+            z.wait_pending()  # all-gathers of the bf16 weights still running beside a forward (gather_begin)
         if z is not None and z.stale:
             z.gather_state()
 

@@ -16,6 +16,8 @@ backend too, which is how the logic is tested without GPUs (tests/test_dist_cpu.
 Ranks must take the same host-side branch (relation vs node generation,
 src/vqa/vqacpv2.py:192): ``sync_branch`` broadcasts rank 0's draw.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -322,12 +324,15 @@ class ShardedUpdate(GradSync):
         if any(256 % w for w in (self.world,)) and self.world > 1:
             raise RuntimeError("sharded update: world size %d must divide 256" % self.world)
         self.runs = []  # matrix runs (start, end) exchanged in this pass, in exchange order
+        self.batches = []  # the same runs per exchange call (= per backward stage, stage 0 first): gather_begin
+        self.pending = []  # events of all-gathers that are still running beside the next forward (gather_begin)
         self.all_runs = set()  # every run any pass has exchanged (gather_state)
         self.stale = False  # a sharded update has run since the last gather_state: the other ranks' slices of the
         # fp32 masters / moments on THIS rank are out of date (only the bf16 shadow is gathered after an update)
 
     def reset(self):
         self.runs = []
+        self.batches = []
 
     def split(self, ranges):
         """ranges -> (matrix runs, vector runs): cut at the groups' matrix / vector borders"""
@@ -357,6 +362,7 @@ class ShardedUpdate(GradSync):
         op = dist.ReduceOp.SUM  # the average is taken by the norm pass and the update (arena.grad_scale)
         tab = self._begin_table() if sparse else None
         mats, vecs = self.split(dense)
+        self.batches.append(list(mats))
         works = []
         for run in mats:
             self.runs.append(run)
@@ -372,11 +378,13 @@ class ShardedUpdate(GradSync):
 
     def begin(self, ranges, slot=0):
         if not ranges:
+            self.batches.append([])  # a stage without gradients still counts: batches[k] belongs to backward stage k
             return None
         if self.world == 1 and not self.force:
             self.cast_vectors(ranges)
             mats = self.split(ranges)[0]
             self.runs += mats
+            self.batches.append(list(mats))
             self.all_runs.update(mats)
             return None
         return self._begin_inplace(ranges)
@@ -399,18 +407,14 @@ class ShardedUpdate(GradSync):
                 # scale table, once per pass, in front of the update that derives the new scales from it
                 dist.all_reduce(f8.weight_amax(), op=dist.ReduceOp.MAX, group=self.group)
 
-    def gather(self):
-        """all-gather the bf16 shadow weights of this pass's matrix runs from their owners"""
-        self.stale = True
-        if self.world == 1 and not self.force:
-            return
+    def _gather_runs(self, runs):
+        """queue the all-gathers of ``runs`` (bf16 shadow and, with the fp8 forward, the e4m3 copies the owners wrote in
+        the same update) on the current stream's side of the communicator; returns the work handles"""
         f8 = getattr(self.arena, "fp8", None)
-        # what the products read: the bf16 shadow (backward, and forward without fp8) and, with the fp8 forward, the
-        # e4m3 copies the owners wrote in the same update
         bufs = [self.arena.shadow] + ([f8.shadow8] if f8 is not None else [])
         works = []
         for sh in bufs:
-            for run in self.runs:
+            for run in runs:
                 a, b = run
                 o0, o1 = self.own(run)
                 if self.backend == "nccl":
@@ -419,8 +423,49 @@ class ShardedUpdate(GradSync):
                     c = (b - a) // self.world
                     works.append(dist.all_gather([sh[a + i * c:a + (i + 1) * c] for i in range(self.world)], sh[o0:o1].clone(),
                                                  group=self.group, async_op=True))
-        for wk in works:
+        return works
+
+    def gather(self):
+        """all-gather the bf16 shadow weights of this pass's matrix runs from their owners"""
+        self.stale = True
+        if self.world == 1 and not self.force:
+            return
+        for wk in self._gather_runs(self.runs):
             wk.wait()
+
+    def gather_begin(self, comm):
+        """The same gather, stage by stage in the order the NEXT forward reads the weights, on the stream ``comm``: the
+        runs of the LAST backward stage (the lowest layers) first.  Leaves one event per batch in ``pending`` (forward
+        order: pending[i] covers what forward stage i reads); the consumer makes its stream wait for pending[i] right
+        before stage i (engine.CapturedTrainer replays one forward graph per stage), so the gather of stage i + 1 runs
+        under the forward of stage i.  Anything else that reads the shadow weights calls ``wait_pending`` first
+        (runtime.runtime_of does, for every eager forward)."""
+        self.stale = True
+        self.pending = []
+        if self.world == 1 and not self.force:
+            return
+        comm.wait_stream(torch.cuda.current_stream())  # the update that wrote the own slices
+        # test hook (tools/dp_rehearsal.py): hold every batch back by so many microseconds -- a consumer that does not
+        # wait for its batch then reads the weights of the previous step and the rehearsal's bit-exactness checks fail
+        delay = float(os.environ.get("XGGM_GATHER_DELAY_US", "0"))
+        with torch.cuda.stream(comm):
+            for runs in reversed(self.batches):
+                if delay > 0:
+                    torch.cuda._sleep(int(delay * 2000))  # ~2 GHz shader clock
+                for wk in self._gather_runs(runs):
+                    wk.wait()  # (stream-side: `comm` waits for the communicator's stream, the host does not block on nccl)
+                ev = torch.cuda.Event()
+                ev.record(comm)
+                self.pending.append(ev)
+
+    def take_pending(self):
+        ev, self.pending = self.pending, []
+        return ev
+
+    def wait_pending(self):
+        """the current stream waits for every all-gather ``gather_begin`` left running"""
+        for ev in self.take_pending():
+            torch.cuda.current_stream().wait_event(ev)
 
     @torch.no_grad()
     def gather_state(self):

@@ -12,6 +12,10 @@ With data parallelism each pass is captured as two graphs (forward+backward | cl
 and the gradient all-reduce runs between them on the live RCCL communicator; with the overlap
 option (default) the backward is cut below the cross-modality layers into a third graph, and the
 gradients above the cut are already on the wire while the lower backward graph replays.
+With the sharded update (ZeRO-1) on top of the overlap the FORWARD is cut at the same places: the
+all-gather of the bf16 weights that follows the update is queued stage by stage in forward order
+on the communication stream, forward graph i waits only for batch i, and the gather of stage
+i + 1 runs under the forward of stage i (dist.ShardedUpdate.gather_begin).
 """
 import gc
 
@@ -120,7 +124,7 @@ class CapturedTrainer:
         # replay issues it eagerly behind the gather (_replay_update) -- exactly once per trained pass
         return (g1, g2), total
 
-    def _replay_update(self, gus):
+    def _replay_update(self, gus, staged_gather=False):
         if len(gus) == 1:
             gus[0].replay()
             return
@@ -128,8 +132,17 @@ class CapturedTrainer:
         gus[0].replay()
         z.exchange_norm(self.rt.arena.sqnorm)
         gus[1].replay()
-        z.gather()
+        if staged_gather:
+            # the bf16 weights come back stage by stage beside the NEXT pass's forward graphs (run_pass waits per stage)
+            z.gather_begin(self._comm_stream())
+        else:
+            z.gather()
         self.rt.advance()
+
+    def _comm_stream(self):
+        if self._comm is None:
+            self._comm = torch.cuda.Stream()
+        return self._comm
 
     def _stage_ranges(self):
         from .dist import active_ranges, stage_ranges
@@ -204,12 +217,19 @@ class CapturedTrainer:
                 # one graph per backward stage: forward + stage 0 | stage 1 | ... | clip + update.  The capture is
                 # switched from one graph to the next inside Runtime.backward (the ``between`` callback).
                 graphs, early = [torch.cuda.CUDAGraph()], []
+                n_fwd = [0]  # forward cuts passed = forward graphs in front of the one that also holds backward stage 0
 
                 def switch(k):
                     graphs[-1].capture_end()
                     early.append(self._stage_ranges()[k])
                     graphs.append(torch.cuda.CUDAGraph())
                     graphs[-1].capture_begin(pool=graphs[0].pool(), capture_error_mode=self.capture_mode)
+
+                def fwd_switch(i):  # sharded update: one graph per forward stage (see the module docstring)
+                    graphs[-1].capture_end()
+                    graphs.append(torch.cuda.CUDAGraph())
+                    graphs[-1].capture_begin(pool=graphs[0].pool(), capture_error_mode=self.capture_mode)
+                    n_fwd[0] += 1
 
                 torch.cuda.synchronize()
                 gc.collect()
@@ -221,7 +241,11 @@ class CapturedTrainer:
                         graphs[0].capture_begin(capture_error_mode=self.capture_mode)
                     else:
                         graphs[0].capture_begin(pool=pool, capture_error_mode=self.capture_mode)
-                    loss, logit = self._fwd_bwd(kind, switch)
+                    self.rt.fwd_hook = fwd_switch if self.rt.arena.zero1 is not None else None
+                    try:
+                        loss, logit = self._fwd_bwd(kind, switch)
+                    finally:
+                        self.rt.fwd_hook = None
                     graphs[-1].capture_end()
                 torch.cuda.current_stream().wait_stream(cap)
                 pool = graphs[0].pool()
@@ -235,7 +259,7 @@ class CapturedTrainer:
                     for rs in early + [final]:
                         self.model._grad_sync.sync(rs)
                 gus, total = self._capture_update(pool)
-                self.graphs[kind] = ("staged", graphs, early, final, gus)
+                self.graphs[kind] = ("staged", graphs, early, final, gus, n_fwd[0])
                 self.outputs[kind] = (loss, logit, total)
         torch.cuda.synchronize()
 
@@ -272,12 +296,13 @@ class CapturedTrainer:
         else:
             # the exchange of stage k (cast to the wire type, all-reduce, copy back) is queued on a side stream
             # right behind graph k and runs under graph k + 1; the update waits for all of it
-            _, graphs, early, final, gus = gs
+            _, graphs, early, final, gus, n_fwd = gs
             sync = self.model._grad_sync
             main = torch.cuda.current_stream()
-            if self._comm is None:
-                self._comm = torch.cuda.Stream()
-            comm = self._comm
+            comm = self._comm_stream()
+            z = self.rt.arena.zero1
+            # all-gathers of the previous pass's update that are still running: pend[i] covers what forward graph i reads
+            pend = z.take_pending() if z is not None else []
 
             def exchange(k, after):
                 comm.wait_event(after)
@@ -290,16 +315,24 @@ class CapturedTrainer:
             # graph k + 1 is handed to the GPU BEFORE the host enqueues the (eager) exchange of stage k: those dozens
             # of small launches take the host longer than the GPU needs to get to the end of graph k
             prev = None
-            for k, g in enumerate(graphs):
+            for i, g in enumerate(graphs):
+                if i < len(pend):
+                    main.wait_event(pend[i])
+                if i == n_fwd:  # the last forward graph (it also holds backward stage 0): nothing may be left running
+                    for ev in pend[i + 1:]:
+                        main.wait_event(ev)
                 g.replay()
+                k = i - n_fwd  # backward stage this graph ends with (negative: a forward-only graph)
+                if k < 0:
+                    continue
                 ev = torch.cuda.Event()
                 ev.record(main)
                 if prev is not None:
                     exchange(k - 1, prev)
                 prev = ev
-            exchange(len(graphs) - 1, prev)
+            exchange(len(graphs) - 1 - n_fwd, prev)
             main.wait_stream(comm)
-            self._replay_update(gus)
+            self._replay_update(gus, staged_gather=z is not None and n_fwd > 0)
         return self.outputs[kind]
 
     def iteration(self, branch):

@@ -44,6 +44,7 @@ class Runtime:
         self.cut_enabled = False
         self.n_stages = 1
         self._cuts = []       # cuts recorded by the running forward, in forward order: (tag, outputs, leaves)
+        self.fwd_hook = None  # called with the cut's index when the forward passes a cut (engine: one graph per stage)
         self.cut_layout = {}  # filled by LXRTEncoder.forward: where the cuts of this model sit (dist.stage_ranges)
         self.one = torch.ones((), device=arena.device, dtype=F32)  # d loss / d loss: the root of every backward
         self._slots = None    # zeroed scalar slots for the loss kernels of the running pass (one launch for all)
@@ -63,6 +64,8 @@ class Runtime:
         """called by LXRTEncoder.forward at a cut: returns detached leaves to continue with"""
         leaves = [t.detach().requires_grad_(True) for t in tensors]
         self._cuts.append((tag, list(tensors), leaves))
+        if self.fwd_hook is not None:
+            self.fwd_hook(len(self._cuts) - 1)
         return leaves
 
     def backward(self, loss, between=None):

@@ -76,6 +76,9 @@ def runtime_of(module):
             rt.training = old.training
         object.__setattr__(root, "_xg_arena", arena)
         object.__setattr__(root, "_xg_rt", rt)
+    z = rt.arena.zero1
+    if z is not None and z.pending and not torch.cuda.is_current_stream_capturing():
+        z.wait_pending()  # all-gathers of the last sharded update still running beside the captured forward stages
     if getattr(root, "_xg_shadow_dirty", False):
         rt.arena.sync_shadow()
         object.__setattr__(root, "_xg_shadow_dirty", False)
