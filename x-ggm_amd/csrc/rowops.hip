@@ -132,43 +132,40 @@ struct BatchJobs {
     int n;
 };
 
-// 256 threads = 32 column groups (4 consecutive columns, one 16-byte load per partial row) x 8 row slices:
-// a workgroup owns 128 columns of one job.  (The first version read 4 bytes per lane, 64 columns x 4 slices:
-// 35 us per launch of ~29 jobs = 0.9 TB/s.)
-constexpr int RB_COLS = 128;
+// 256 threads = 16 column groups (4 consecutive columns, one 16-byte load per partial row) x 16 row slices: a workgroup
+// owns 64 columns of one job, a thread the partial rows sl, sl + 16, ... with EIGHT loads in flight -- the 80 / 144 partial
+// rows of a LayerNorm backward are then read in one round trip (two for the longest jobs).  History: 4 bytes per lane,
+// 64 columns x 4 slices 35 us per launch of ~29 jobs; 16 bytes per lane, 128 columns x 8 slices with four loads in flight
+// 37 us per launch of 72 jobs (41 MB = 1.1 TB/s: five dependent round trips per thread, rocprofv3 round 3).
+constexpr int RB_COLS = 64;
+constexpr int RB_SL = 16;
 __global__ __launch_bounds__(NT) void partial_reduce_batch_kernel(BatchJobs bj) {
-    __shared__ float4 red[8][32];
+    __shared__ float4 red[RB_SL][RB_COLS / 4];
     int ji = 0;
     for (int k = 1; k < bj.n; ++k)
         if ((int)blockIdx.x >= bj.start[k]) ji = k;
     const xggm_reduce_job job = bj.j[ji];
-    const int ci = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int ci = threadIdx.x & (RB_COLS / 4 - 1), sl = threadIdx.x / (RB_COLS / 4);
     const int idx = (blockIdx.x - bj.start[ji]) * RB_COLS + ci * 4;
     const int KH = job.K * job.H;  // H % 4 == 0: a column group never straddles two of the K rows
     typedef float f4 __attribute__((ext_vector_type(4)));
-    f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
     if (idx < KH) {
         const float* p = job.ws + idx;
-        int b = sl;
-        // four loads in flight per thread (the sums keep the two-accumulator order: even steps into a0, odd into a1)
-        for (; b + 24 < job.nblk; b += 32) {  // read once: non-temporal
-            const f4 r0 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p + (int64_t)b * KH));
-            const f4 r1 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p + (int64_t)(b + 8) * KH));
-            const f4 r2 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p + (int64_t)(b + 16) * KH));
-            const f4 r3 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p + (int64_t)(b + 24) * KH));
-            a0 += r0;
-            a1 += r1;
-            a0 += r2;
-            a1 += r3;
+        const f4 zero = {0.f, 0.f, 0.f, 0.f};
+        // a thread's rows are added in row order whatever the batching: the result does not depend on scheduling
+        for (int b = sl; b < job.nblk; b += 8 * RB_SL) {  // read once: non-temporal
+            f4 r[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int row = b + q * RB_SL;
+                r[q] = row < job.nblk ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(p + (int64_t)row * KH)) : zero;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += r[q];
         }
-        for (; b + 8 < job.nblk; b += 16) {
-            a0 += __builtin_nontemporal_load(reinterpret_cast<const f4*>(p + (int64_t)b * KH));
-            a1 += __builtin_nontemporal_load(reinterpret_cast<const f4*>(p + (int64_t)(b + 8) * KH));
-        }
-        for (; b < job.nblk; b += 8) a0 += __builtin_nontemporal_load(reinterpret_cast<const f4*>(p + (int64_t)b * KH));
-        a0 += a1;
     }
-    red[sl][ci] = make_float4(a0[0], a0[1], a0[2], a0[3]);
+    red[sl][ci] = make_float4(acc[0], acc[1], acc[2], acc[3]);
     __syncthreads();
     if (sl == 0 && idx < KH) {
         const int k = idx / job.H, c = idx % job.H;
@@ -176,7 +173,7 @@ __global__ __launch_bounds__(NT) void partial_reduce_batch_kernel(BatchJobs bj) 
         if (t) {
             float4 s = red[0][ci];
 #pragma unroll
-            for (int q = 1; q < 8; ++q) {  // fixed order: the result does not depend on scheduling
+            for (int q = 1; q < RB_SL; ++q) {  // fixed order
                 const float4 r = red[q][ci];
                 s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w;
             }
