@@ -174,6 +174,33 @@ def test_two_data_parallel_ranks_on_one_gpu_stay_identical():
     assert "fp8 forward: sharded == replicated update bit for bit (clip not binding), 3 iterations: True" in r.stdout
 
 
+@pytest.mark.parametrize("nowait", [0, 1])
+def test_staged_all_gather_of_the_sharded_update_is_waited_for(nowait):
+    """ZeRO-1: the bf16 weights come back stage by stage on the communication stream beside the next pass's forward
+    graphs, and forward graph i waits for batch i only (dist.ShardedUpdate.gather_begin, CapturedTrainer.run_pass).  With
+    every batch held back 20 ms the two-rank rehearsal must still train bit for bit like the replicated update -- and it
+    must NOT when the engine is denied the events (the negative control: this is what shows that the rehearsal, whose
+    passes follow each other without a host synchronisation, catches a forward that reads the previous step's weights)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", XGGM_GATHER_DELAY_US="20000", XGGM_REHEARSE_ONLY="sharded")
+    if nowait:
+        env["XGGM_REHEARSE_NOWAIT"] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                        os.path.join(root, "tools", "dp_rehearsal.py")], capture_output=True, text=True, timeout=600,
+                       env=env, cwd=root)
+    ok = "sharded == replicated update bit for bit (clip not binding), 3 iterations: True"
+    bad = "sharded == replicated update bit for bit (clip not binding), 3 iterations: False"
+    assert "bf16 weights identical on both ranks: True (forward cut into 4 + 1 graphs)" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    if nowait:
+        assert r.returncode != 0 and bad in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    else:
+        assert r.returncode == 0 and ok in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_bench_on_a_one_rank_rccl_group():
     """bench.py with XGGM_DP_FORCE=1: a real ``nccl`` (RCCL) process group of one rank, so the staged capture, the
     collectives on RCCL's stream between the replayed stage graphs and the watchdog thread are all live on one GPU;

@@ -3,9 +3,10 @@ model, DIFFERENT batches per rank.  Checks (a) replicas stay identical (the exch
 overlapped three-graph path gives the same parameters as the plain two-graph path.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 tools/dp_rehearsal.py
 XGGM_GATHER_DELAY_US=3000 holds every batch of the sharded update's staged all-gather back by 3 ms: the checks must still
-pass (the forward graphs wait for their batch).  XGGM_REHEARSE_NOWAIT=1 on top removes those waits -- a negative control
-for a box with a truly asynchronous backend (nccl, one rank per GPU): over gloo the host blocks inside every collective,
-the gather has always finished before the next graph is launched, and the control passes too (seen on the one-GPU box)."""
+pass (the forward graphs wait for their batch).  XGGM_REHEARSE_NOWAIT=1 on top removes those waits -- the negative
+control: the checks must then FAIL (over gloo the gathered slices reach the weights through an asynchronous device copy
+behind the delay, dist.ShardedUpdate._gather_runs, so a forward graph that does not wait reads the previous step's
+weights)."""
 import os
 import sys
 
@@ -40,9 +41,10 @@ def run(overlap, rank, use_graph=True, iters=("rel", "node", "rel"), layers=(2, 
     for br in iters:
         outs = [tr.run_pass("plain")] if br == "plain" else tr.iteration(br)
         for out in outs:
-            norms.append(float(out[2]))  # the clip norm of the pass
+            norms.append(out[2].clone())  # the clip norm of the pass (read after the loop: NO host synchronisation between
+            # the passes -- the next pass's forward graphs are queued while the staged all-gather of this pass still runs)
     torch.cuda.synchronize()
-    run.norms = norms
+    run.norms = norms = [float(x) for x in norms]
     g = tr.graphs.get("rel") if use_graph else None
     run.n_fwd = g[5] if g is not None and g[0] == "staged" else 0  # forward graphs in front of the backward (sharded update)
     run.names = [(n, p.numel()) for n, p in m.named_parameters()]
@@ -79,9 +81,13 @@ def main():
     dist.init_process_group("gloo")
     if os.environ.get("XGGM_REHEARSE_NOWAIT"):
         # negative control for the staged all-gather (run with XGGM_GATHER_DELAY_US=3000): the engine gets no events to wait
-        # for; with an asynchronous backend the forward graphs then read the weights of the previous step (docstring)
+        # for; the forward graphs then read the weights of the previous step and the bit-exactness checks fail (docstring)
         from xggm_amd.dist import ShardedUpdate
         ShardedUpdate.take_pending = lambda self: []
+    if os.environ.get("XGGM_REHEARSE_ONLY") == "sharded":  # the staged gather's controls (tests/test_engine_gpu.py)
+        check_sharded(rank)
+        dist.destroy_process_group()
+        return
     report(run(False, rank, use_graph=False, iters=("rel",)), rank, "eager, 1 iteration")
     for layers in ((2, 2, 1), (5, 4, 4)):  # two cuts (three backward stages) / four cuts (five stages)
         check(rank, layers)

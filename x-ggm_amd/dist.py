@@ -407,9 +407,14 @@ class ShardedUpdate(GradSync):
                 # scale table, once per pass, in front of the update that derives the new scales from it
                 dist.all_reduce(f8.weight_amax(), op=dist.ReduceOp.MAX, group=self.group)
 
-    def _gather_runs(self, runs):
+    def _gather_runs(self, runs, defer=None):
         """queue the all-gathers of ``runs`` (bf16 shadow and, with the fp8 forward, the e4m3 copies the owners wrote in
-        the same update) on the current stream's side of the communicator; returns the work handles"""
+        the same update) on the current stream's side of the communicator; returns the work handles.  gloo on DEVICE
+        tensors (tools/dp_rehearsal.py: two ranks on one GPU) gathers into staging buffers: the host blocks inside a gloo
+        collective, so gathered straight into the shadow the bytes would always be in place before the next graph is
+        launched and a consumer that forgot to wait for its batch could never be caught; the staged slices reach the shadow
+        by device copies -- right away, or, with ``defer`` (a list that receives (destination, staging) pairs), when
+        ``gather_begin`` queues them behind the test hook's delay: asynchronous as the nccl path is."""
         f8 = getattr(self.arena, "fp8", None)
         bufs = [self.arena.shadow] + ([f8.shadow8] if f8 is not None else [])
         works = []
@@ -417,12 +422,19 @@ class ShardedUpdate(GradSync):
             for run in runs:
                 a, b = run
                 o0, o1 = self.own(run)
+                c = (b - a) // self.world
                 if self.backend == "nccl":
                     works.append(dist.all_gather_into_tensor(sh[a:b], sh[o0:o1], group=self.group, async_op=True))
-                else:
-                    c = (b - a) // self.world
+                elif not sh.is_cuda:
                     works.append(dist.all_gather([sh[a + i * c:a + (i + 1) * c] for i in range(self.world)], sh[o0:o1].clone(),
                                                  group=self.group, async_op=True))
+                else:
+                    stage = torch.empty(b - a, dtype=sh.dtype, device=sh.device)
+                    dist.all_gather([stage[i * c:(i + 1) * c] for i in range(self.world)], sh[o0:o1].clone(), group=self.group)
+                    if defer is not None:
+                        defer.append((sh[a:b], stage))
+                    else:
+                        sh[a:b].copy_(stage, non_blocking=True)
         return works
 
     def gather(self):
@@ -447,13 +459,24 @@ class ShardedUpdate(GradSync):
         comm.wait_stream(torch.cuda.current_stream())  # the update that wrote the own slices
         # test hook (tools/dp_rehearsal.py): hold every batch back by so many microseconds -- a consumer that does not
         # wait for its batch then reads the weights of the previous step and the rehearsal's bit-exactness checks fail
-        delay = float(os.environ.get("XGGM_GATHER_DELAY_US", "0"))
+        delay = int(float(os.environ.get("XGGM_GATHER_DELAY_US", "0")) * 2000)  # ~2 GHz shader clock
+        staged = self.backend != "nccl" and self.arena.shadow.is_cuda
         with torch.cuda.stream(comm):
-            for runs in reversed(self.batches):
+            if staged:  # every (host-blocking) gloo collective first, then the device side batch by batch
+                parts = []
+                for runs in reversed(self.batches):
+                    d = []
+                    self._gather_runs(runs, defer=d)
+                    parts.append(d)
+            for i, runs in enumerate(reversed(self.batches)):
                 if delay > 0:
-                    torch.cuda._sleep(int(delay * 2000))  # ~2 GHz shader clock
-                for wk in self._gather_runs(runs):
-                    wk.wait()  # (stream-side: `comm` waits for the communicator's stream, the host does not block on nccl)
+                    torch.cuda._sleep(delay)
+                if staged:
+                    for dst, st in parts[i]:
+                        dst.copy_(st, non_blocking=True)
+                else:
+                    for wk in self._gather_runs(runs):
+                        wk.wait()  # (stream-side: `comm` waits for the communicator's stream, the host does not block on nccl)
                 ev = torch.cuda.Event()
                 ev.record(comm)
                 self.pending.append(ev)
