@@ -65,6 +65,36 @@ __global__ __launch_bounds__(64 * WAVES, 2) void loop_kernel(const __bf16* src, 
         const __bf16* Ac = lds + stage * STAGE;
         const __bf16* Bc = Ac + 128 * 64;
         int dma = 0;
+        if (MODE & 16) {  // every fragment of the k-tile requested before the first MFMA (64 registers of fragments)
+            bf16x8_t ga[2][TM], gb[2][TN];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int row = wm + i * 16 + fr, chunk = ((h * 4) + fq) ^ ((row >> 1) & 7);
+                    ga[h][i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(Ac + row * 64 + (chunk << 3)));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int row = wn + j * 16 + fr, chunk = ((h * 4) + fq) ^ ((row >> 1) & 7);
+                    gb[h][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(Bc + row * 64 + (chunk << 3)));
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gb[h][j], ga[h][i], acc[i][j], 0, 0, 0);
+                        if ((MODE & 8) && ((i * TN + j) & 3) == 3 && dma < G) {
+                            glds16(rs, dst + dma * NT * 16, voff[dma], soff);
+                            ++dma;
+                        }
+                    }
+            stage ^= 1;
+            continue;
+        }
 #pragma unroll
         for (int ks = 0; ks < 64; ks += 32) {
             if (MODE & 1) {
@@ -240,6 +270,12 @@ int main() {
         run<11, 4>("  the same DMA spread between the MFMAs", src, out, sink, w);
         run<6, 4>("barrier + DMA, MFMAs on registers (no fragment reads)", src, out, sink, w);
         run<4, 4>("DMA + MFMAs on registers, no barrier", src, out, sink, w);
+    }
+    for (int w = 1; w <= 2; ++w) {
+        run<16 | 1, 4>("all 16 fragment reads up front, then the MFMAs", src, out, sink, w);
+        run<16 | 3, 4>("  + barrier", src, out, sink, w);
+        run<16 | 7, 4>("  + barrier + DMA after the barrier", src, out, sink, w);
+        run<16 | 11, 4>("  + barrier + DMA spread between the MFMAs", src, out, sink, w);
     }
     run<0, 8>("8 waves: 16 MFMAs per wave, registers", src, out, sink, 1);
     run<3, 8>("8 waves: + reads + barrier", src, out, sink, 1);
