@@ -1671,6 +1671,14 @@ template <typename T> int grouped(const xggm_gemm_problem* probs, int n, hipStre
             nkmin = std::min(nkmin, ceil_div(ga.p[i].K, 64));
         }
         if (kmaj && t128 > 200 && t128 <= 256 && nkmin >= 12 && !g_no_8w) v = 4;
+        // From 1.75 128 x 128 tiles per CU: the four-wave 128 x 128 tile (two workgroups per CU, 64 x 64 per wave = half the
+        // LDS fragment bytes per MFMA of the other tiles).  The cost model above was fitted at 32 samples, where only the
+        // FFN2 backward group is this large (and the in-step tuner pinned it to this tile); at 64 samples and at the
+        // reference's batches of 92 / 96 the tuner found the same for every heavy launch -- FFN1 forward pair 58.9 -> 48.8 us,
+        // FFN2 backward group 95.6 -> 77.8, QKV forward pair 38.4 -> 35.0 (tools/tune_gemm.py --batch 64 / 92, --order gqa
+        // --batch 96) -- and no launch of that size where another tile won.  Below, the tile loses: 372 tiles (FFN1 backward
+        // group at 32 samples, 48-deep k-loops on few tiles) 39.3 us against 30.3.
+        else if (t128 >= 448) v = 3;
     }
     // (measured and not kept, round 3: 128 x 256 and 256 x 128 on eight waves -- slower on every launch of the step;
     // 192 x 128 on four waves of 96 x 64, the vendor library's tile for the FFN1 shape -- 2 us faster on the FFN1
