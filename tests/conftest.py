@@ -19,7 +19,7 @@ def pytest_configure(config):
 # never hide whether the kernels and the model match the oracle.
 _FILE_ORDER = ["test_oracle_golden", "test_abi_cpu", "test_data_cpu", "test_dist_cpu", "test_kernels_gpu", "test_model_gpu",
                "test_engine_gpu"]
-_LATE = ("bench", "data_parallel", "rccl", "spawn", "sharded_update")
+_LATE = ("bench", "data_parallel", "rccl", "spawn", "sharded_update", "gradient_exchange")
 
 
 def pytest_collection_modifyitems(session, config, items):

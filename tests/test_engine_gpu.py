@@ -201,6 +201,30 @@ def test_staged_all_gather_of_the_sharded_update_is_waited_for(nowait):
         assert r.returncode == 0 and ok in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("broken", ["", "NOJOIN", "NOAFTER"])
+def test_staged_gradient_exchange_of_the_data_parallel_engine_is_waited_for(broken):
+    """The overlapped exchange: the collectives of backward stage k run on the communication stream under graph k + 1.  Two
+    waits hold it together -- the exchange of a stage waits for the graph that wrote the stage's gradients, the update
+    waits for the communication stream.  Over gloo the summed slices come back through a device copy behind a 20 ms delay
+    (dist.GradSync._all_reduce_in_place), so each wait can be shown to matter: with both in place the replicas of the
+    two-rank rehearsal stay bit-identical, with either removed (tools/dp_rehearsal.py patches it out) they come apart."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", XGGM_GATHER_DELAY_US="20000", XGGM_REHEARSE_ONLY="exchange")
+    if broken:
+        env["XGGM_REHEARSE_" + broken] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                        os.path.join(root, "tools", "dp_rehearsal.py")], capture_output=True, text=True, timeout=600,
+                       env=env, cwd=root)
+    if broken:
+        assert r.returncode != 0 and "overlap=True: replicas identical: False" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    else:
+        assert r.returncode == 0 and "overlap=True: replicas identical: True" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_bench_on_a_one_rank_rccl_group():
     """bench.py with XGGM_DP_FORCE=1: a real ``nccl`` (RCCL) process group of one rank, so the staged capture, the
     collectives on RCCL's stream between the replayed stage graphs and the watchdog thread are all live on one GPU;

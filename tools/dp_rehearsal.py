@@ -6,7 +6,10 @@ XGGM_GATHER_DELAY_US=3000 holds every batch of the sharded update's staged all-g
 pass (the forward graphs wait for their batch).  XGGM_REHEARSE_NOWAIT=1 on top removes those waits -- the negative
 control: the checks must then FAIL (over gloo the gathered slices reach the weights through an asynchronous device copy
 behind the delay, dist.ShardedUpdate._gather_runs, so a forward graph that does not wait reads the previous step's
-weights)."""
+weights).  The same for the staged gradient exchange: XGGM_REHEARSE_NOJOIN=1 (the update does not wait for the
+communication stream) and XGGM_REHEARSE_NOAFTER=1 (the exchange of a stage does not wait for the backward graph that wrote
+its gradients) must make the replicas come apart -- over gloo the summed slices come back through a delayed device copy too
+(dist.GradSync._all_reduce_in_place)."""
 import os
 import sys
 
@@ -79,6 +82,38 @@ def main():
     rank = int(os.environ["RANK"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo")
+    # negative controls of the staged gradient exchange (run with XGGM_GATHER_DELAY_US): the update must wait for the
+    # communication stream (XGGM_REHEARSE_NOJOIN=1 removes that wait), and the exchange of a stage must wait for the
+    # backward graph that wrote the stage's gradients (XGGM_REHEARSE_NOAFTER=1 removes that one); either way the replicas
+    # must come apart.  Only waits that involve a trainer's communication stream are touched.
+    if os.environ.get("XGGM_REHEARSE_NOJOIN") or os.environ.get("XGGM_REHEARSE_NOAFTER"):
+        from xggm_amd.engine import CapturedTrainer
+        comm_streams = []
+        make = CapturedTrainer._comm_stream
+
+        def registering(self):
+            st = make(self)
+            if all(st is not c for c in comm_streams):
+                comm_streams.append(st)
+            return st
+
+        CapturedTrainer._comm_stream = registering
+        if os.environ.get("XGGM_REHEARSE_NOJOIN"):
+            ws = torch.cuda.Stream.wait_stream
+            skipped = [0]
+
+            def no_join(self, other):
+                if any(other is c for c in comm_streams):
+                    skipped[0] += 1
+                    if skipped[0] in (1, 10):
+                        print("rank %d: wait_stream(communication stream) skipped (%d so far)" % (rank, skipped[0]), flush=True)
+                    return None
+                return ws(self, other)
+
+            torch.cuda.Stream.wait_stream = no_join
+        if os.environ.get("XGGM_REHEARSE_NOAFTER"):
+            we = torch.cuda.Stream.wait_event
+            torch.cuda.Stream.wait_event = lambda self, ev: None if any(self is c for c in comm_streams) else we(self, ev)
     if os.environ.get("XGGM_REHEARSE_NOWAIT"):
         # negative control for the staged all-gather (run with XGGM_GATHER_DELAY_US=3000): the engine gets no events to wait
         # for; the forward graphs then read the weights of the previous step and the bit-exactness checks fail (docstring)
@@ -86,6 +121,10 @@ def main():
         ShardedUpdate.take_pending = lambda self: []
     if os.environ.get("XGGM_REHEARSE_ONLY") == "sharded":  # the staged gather's controls (tests/test_engine_gpu.py)
         check_sharded(rank)
+        dist.destroy_process_group()
+        return
+    if os.environ.get("XGGM_REHEARSE_ONLY") == "exchange":  # the staged gradient exchange's controls
+        check(rank, (5, 4, 4), modes=(True,))  # the staged engine alone: replicas must stay identical
         dist.destroy_process_group()
         return
     report(run(False, rank, use_graph=False, iters=("rel",)), rank, "eager, 1 iteration")
@@ -165,10 +204,12 @@ def check_sharded(rank):
     assert d < 1e-6
 
 
-def check(rank, layers):
+def check(rank, layers, modes=(False, True)):
     out = {}
-    for overlap in (False, True):
+    for overlap in modes:
         v = run(overlap, rank, layers=layers)
+        if os.environ.get("XGGM_DEBUG_RUNS"):
+            print("rank %d overlap=%s clip norms %s" % (rank, overlap, " ".join("%.6f" % x for x in run.norms)), flush=True)
         other = [torch.empty_like(v) for _ in range(2)]
         dist.all_gather(other, v)
         same = bool(torch.equal(other[0], other[1]))
@@ -177,6 +218,8 @@ def check(rank, layers):
             print("layers %s overlap=%s: replicas identical: %s, |params| = %.6f" % (layers, overlap, same, float(v.double().norm())),
                   flush=True)
         assert same, "replicas diverged: the gradient exchange did not happen"
+    if len(modes) < 2:
+        return
     d = float((out[True] - out[False]).double().norm() / out[False].double().norm())
     if rank == 0:
         print("overlapped vs plain exchange: relative parameter difference %.2e" % d, flush=True)

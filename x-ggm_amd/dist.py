@@ -191,12 +191,35 @@ class GradSync:
         w = self.arena.wire
         tab = self._begin_table() if sparse else None
         rs = self.merged(dense)
-        works = [dist.all_reduce(w[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for s, e in rs]
-        return ("inplace", rs, works, True, tab)
+        works, staged = [], []
+        for s, e in rs:
+            wk, st = self._all_reduce_in_place(w[s:e])
+            works.append(wk)
+            if st is not None:
+                staged.append(st)
+        return ("inplace", rs, works, True, tab, staged)
+
+    def _all_reduce_in_place(self, t):
+        """SUM all-reduce of the slice ``t`` where it lies; returns (work, staging pair or None).  gloo on DEVICE tensors
+        (tools/dp_rehearsal.py) reduces a copy and lets ``_finish_inplace`` bring the result back with a device copy on the
+        current stream, behind the test hook's delay: the host blocks inside a gloo collective, so reduced in place the sums
+        would always be there before the next graph is launched and an update that forgot to wait for the exchange (or an
+        exchange that started before the backward stage had written its gradients) could not be caught."""
+        if self.backend != "nccl" and t.is_cuda:
+            st = t.clone()
+            return dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group, async_op=True), (t, st)
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None
 
     def _finish_inplace(self, handle):
         for wk in handle[2]:
             wk.wait()
+        staged = handle[5] if len(handle) > 5 else []
+        if staged:
+            delay = int(float(os.environ.get("XGGM_GATHER_DELAY_US", "0")) * 2000)  # the rehearsal's delay hook
+            if delay > 0:
+                torch.cuda._sleep(delay)
+            for dst, st in staged:
+                dst.copy_(st, non_blocking=True)
         if len(handle) > 4 and handle[4] is not None:
             self._finish_table(handle[4])
 
@@ -363,7 +386,7 @@ class ShardedUpdate(GradSync):
         tab = self._begin_table() if sparse else None
         mats, vecs = self.split(dense)
         self.batches.append(list(mats))
-        works = []
+        works, staged = [], []
         for run in mats:
             self.runs.append(run)
             self.all_runs.add(run)
@@ -372,9 +395,16 @@ class ShardedUpdate(GradSync):
                 o0, o1 = self.own(run)
                 works.append(dist.reduce_scatter_tensor(w[o0:o1], w[a:b], op=op, group=self.group, async_op=True))
             else:     # gloo has no reduce-scatter: all-reduce, every rank then uses its slice only
-                works.append(dist.all_reduce(w[a:b], op=op, group=self.group, async_op=True))
-        works += [dist.all_reduce(w[s:e], op=op, group=self.group, async_op=True) for s, e in vecs]
-        return ("inplace", mats + vecs, works, nccl, tab)
+                wk, st = self._all_reduce_in_place(w[a:b])
+                works.append(wk)
+                if st is not None:
+                    staged.append(st)
+        for s, e in vecs:
+            wk, st = self._all_reduce_in_place(w[s:e])
+            works.append(wk)
+            if st is not None:
+                staged.append(st)
+        return ("inplace", mats + vecs, works, nccl, tab, staged)
 
     def begin(self, ranges, slot=0):
         if not ranges:
