@@ -298,6 +298,6 @@ def test_measured_tile_table_is_well_formed():
     for sig, pin in t["tiles"].items():
         assert pin in (1, 2, 3, 4), (sig, pin)
         dtp, probs = sig.split("|")
-        assert dtp in ("bf16", "f32")
+        assert dtp in ("bf16", "f32", "e4m3")
         for p in probs.split("+"):
             assert re.fullmatch(r"\d+x\d+x\d+(b\d+)?:[01][01][a-zA-Z]*", p), p

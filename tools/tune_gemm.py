@@ -40,7 +40,7 @@ def main():
     times = {}  # signature -> pin -> [us]
 
     def hook(dt, chunk, sig, arr):
-        name = "xggm_gemm_grouped_" + ops.sfx(dt)
+        name = "xggm_gemm_grouped_fp8e4m3" if dt == "e4m3" else "xggm_gemm_grouped_" + ops.sfx(dt)
         fn = getattr(_lib.lib, name)
         st = ops.stream()
         rec = times.setdefault(sig, {p: [] for p in PINS})

@@ -246,11 +246,24 @@ def p_fwd8(x8, w8, sx, sw, bias=None, act=ACT_NONE, want_preact=False, emit8=Non
 
 
 def gemm_group8(problems):
-    """launch up to 4 e4m3 forward products in one grid (more: consecutive groups of 4)."""
+    """launch up to 4 e4m3 forward products in one grid (more: consecutive groups of 4); the measured tile table
+    applies as for the bf16 groups (signatures start with ``e4m3|``)."""
     for i in range(0, len(problems), 4):
         chunk = problems[i:i + 4]
         arr = (GemmProblem * len(chunk))(*chunk)
-        call("xggm_gemm_grouped_fp8e4m3", _ct.cast(arr, _ct.c_void_p), len(chunk), stream())
+        pin = 0
+        if TILE_TABLE or TILE_HOOK is not None:
+            sig = gemm_signature("e4m3", chunk)
+            pin = TILE_TABLE.get(sig, 0)
+            if TILE_HOOK is not None:
+                pin = TILE_HOOK("e4m3", chunk, sig, arr) or pin
+        if pin:
+            _lib.lib.xggm_gemm_set_group_tile(pin)
+        try:
+            call("xggm_gemm_grouped_fp8e4m3", _ct.cast(arr, _ct.c_void_p), len(chunk), stream())
+        finally:
+            if pin:
+                _lib.lib.xggm_gemm_set_group_tile(0)
 
 
 def p_dgrad(dy, w, residual=None, gelu_aux=None, colsum=None, into=None, defer=None):
@@ -336,7 +349,7 @@ def gemm_signature(dt, chunk):
               ("g" if p.act == ACT_GELU_GRAD else ("G" if p.act == ACT_GELU else "")) + ("c" if p.colsum else "")
         parts.append("%dx%dx%d%s:%d%d%s" % (p.M, p.N, p.K, ("b%d" % p.batch) if p.batch != 1 else "", int(p.a_ks == 1),
                                             int(p.b_ks == 1), ext))
-    return sfx(dt) + "|" + "+".join(parts)
+    return (dt if isinstance(dt, str) else sfx(dt)) + "|" + "+".join(parts)
 
 
 def gemm_group(dt, problems):
