@@ -1684,6 +1684,10 @@ template <typename T> int grouped(const xggm_gemm_problem* probs, int n, hipStre
     // 192 x 128 on four waves of 96 x 64, the vendor library's tile for the FFN1 shape -- 2 us faster on the FFN1
     // forward pair in isolation, never the fastest inside the step, 91 spilled registers.  The epilogues above stay
     // general in the tile shape: whole 64-row blocks, 32-row column-sum blocks.)
+#ifdef XGGM_BIG_TILES  // experiment builds only (make alt ALT=-DXGGM_BIG_TILES): 128 x 256 / 256 x 128 on eight waves
+    if (v == 5) return launch_grouped_tile<128, 256, 8>(ga, stream);
+    if (v == 6) return launch_grouped_tile<256, 128, 8>(ga, stream);
+#endif
     if (v == 4) return launch_grouped_tile<128, 128, 8>(ga, stream);
     if (v == 3) return launch_grouped_tile<128, 128>(ga, stream);
     if (v == 2) return launch_grouped_tile<128, 64>(ga, stream);
