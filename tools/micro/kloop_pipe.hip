@@ -1,0 +1,775 @@
+// Round 4: the software-pipelined k-loop of the grouped GEMM, developed stand-alone before it goes into gemm.hip.
+// A REAL product (C = A B^T, both operands k-contiguous bf16, fp32 accumulation, bf16 output) on 128 x 128 tiles of a
+// 4-wave workgroup (64 x 64 = 4 x 4 blocks of v_mfma_f32_16x16x32_bf16 per wave), two problems sharing one grid as
+// the step's language / vision pairs do, checked against a host reference and timed from a replayed hipGraph beside
+// the shipped library's grouped launch of the same pair (dlopen of libxggm_hip.so: in-process A/B, same device).
+//   hipcc -O3 --offload-arch=gfx950 tools/micro/kloop_pipe.hip -o tools/micro/kloop_pipe -ldl
+//   tools/micro/kloop_pipe [path to libxggm_hip.so]
+//
+// Variants (template parameter V, bit field):
+//   bit 0   fragment double buffer: the ds_read_b128 of k-step s + 1 are issued between the MFMAs of step s, the
+//           barrier sits between the two k-steps of a k-tile (after it the MFMAs of step 1 run on fragments that are
+//           already in registers, the reads of the next tile's step 0 under them)
+//   bit 1   the LDS-DMA of tile t + NS - 1 spread over the iteration (one instruction per four MFMAs) instead of
+//           issued in one burst after the barrier
+//   bit 2   per-wave stagger of the DMA slots (wave w issues after MFMA 4 q + w of a group): needs bit 1
+//   bit 3   sched_group_barrier interleave requests inside each group of four MFMAs
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <dlfcn.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include <string>
+#include <algorithm>
+
+typedef __hip_bfloat16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float float4_t;
+typedef short short8_t __attribute__((ext_vector_type(8)));
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef int int4v __attribute__((ext_vector_type(4)));
+
+#define CHECK(x)                                                                                  \
+    do {                                                                                          \
+        hipError_t e_ = (x);                                                                      \
+        if (e_ != hipSuccess) {                                                                   \
+            fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_));     \
+            exit(1);                                                                              \
+        }                                                                                         \
+    } while (0)
+
+__device__ __forceinline__ void glds16(const int4v& rsrc, unsigned lds, int voff, int soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory");
+}
+__device__ __forceinline__ int4v raw_rsrc(const bf16* base, int64_t bytes) {
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    int4v r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) & 0xffff;
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+
+struct Prob {
+    const bf16* A;  // [M][K]
+    const bf16* B;  // [N][K]
+    bf16* C;        // [M][N]
+    int M, N, K;
+};
+struct Pair {
+    Prob p[2];
+    int tile_start[3];
+};
+
+__device__ __forceinline__ int xcd_remap(int L, int nb) {
+    const int q = nb >> 3, r = nb & 7, xcd = L & 7, idx = L >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// position p of the XCD-contiguous order read rectangle-major: bands of rh tile rows, inside a band column groups of
+// rw tiles (gemm.hip tile_of_position): an XCD's run of positions is about one rh x rw rectangle of the tile grid
+__device__ __forceinline__ void tile_of_position(int p, int gx, int gy, int M, int N, int& tile_m, int& tile_n) {
+    int xr = 1;
+    long best = 8l * M + N;
+#pragma unroll
+    for (int r = 2; r <= 8; r *= 2) {
+        const long c = (long)(8 / r) * M + (long)r * N;
+        if (c < best) { best = c; xr = r; }
+    }
+    const int xc = 8 / xr;
+    const int rh = (gy + xr - 1) / xr, rw = (gx + xc - 1) / xc;
+    int band = 0, q = p;
+#pragma unroll
+    for (int b = 1; b < 8; ++b)
+        if (b < xr && p >= b * rh * gx) { band = b; q = p - b * rh * gx; }
+    const int hb = min(rh, gy - band * rh);
+    int cg = 0, r = q;
+#pragma unroll
+    for (int c = 1; c < 8; ++c)
+        if (c < xc && q >= c * rw * hb) { cg = c; r = q - c * rw * hb; }
+    const int wb = min(rw, gx - cg * rw);
+    const int dr = r / wb;
+    tile_m = band * rh + dr;
+    tile_n = cg * rw + (r - dr * wb);
+}
+
+constexpr int BM = 128, BN = 128;
+constexpr int AEL = BM * 64, STAGE = (BM + BN) * 64;  // elements
+
+// The pipelined loop for one wave role.  W waves per workgroup (4: 2 x 2, wave tile 64 x 64; 8: 4 x 2, wave tile 32 x 64),
+// SLOT: the MFMA of every group after which this wave issues its DMA instruction (stagger: SLOT = wave % 4).
+template <int NS, int V, int W, int SLOT>
+__device__ __forceinline__ void pipe_loop(float4_t (&acc)[BM / (8 * W)][4], bf16* fsm, const int4v& ra, const int4v& rb,
+                                          const int (&va)[32 / W], const int (&vb)[32 / W], unsigned lds0, int la0, int la1, int lb0,
+                                          int lb1, int nk) {
+    constexpr int NT = 64 * W, TM = BM / (8 * W), TN = 4;
+    constexpr int GA = 16 / W * 1, G = 32 / W;  // DMA instructions per wave and k-tile: GA for A, GA for B
+    constexpr bool SPREAD = (V & 2) != 0, NODMA = (V & 16) != 0, NOBAR = (V & 32) != 0;
+    constexpr int H1 = !SPREAD ? G : (NS == 2 ? G : G / 2);
+    constexpr int RPG = (TM + TN + TM - 1) / TM;  // fragment reads per group of TN MFMAs
+    static_assert(!SPREAD || (G - H1) <= TM && (H1 <= TM || H1 == 2 * TM), "one (two) DMA per group");
+    auto dma = [&](int t, int stage, int which) {  // which: 0 .. GA-1 = A pieces, GA .. G-1 = B pieces
+        const unsigned dst = lds0 + stage * (STAGE * 2);
+        const int off = __builtin_amdgcn_readfirstlane(t * 128);
+        if (which < GA) glds16(ra, dst + which * NT * 16, va[which], off);
+        else glds16(rb, dst + AEL * 2 + (which - GA) * NT * 16, vb[which - GA], off);
+    };
+    auto ldfrag = [&](int off) { return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(fsm + off)); };
+    bf16x8_t a0[TM], b0[TN], a1[TM], b1[TN];
+    // read r (0 .. TM + TN - 1) of a step, in the order the next step's MFMAs need them: b0 a0 b1 .. b(TN-1) a1 ..
+    auto rd = [&](bf16x8_t (&a)[TM], bf16x8_t (&b)[TN], int base_a, int base_b, int r) {
+        if (r == 0) b[0] = ldfrag(base_b);
+        else if (r == 1) a[0] = ldfrag(base_a);
+        else if (r <= TN) b[r - 1] = ldfrag(base_b + (r - 1) * 16 * 64);
+        else a[r - TN] = ldfrag(base_a + (r - TN) * 16 * 64);
+    };
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) {
+#pragma unroll
+            for (int w = 0; w < G; ++w) dma(s, s, w);
+        }
+    if (NS - 1 < nk) {
+#pragma unroll
+        for (int w = 0; w < H1; ++w) dma(NS - 1, NS - 1, w);
+    }
+    if (nk >= NS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * G + H1) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < TM + TN; ++r) rd(a0, b0, la0, lb0, r);
+
+    int stage = 0;  // stage of tile t
+    for (int t = 0; t < nk; ++t) {
+        const int so = stage * STAGE;
+        const int sn = (stage + 1 == NS ? 0 : stage + 1);  // stage of tile t + 1
+        const int sd = (stage == 0 ? NS - 1 : stage - 1);   // stage of tile t - 1 = of tile t + NS - 1
+        const bool more = t + NS - 1 < nk;                   // tile t + NS - 1 exists
+        const bool more2 = t + NS < nk;                      // tile t + NS exists
+        // ---- step 0: MFMAs on (a0, b0); reads of (t, step 1); the rest of tile t + NS - 1's DMA
+#pragma unroll
+        for (int q = 0; q < TM; ++q) {
+#pragma unroll
+            for (int r = q * RPG; r < (q + 1) * RPG && r < TM + TN; ++r) rd(a1, b1, so + la1, so + lb1, r);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[q][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j], a0[q], acc[q][j], 0, 0, 0);
+                if (!NODMA && H1 < G && more && j == SLOT && H1 + q < G) dma(t + NS - 1, sd, H1 + q);
+            }
+            if (V & 8) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, RPG - 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            }
+        }
+        // ---- tile t + 1 has landed (younger: tiles t + 2 .. t + NS - 1); every wave is done reading tile t
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * G) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!NOBAR) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (!NODMA && !SPREAD && more2) {
+#pragma unroll
+            for (int w = 0; w < G; ++w) dma(t + NS, stage, w);
+        }
+        // ---- step 1: MFMAs on (a1, b1); reads of (t + 1, step 0); the first H1 DMA instructions of tile t + NS
+        const int son = sn * STAGE;
+#pragma unroll
+        for (int q = 0; q < TM; ++q) {
+#pragma unroll
+            for (int r = q * RPG; r < (q + 1) * RPG && r < TM + TN; ++r) rd(a0, b0, son + la0, son + lb0, r);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[q][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a1[q], acc[q][j], 0, 0, 0);
+                if (!NODMA && SPREAD && more2) {
+                    if (H1 <= TM && j == SLOT && q < H1) dma(t + NS, stage, q);
+                    if (H1 == 2 * TM && (j & 1)) dma(t + NS, stage, 2 * q + (j >> 1));
+                }
+            }
+            if (V & 8) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, RPG - 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            }
+        }
+        stage = sn;
+    }
+}
+
+template <int NS, int V, int W>
+__global__ __launch_bounds__(64 * W, (W == 8 ? 2 : 2)) void pipe_kernel(Pair pr, long long* stamps) {
+    extern __shared__ __attribute__((aligned(16))) bf16 fsm[];
+    constexpr int NT = 64 * W, WM = W / 2, TM = BM / (16 * WM), G = 32 / W, GA = G / 2;
+    const long long ts0 = __builtin_readcyclecounter();
+    const long long rt0 = __builtin_amdgcn_s_memrealtime();
+    const int b = blockIdx.x;
+    const int pi = b >= pr.tile_start[1] ? 1 : 0;
+    const Prob g = pr.p[pi];
+    const int t0 = pr.tile_start[pi], t1 = pr.tile_start[pi + 1];
+    const int local = xcd_remap(b - t0, t1 - t0);
+    const int gx = (g.N + BN - 1) / BN, gy = (g.M + BM - 1) / BM;
+    int tile_m = local / gx, tile_n = local - tile_m * gx;
+    if (V & 64) tile_of_position(local, gx, gy, g.M, g.N, tile_m, tile_n);
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wid >> 1) * (BM / WM), wn = (wid & 1) * 64;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int64_t bytes_a = (int64_t)g.M * g.K * 2, bytes_b = (int64_t)g.N * g.K * 2;
+    const int4v ra = raw_rsrc(g.A, bytes_a), rb = raw_rsrc(g.B, bytes_b);
+
+    float4_t acc[TM][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    // source offsets of this thread's A chunks and B chunks of a k-tile (LDS chunk c = tid + NT i)
+    int va[G], vb[G];
+#pragma unroll
+    for (int i = 0; i < GA; ++i) {
+        const int c = tid + NT * i, row = c >> 3, kc = (c & 7) ^ ((row >> 1) & 7);
+        va[i] = (min(((V & 128) ? 0 : m0) + row, g.M - 1) * g.K + kc * 8) * 2;
+        vb[i] = (min(((V & 128) ? 0 : n0) + row, g.N - 1) * g.K + kc * 8) * 2;
+    }
+    const int nk = g.K / 64;
+    const unsigned lds0 =
+        __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(fsm) + wid * 1024);
+    const int sw = (fr >> 1) & 7;
+    const int la0 = (wm + fr) * 64 + ((fq ^ sw) << 3), la1 = (wm + fr) * 64 + (((4 + fq) ^ sw) << 3);
+    const int lb0 = AEL + (wn + fr) * 64 + ((fq ^ sw) << 3), lb1 = AEL + (wn + fr) * 64 + (((4 + fq) ^ sw) << 3);
+
+    if constexpr (!(V & 1)) {
+        static_assert(W == 4, "baseline: four waves");
+        auto dma = [&](int t, int stage, int which) {
+            const unsigned dst = lds0 + stage * (STAGE * 2);
+            const int off = __builtin_amdgcn_readfirstlane(t * 128);
+            if (which < 4) glds16(ra, dst + which * NT * 16, va[which], off);
+            else glds16(rb, dst + AEL * 2 + (which - 4) * NT * 16, vb[which - 4], off);
+        };
+        auto ldfrag = [&](int off) { return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(fsm + off)); };
+        // ---- baseline: the shipped structure (all reads of a k-step, then its MFMAs; DMA burst after the barrier)
+#pragma unroll
+        for (int s = 0; s < NS - 1; ++s)
+            if (s < nk) {
+#pragma unroll
+                for (int w = 0; w < 8; ++w) dma(s, s, w);
+            }
+        int stage = 0;
+        for (int t = 0; t < nk; ++t) {
+            if (NS == 2 || t + NS - 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * 8) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (t + NS - 1 < nk) {
+                const int ds = stage == 0 ? NS - 1 : stage - 1;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) dma(t + NS - 1, ds, w);
+            }
+            const int so = stage * STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8_t a[4], bb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = ldfrag(so + (ks ? la1 : la0) + i * 16 * 64);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bb[j] = ldfrag(so + (ks ? lb1 : lb0) + j * 16 * 64);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb[j], a[i], acc[i][j], 0, 0, 0);
+            }
+            stage = stage + 1 == NS ? 0 : stage + 1;
+        }
+    } else if constexpr ((V & 4) != 0) {
+        switch (wid & 3) {
+            case 0: pipe_loop<NS, V, W, 0>(acc, fsm, ra, rb, va, vb, lds0, la0, la1, lb0, lb1, nk); break;
+            case 1: pipe_loop<NS, V, W, 1>(acc, fsm, ra, rb, va, vb, lds0, la0, la1, lb0, lb1, nk); break;
+            case 2: pipe_loop<NS, V, W, 2>(acc, fsm, ra, rb, va, vb, lds0, la0, la1, lb0, lb1, nk); break;
+            default: pipe_loop<NS, V, W, 3>(acc, fsm, ra, rb, va, vb, lds0, la0, la1, lb0, lb1, nk); break;
+        }
+    } else {
+        pipe_loop<NS, V, W, 3>(acc, fsm, ra, rb, va, vb, lds0, la0, la1, lb0, lb1, nk);
+    }
+    const long long ts1 = __builtin_readcyclecounter();
+    // epilogue: lane (fr, fq) holds row fr, columns 4 fq .. 4 fq + 3 of every 16 x 16 block
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = m0 + wm + i * 16 + fr;
+        if (row >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + wn + j * 16 + fq * 4;
+            if (col >= g.N) continue;
+            short4v ov;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ov[e] = __builtin_bit_cast(short, __float2bfloat16(acc[i][j][e]));
+            *reinterpret_cast<short4v*>(g.C + (int64_t)row * g.N + col) = ov;
+        }
+    }
+    if (stamps && tid == 0) {
+        stamps[8 * b] = ts1 - ts0;
+        stamps[8 * b + 1] = __builtin_readcyclecounter() - ts1;
+        stamps[8 * b + 2] = 0;
+        stamps[8 * b + 3] = rt0;
+        stamps[8 * b + 4] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
+// Producer / consumer roles: waves 0-3 compute (64 x 64 each: fragment double buffer, MFMAs, one barrier per k-tile,
+// never a vector-memory instruction or a vmcnt wait), waves 4 .. 4 + L - 1 load (all LDS-DMA of the tile, the counted
+// waits).  One s_barrier per k-tile joins the roles.
+template <int NS, int L, int V>
+__global__ __launch_bounds__(64 * (4 + L), 2) void role_kernel(Pair pr, long long* stamps) {
+    extern __shared__ __attribute__((aligned(16))) bf16 fsm[];
+    constexpr int P = 32 / L;  // 1 KB pieces per loader wave and k-tile
+    const long long ts0 = __builtin_readcyclecounter();
+    const long long rt0 = __builtin_amdgcn_s_memrealtime();
+    const int b = blockIdx.x;
+    const int ts1v = pr.tile_start[1];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(ts1v) : "memory");
+    const long long tsA = __builtin_readcyclecounter();
+    const int pi = b >= ts1v ? 1 : 0;
+    const Prob g = pr.p[pi];
+    const int t0 = pr.tile_start[pi], t1 = pr.tile_start[pi + 1];
+    const int local = xcd_remap(b - t0, t1 - t0);
+    const int gx = (g.N + BN - 1) / BN, gy = (g.M + BM - 1) / BM;
+    int tile_m = local / gx, tile_n = local - tile_m * gx;
+    if (V & 64) tile_of_position(local, gx, gy, g.M, g.N, tile_m, tile_n);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(tile_m), "s"(tile_n) : "memory");
+    const long long tsB = __builtin_readcyclecounter();
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int lm0 = (V & 128) ? 0 : m0, ln0 = (V & 128) ? 0 : n0;  // V & 128: every tile LOADS panel 0 (L2-hot operands)
+    const int nk = g.K / 64;
+    const unsigned ldsb = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(fsm));
+    if (wid >= 4) {
+        // ---------------- loader
+        const int l = wid - 4;
+        const int4v ra = raw_rsrc(g.A, (int64_t)g.M * g.K * 2), rb = raw_rsrc(g.B, (int64_t)g.N * g.K * 2);
+        int voff[P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const int p = l + L * i;  // piece: p < 16 rows 8 p .. of A, else rows 8 (p - 16) .. of B
+            const int row = (p & 15) * 8 + (lane >> 3), kc = (lane & 7) ^ ((row >> 1) & 7);
+            voff[i] = p < 16 ? (min(lm0 + row, g.M - 1) * g.K + kc * 8) * 2 : (min(ln0 + row, g.N - 1) * g.K + kc * 8) * 2;
+        }
+        auto issue = [&](int t, int stage) {
+            const int off = __builtin_amdgcn_readfirstlane(t * 128);
+            const unsigned dst = ldsb + stage * (STAGE * 2);
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                const int p = l + L * i;
+                if (p < 16) glds16(ra, dst + p * 1024, voff[i], off);
+                else glds16(rb, dst + p * 1024, voff[i], off);
+            }
+        };
+        const long long tl1 = __builtin_readcyclecounter();
+        long long tl2;
+        if (V & 256) {
+            // tile 0 alone first: the compute waves start on it while tiles 1 .. NS - 1 are being issued
+            issue(0, 0);
+            tl2 = __builtin_readcyclecounter();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2)
+                if (s2 < nk) issue(s2, s2);
+            tl2 = __builtin_readcyclecounter();
+            if (nk >= NS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * P > 63 ? 63 : (NS - 1) * P) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const long long tl3 = __builtin_readcyclecounter();
+        __builtin_amdgcn_s_barrier();
+        if (V & 256) {
+#pragma unroll
+            for (int s2 = 1; s2 < NS; ++s2)
+                if (s2 < nk) issue(s2, s2);
+        }
+        if (stamps && tid == 256 && b < 2048) {
+            stamps[8 * b + 5] = tl1 - ts0;
+            stamps[8 * b + 6] = tl2 - ts0;
+            stamps[8 * b + 7] = tl3 - ts0;
+            stamps[8 * 2048 + 2 * b] = tsA - ts0;
+            stamps[8 * 2048 + 2 * b + 1] = tsB - ts0;
+        }
+        int stage = 0;
+        for (int t = 0; t < nk; ++t) {
+            if (t + NS - 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * P > 63 ? 63 : (NS - 2) * P) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (t + NS < nk) issue(t + NS, stage);
+            stage = stage + 1 == NS ? 0 : stage + 1;
+        }
+        return;
+    }
+    // ---------------- compute
+    const int wm = (wid >> 1) * 64, wn = (wid & 1) * 64;
+    const int fr = lane & 15, fq = lane >> 4;
+    float4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    const int sw = (fr >> 1) & 7;
+    const int la0 = (wm + fr) * 64 + ((fq ^ sw) << 3), la1 = (wm + fr) * 64 + (((4 + fq) ^ sw) << 3);
+    const int lb0 = AEL + (wn + fr) * 64 + ((fq ^ sw) << 3), lb1 = AEL + (wn + fr) * 64 + (((4 + fq) ^ sw) << 3);
+    auto ldfrag = [&](int off) { return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(fsm + off)); };
+    bf16x8_t a0[4], b0[4], a1[4], b1[4];
+    auto rd = [&](bf16x8_t (&a)[4], bf16x8_t (&bq)[4], int base_a, int base_b, int r) {
+        if (r == 0) bq[0] = ldfrag(base_b);
+        else if (r == 1) a[0] = ldfrag(base_a);
+        else if (r <= 4) bq[r - 1] = ldfrag(base_b + (r - 1) * 16 * 64);
+        else a[r - 4] = ldfrag(base_a + (r - 4) * 16 * 64);
+    };
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const long long ts1 = __builtin_readcyclecounter();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) rd(a0, b0, la0, lb0, r);
+    int stage = 0;
+    for (int t = 0; t < nk; ++t) {
+        const int so = stage * STAGE;
+        const int sn = (stage + 1 == NS ? 0 : stage + 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            rd(a1, b1, so + la1, so + lb1, 2 * q);
+            rd(a1, b1, so + la1, so + lb1, 2 * q + 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[q][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j], a0[q], acc[q][j], 0, 0, 0);
+            if (V & 8) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int son = sn * STAGE;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            rd(a0, b0, son + la0, son + lb0, 2 * q);
+            rd(a0, b0, son + la0, son + lb0, 2 * q + 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[q][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a1[q], acc[q][j], 0, 0, 0);
+            if (V & 8) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            }
+        }
+        stage = sn;
+    }
+    if (V & 512) {  // the loaders have exited (or will): a barrier of the surviving waves only
+        __builtin_amdgcn_s_barrier();
+        fsm[tid] = __float2bfloat16(acc[0][0][0]);
+        __builtin_amdgcn_s_barrier();
+        if (fsm[(tid + 64) & 255] == __float2bfloat16(123.456f)) acc[0][0][0] += 1.f;
+        __builtin_amdgcn_s_barrier();
+    }
+    const long long ts2 = __builtin_readcyclecounter();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = m0 + wm + i * 16 + fr;
+        if (row >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + wn + j * 16 + fq * 4;
+            if (col >= g.N) continue;
+            short4v ov;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ov[e] = __builtin_bit_cast(short, __float2bfloat16(acc[i][j][e]));
+            *reinterpret_cast<short4v*>(g.C + (int64_t)row * g.N + col) = ov;
+        }
+    }
+    if (stamps && tid == 0) {
+        stamps[8 * b] = ts2 - ts0;
+        stamps[8 * b + 1] = __builtin_readcyclecounter() - ts2;
+        stamps[8 * b + 2] = ts1 - ts0;
+        stamps[8 * b + 3] = rt0;
+        stamps[8 * b + 4] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
+// L2 -> LDS rate of the LDS-DMA path alone: every wave issues G instructions per round into a ring of stages and waits
+// for the round before last; the workgroups of one XCD read the same 512 KB (L2 hits)
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void dma_rate_kernel(const bf16* src, long long* out, int rounds) {
+    extern __shared__ __attribute__((aligned(16))) bf16 fsm[];
+    constexpr int NTH = 64 * WAVES, G = 32 / WAVES;  // 32 KB per round
+    const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int4v rs = raw_rsrc(src + (size_t)(blockIdx.x & 7) * 256 * 1024, 512 * 1024);
+    const unsigned lds0 =
+        __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(fsm) + wid * 1024);
+    int voff[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) voff[i] = (tid + NTH * i) * 16;
+    __syncthreads();
+    const long long t0 = __builtin_readcyclecounter();
+    for (int r = 0; r < rounds; ++r) {
+        const int soff = __builtin_amdgcn_readfirstlane((r & 15) * 32768);
+        const unsigned dst = lds0 + (r % 3) * 32768;
+#pragma unroll
+        for (int i = 0; i < G; ++i) glds16(rs, dst + i * NTH * 16, voff[i], soff);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G > 63 ? 63 : 2 * G) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long t1 = __builtin_readcyclecounter();
+    if (tid == 0) out[blockIdx.x] = t1 - t0;
+}
+
+// ------------------------------------------------------------------------------------------------ host
+static float bf2f(bf16 v) { return __bfloat162float(v); }
+
+typedef struct xggm_gemm_problem {
+    const void* A; const void* B; void* C;
+    int M, N, K;
+    int64_t a_rs, a_ks, b_ns, b_ks, ldc;
+    int batch;
+    int64_t a_bs, b_bs, c_bs;
+    const float* bias; const void* residual; void* preact; const void* aux; float* colsum;
+    int act, c_f32, accumulate;
+    float alpha;
+    float* sqsum;
+    const float* scale_a; const float* scale_b; void* c8; const float* c8_qscale; float* c8_amax;
+    int amax_slots;
+} xggm_gemm_problem;
+typedef int (*grouped_fn)(const xggm_gemm_problem*, int, void*);
+typedef int (*settile_fn)(int);
+
+struct Shape { const char* name; int N, K; };
+
+template <typename F> static float time_graph(F&& launch, int per_graph = 40, int reps = 20) {
+    hipStream_t s;
+    CHECK(hipStreamCreate(&s));
+    hipGraph_t gr;
+    hipGraphExec_t ge;
+    CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+    for (int i = 0; i < per_graph; ++i) launch(s);
+    CHECK(hipStreamEndCapture(s, &gr));
+    CHECK(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) CHECK(hipGraphLaunch(ge, s));
+    CHECK(hipStreamSynchronize(s));
+    std::vector<float> ts;
+    for (int r = 0; r < reps; ++r) {
+        CHECK(hipEventRecord(e0, s));
+        CHECK(hipGraphLaunch(ge, s));
+        CHECK(hipEventRecord(e1, s));
+        CHECK(hipStreamSynchronize(s));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        ts.push_back(ms * 1000.f / per_graph);
+    }
+    std::sort(ts.begin(), ts.end());
+    CHECK(hipGraphExecDestroy(ge));
+    CHECK(hipGraphDestroy(gr));
+    CHECK(hipStreamDestroy(s));
+    return ts[ts.size() / 2];
+}
+
+template <int NS, int V, int W> static void launch_pipe(const Pair& pr, hipStream_t s, long long* stamps = nullptr) {
+    static bool set = false;
+    const size_t lds = (size_t)NS * STAGE * 2;
+    if (!set) {
+        CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pipe_kernel<NS, V, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        set = true;
+    }
+    hipLaunchKernelGGL((pipe_kernel<NS, V, W>), dim3(pr.tile_start[2]), dim3(64 * W), lds, s, pr, stamps);
+}
+
+template <int NS, int L, int V> static void launch_role(const Pair& pr, hipStream_t s, long long* stamps = nullptr) {
+    static bool set = false;
+    const size_t lds = (size_t)NS * STAGE * 2;
+    if (!set) {
+        CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&role_kernel<NS, L, V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        set = true;
+    }
+    hipLaunchKernelGGL((role_kernel<NS, L, V>), dim3(pr.tile_start[2]), dim3(64 * (4 + L)), lds, s, pr, stamps);
+}
+
+int main(int argc, char** argv) {
+    const char* libpath = argc > 1 ? argv[1] : "x-ggm_amd/csrc/libxggm_hip.so";
+    void* lib = dlopen(libpath, RTLD_NOW);
+    grouped_fn lib_grouped = lib ? (grouped_fn)dlsym(lib, "xggm_gemm_grouped_bf16") : nullptr;
+    settile_fn lib_tile = lib ? (settile_fn)dlsym(lib, "xggm_gemm_set_group_tile") : nullptr;
+    if (!lib_grouped) printf("(library not loaded: %s)\n", dlerror());
+
+    // ---- L2 -> LDS rate
+    {
+        bf16* src;
+        long long* out;
+        CHECK(hipMalloc(&src, 8 * 512 * 1024));
+        CHECK(hipMalloc(&out, 1024 * sizeof(long long)));
+        CHECK(hipMemset(src, 0, 8 * 512 * 1024));
+        auto run = [&](auto kern, int waves, int wgs) {
+            const int grid = 256 * wgs, rounds = 2000;
+            CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32768));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * waves), 3 * 32768, 0, src, out, 200);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * waves), 3 * 32768, 0, src, out, rounds);
+            CHECK(hipDeviceSynchronize());
+            std::vector<long long> h(grid);
+            CHECK(hipMemcpy(h.data(), out, grid * sizeof(long long), hipMemcpyDeviceToHost));
+            double m = 0;
+            for (auto v : h) m += (double)v;
+            m /= grid;
+            printf("LDS-DMA only, %d waves, %d WG/CU: %.0f cycles per 32 KB round per WG = %.1f B/clk per CU\n", waves, wgs, m / rounds,
+                   32768.0 * rounds * wgs / m);
+        };
+        run(dma_rate_kernel<4>, 4, 1);
+        run(dma_rate_kernel<8>, 8, 1);
+        run(dma_rate_kernel<1>, 1, 1);
+        run(dma_rate_kernel<2>, 2, 1);
+        CHECK(hipFree(src));
+        CHECK(hipFree(out));
+    }
+
+    const Shape shapes[] = {{"attn-out fwd", 768, 768}};
+    long long* dstamps;
+    CHECK(hipMalloc(&dstamps, 4096 * 64 * 2));
+    const int Ms[2] = {1152, 640};
+    for (const Shape& sh : shapes) {
+        Pair pr;
+        std::vector<std::vector<bf16>> hA(2), hB(2);
+        bf16 *dA[2], *dB[2], *dC[2], *dCref[2];
+        int total = 0;
+        for (int p = 0; p < 2; ++p) {
+            const int M = Ms[p];
+            hA[p].resize((size_t)M * sh.K);
+            hB[p].resize((size_t)sh.N * sh.K);
+            unsigned s = 1234u + p * 77u + sh.N;
+            auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.f - 0.5f; };
+            for (auto& v : hA[p]) v = __float2bfloat16(rnd());
+            for (auto& v : hB[p]) v = __float2bfloat16(rnd() * 0.25f);
+            CHECK(hipMalloc(&dA[p], hA[p].size() * 2));
+            CHECK(hipMalloc(&dB[p], hB[p].size() * 2));
+            CHECK(hipMalloc(&dC[p], (size_t)M * sh.N * 2));
+            CHECK(hipMalloc(&dCref[p], (size_t)M * sh.N * 2));
+            CHECK(hipMemcpy(dA[p], hA[p].data(), hA[p].size() * 2, hipMemcpyHostToDevice));
+            CHECK(hipMemcpy(dB[p], hB[p].data(), hB[p].size() * 2, hipMemcpyHostToDevice));
+            pr.p[p] = Prob{dA[p], dB[p], dC[p], M, sh.N, sh.K};
+            pr.tile_start[p] = total;
+            total += ((M + BM - 1) / BM) * ((sh.N + BN - 1) / BN);
+        }
+        pr.tile_start[2] = total;
+        printf("\n%s: M = %d + %d, N = %d, K = %d, %d tiles of 128 x 128\n", sh.name, Ms[0], Ms[1], sh.N, sh.K, total);
+
+        // reference result: a few host rows, and the library's kernel for the full comparison
+        xggm_gemm_problem lp[2];
+        memset(lp, 0, sizeof(lp));
+        for (int p = 0; p < 2; ++p) {
+            lp[p].A = dA[p]; lp[p].B = dB[p]; lp[p].C = dCref[p];
+            lp[p].M = Ms[p]; lp[p].N = sh.N; lp[p].K = sh.K;
+            lp[p].a_rs = sh.K; lp[p].a_ks = 1; lp[p].b_ns = sh.K; lp[p].b_ks = 1; lp[p].ldc = sh.N;
+            lp[p].batch = 1; lp[p].alpha = 1.f;
+        }
+        if (lib_grouped) {
+            for (int tile = 0; tile <= 4; ++tile) {
+                lib_tile(tile);
+                const float us = time_graph([&](hipStream_t s) { lib_grouped(lp, 2, s); });
+                static const char* tn[] = {"heuristic", "64x64", "128x64", "128x128/4w", "128x128/8w"};
+                printf("  library %-11s %7.2f us\n", tn[tile], us);
+            }
+            lib_tile(3);
+            lib_grouped(lp, 2, nullptr);
+            CHECK(hipDeviceSynchronize());
+            lib_tile(0);
+        }
+        auto check = [&](const char* what) {
+            double worst = 0;
+            long mism = 0;
+            for (int p = 0; p < 2; ++p) {
+                const int M = Ms[p];
+                std::vector<bf16> hC((size_t)M * sh.N), hR((size_t)M * sh.N);
+                CHECK(hipMemcpy(hC.data(), dC[p], hC.size() * 2, hipMemcpyDeviceToHost));
+                if (lib_grouped) {
+                    CHECK(hipMemcpy(hR.data(), dCref[p], hR.size() * 2, hipMemcpyDeviceToHost));
+                    for (size_t i = 0; i < hC.size(); ++i)
+                        if (memcmp(&hC[i], &hR[i], 2) != 0) ++mism;
+                }
+                for (int m : {0, 1, 63, 64, 127, 128, M - 129, M - 1})
+                    for (int n = 0; n < sh.N; n += 37) {
+                        double ref = 0;
+                        for (int k = 0; k < sh.K; ++k) ref += (double)bf2f(hA[p][(size_t)m * sh.K + k]) * bf2f(hB[p][(size_t)n * sh.K + k]);
+                        worst = std::max(worst, fabs(ref - bf2f(hC[(size_t)m * sh.N + n])) / (fabs(ref) + 1.0));
+                    }
+            }
+            printf("  %-34s host check: worst rel err %.2e%s", what, worst, worst < 2e-2 ? "" : "  <-- WRONG");
+            if (lib_grouped) printf(", %ld elements differ from the library's 128x128 result", mism);
+            printf("\n");
+        };
+#define RUN_(LAUNCH, NAME, NOCHECK)                                                                     \
+    do {                                                                                                 \
+        for (int p = 0; p < 2; ++p) CHECK(hipMemset(dC[p], 0xff, (size_t)Ms[p] * sh.N * 2));             \
+        LAUNCH(nullptr, dstamps);                                                                        \
+        CHECK(hipDeviceSynchronize());                                                                   \
+        if (!(NOCHECK)) check(NAME);                                                                     \
+        CHECK(hipMemset(dstamps, 0, 4096 * 64 * 2));                                                         \
+        for (int w_ = 0; w_ < 5; ++w_) LAUNCH(nullptr, dstamps);                                         \
+        CHECK(hipDeviceSynchronize());                                                                   \
+        std::vector<long long> hs(8 * total);                                                            \
+        CHECK(hipMemcpy(hs.data(), dstamps, hs.size() * 8, hipMemcpyDeviceToHost));                      \
+        double kl = 0, ep = 0, pro = 0, l1 = 0, l2 = 0, l3 = 0;                                          \
+        long long first = hs[3], last_in = hs[3], last_out = hs[4];                                      \
+        for (int i = 0; i < total; ++i) {                                                                \
+            kl += hs[8 * i]; ep += hs[8 * i + 1]; pro += hs[8 * i + 2];                                  \
+            l1 += hs[8 * i + 5]; l2 += hs[8 * i + 6]; l3 += hs[8 * i + 7];                               \
+            first = std::min(first, hs[8 * i + 3]); last_in = std::max(last_in, hs[8 * i + 3]);          \
+            last_out = std::max(last_out, hs[8 * i + 4]);                                                \
+        }                                                                                                \
+        {                                                                                                \
+            std::vector<long long> h2(2 * total);                                                        \
+            CHECK(hipMemcpy(h2.data(), dstamps + 8 * 2048, h2.size() * 8, hipMemcpyDeviceToHost));       \
+            double sa = 0, sb = 0;                                                                       \
+            for (int i = 0; i < total; ++i) { sa += h2[2 * i]; sb += h2[2 * i + 1]; }                    \
+            if (sa > 0) printf("      kernarg visible %.0f, tile mapped %.0f cycles after entry\n", sa / total, sb / total); \
+        }                                                                                                \
+        const float us = time_graph([&](hipStream_t s) { LAUNCH(s, nullptr); });                         \
+        printf("  %-26s %7.2f us  (entry->loop end %6.0f cyc = %5.0f/k-tile, prologue %5.0f [loader: setup %4.0f issued %4.0f landed %4.0f], epilogue %5.0f; entry->exit %.2f us)\n", \
+               NAME, us, kl / total, kl / total / (sh.K / 64), pro / total, l1 / total, l2 / total, l3 / total, ep / total, (last_out - first) * 0.01); \
+    } while (0)
+#define RUN(NS_, V_, W_)                                                                                 \
+    do {                                                                                                 \
+        char nm[64];                                                                                     \
+        snprintf(nm, sizeof nm, "pipe NS=%d V=%d W=%d", NS_, V_, W_);                                    \
+        auto L_ = [&](hipStream_t s, long long* st) { launch_pipe<NS_, V_, W_>(pr, s, st); };            \
+        RUN_(L_, nm, ((V_) & (48 + 128)));                                                                       \
+    } while (0)
+#define RUNR(NS_, L_N, V_)                                                                               \
+    do {                                                                                                 \
+        char nm[64];                                                                                     \
+        snprintf(nm, sizeof nm, "role NS=%d L=%d V=%d", NS_, L_N, V_);                                   \
+        auto L_ = [&](hipStream_t s, long long* st) { launch_role<NS_, L_N, V_>(pr, s, st); };           \
+        RUN_(L_, nm, ((V_) & 128));                                                                      \
+    } while (0)
+        RUNR(3, 4, 8 + 64 + 256 + 512);
+        for (int p = 0; p < 2; ++p) {
+            CHECK(hipFree(dA[p]));
+            CHECK(hipFree(dB[p]));
+            CHECK(hipFree(dC[p]));
+            CHECK(hipFree(dCref[p]));
+        }
+    }
+    return 0;
+}
