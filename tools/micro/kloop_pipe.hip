@@ -645,7 +645,8 @@ int main(int argc, char** argv) {
         CHECK(hipFree(out));
     }
 
-    const Shape shapes[] = {{"attn-out fwd", 768, 768}};
+    const Shape shapes[] = {{"QKV fwd", 2304, 768}, {"attn-out fwd", 768, 768}, {"FFN1 fwd", 3072, 768}, {"FFN2 fwd", 768, 3072}};
+    const bool lib_only = argc > 2;
     long long* dstamps;
     CHECK(hipMalloc(&dstamps, 4096 * 64 * 2));
     const int Ms[2] = {1152, 640};
@@ -685,10 +686,11 @@ int main(int argc, char** argv) {
             lp[p].batch = 1; lp[p].alpha = 1.f;
         }
         if (lib_grouped) {
-            for (int tile = 0; tile <= 4; ++tile) {
+            for (int tile = 0; tile <= 8; ++tile) {
+                if (tile == 5 || tile == 6) continue;
                 lib_tile(tile);
                 const float us = time_graph([&](hipStream_t s) { lib_grouped(lp, 2, s); });
-                static const char* tn[] = {"heuristic", "64x64", "128x64", "128x128/4w", "128x128/8w"};
+                static const char* tn[] = {"heuristic", "64x64", "128x64", "128x128/4w", "128x128/8w", "", "", "role 128x128", "role 128x64"};
                 printf("  library %-11s %7.2f us\n", tn[tile], us);
             }
             lib_tile(3);
@@ -763,7 +765,7 @@ int main(int argc, char** argv) {
         auto L_ = [&](hipStream_t s, long long* st) { launch_role<NS_, L_N, V_>(pr, s, st); };           \
         RUN_(L_, nm, ((V_) & 128));                                                                      \
     } while (0)
-        RUNR(3, 4, 8 + 64 + 256 + 512);
+        if (!lib_only) RUNR(3, 4, 8 + 64 + 256);
         for (int p = 0; p < 2; ++p) {
             CHECK(hipFree(dA[p]));
             CHECK(hipFree(dB[p]));

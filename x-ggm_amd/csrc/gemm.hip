@@ -52,6 +52,13 @@ struct GemmArgs {
     int xcd_swizzle;
     int batch;
     int use_glds;  // k-major operand pairs take the LDS-DMA k-loop (gemm_kloop_glds)
+    // block -> tile map of the grouped kernels, constants computed on the host per (problem, tile shape): see tile_from_map
+    struct TileMap {
+        int gx, gy, gxy;              // tile grid; tiles per batch entry
+        int xr, xc, rh, rw;           // XCD rectangles: xr bands of rh tile rows x xc column groups of rw tiles
+        int ncg, wb_last;             // non-empty column groups, width of the last one
+        unsigned m_rw, m_wbl, m_gxy;  // ceil(2^32 / d) for d = rw, wb_last, gxy (unused where d == 1)
+    } tm;
 #ifdef XGGM_STAMP
     long long* stamp;  // instrumented build (make stamp): 8 cycle-counter slots per workgroup
     int ablate;        // instrumented build: 1 skips the chunk loop of the epilogue, 2 the whole epilogue
@@ -1101,6 +1108,176 @@ __device__ __forceinline__ void gemm_kloop_glds(const GemmArgs& g, int tile_m, i
     TRACE(g, 0);
 }
 
+// ---- k-loop with wave roles (round 4) ---------------------------------------------------------------------------
+// tools/micro/kloop_pipe.hip, profiles/r04_experiments/: in gemm_kloop_glds every wave does everything in turn -- issue
+// the LDS-DMA of a later tile (~26 cycles of the CU's address path per instruction, during which the wave issues nothing
+// else), wait, barrier, read ALL fragments of a k-step, then its MFMAs -- and with one wave per SIMD the pieces add:
+// 1 300-1 600 cycles per 128 x 128 x 64 k-tile against 512 of matrix work.  Here a 512-thread workgroup splits the work:
+//   waves 0-3  compute: 2 x 2 over the tile, TWO fragment sets.  Iteration t = [k-step 0: MFMAs on set 0, the ds_reads of
+//              (t, k-step 1) into set 1 between them] -> s_barrier -> [k-step 1: MFMAs on set 1, the reads of
+//              (t + 1, k-step 0) into set 0 between them].  No vector-memory instruction, no vmcnt wait, and no
+//              fragment read whose latency is exposed: after the barrier the matrix pipe runs on registers.
+//   waves 4-7  load: every LDS-DMA instruction of the tile (1 KB pieces, loader l takes pieces l, l + 4, ...) and the
+//              counted waits.  At the barrier of iteration t every compute wave holds both k-steps of tile t in
+//              registers, so stage t % NS is free: tile t + NS goes there, i.e. NS - 1 whole tiles stay in flight.
+// One s_barrier per k-tile joins the roles (the loaders arrive after their counted wait for tile t + 1).  The loaders
+// exit after the last barrier; s_barrier counts surviving waves only, so the compute waves' epilogue barriers stand.
+// Same k order and the same v_mfma_f32_16x16x32_bf16 chain per accumulator as every other tile: results are bit-identical.
+// Measured per k-tile (128 x 128, one workgroup per CU, K = 3072): 1 345 cycles before, 1 108 with the fragment double
+// buffer alone, 931 with the roles; the micro-benchmark's ideal (no DMA at all) is 740.
+template <int BM, int BN, bool AK, bool BKM, int NS>
+__device__ __forceinline__ void gemm_role_load(const GemmArgs& g, int tile_m, int tile_n, int bz, bf16* fsm, int l) {
+    constexpr int PA = BM / 8, PB = BN / 8;      // 1 KB pieces of the A and of the B image of one stage
+    constexpr int NA = PA / 4, NB = PB / 4;      // pieces per loader wave
+    constexpr int P = NA + NB;
+    constexpr int STAGE_B = (BM + BN) * 128;     // bytes per stage
+    static_assert(PA % 4 == 0 && PB % 4 == 0, "whole pieces per loader");
+    static_assert(BM <= 128 && BN <= 128, "at most four groups per k-step");
+    const int lane = threadIdx.x & 63;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const bf16* A = reinterpret_cast<const bf16*>(g.A) + (int64_t)bz * g.a_bs;
+    const bf16* B = reinterpret_cast<const bf16*>(g.B) + (int64_t)bz * g.b_bs;
+    const int64_t bytes_a = AK ? ((int64_t)(g.M - 1) * g.a_rs + g.K) * 2 : ((int64_t)(g.K - 1) * g.a_ks + g.a_rows) * 2;
+    const int64_t bytes_b = BKM ? ((int64_t)(g.N - 1) * g.b_ns + g.K) * 2 : ((int64_t)(g.K - 1) * g.b_ks + g.b_rows) * 2;
+    const int4v ra = raw_rsrc(A, bytes_a), rb = raw_rsrc(B, bytes_b);
+    const int a_rs = __builtin_amdgcn_readfirstlane((int)g.a_rs), a_ks = __builtin_amdgcn_readfirstlane((int)g.a_ks);
+    const int b_ns = __builtin_amdgcn_readfirstlane((int)g.b_ns), b_ks = __builtin_amdgcn_readfirstlane((int)g.b_ks);
+    // byte offset (inside one k-tile) of the chunk this lane moves in piece p of an operand image: LDS chunk c = 64 p + lane
+    int va[NA], vb[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int c = (l + 4 * i) * 64 + lane;
+        if (AK) {
+            const int row = c >> 3, kc = (c & 7) ^ ((row >> 1) & 7);
+            va[i] = (min(m0 + row, g.a_rows - 1) * a_rs + kc * 8) * 2;
+        } else {
+            const int kl = c / (BM / 8), rc = ((c % (BM / 8)) ^ glds_rx<BM>(kl)) * 8;
+            va[i] = (kl * a_ks + min(m0 + rc, g.a_rows - 8)) * 2;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int c = (l + 4 * i) * 64 + lane;
+        if (BKM) {
+            const int row = c >> 3, kc = (c & 7) ^ ((row >> 1) & 7);
+            vb[i] = (min(n0 + row, g.b_rows - 1) * b_ns + kc * 8) * 2;
+        } else {
+            const int kl = c / (BN / 8), rc = ((c % (BN / 8)) ^ glds_rx<BN>(kl)) * 8;
+            vb[i] = (kl * b_ks + min(n0 + rc, g.b_rows - 8)) * 2;
+        }
+    }
+    const int step_a = AK ? 128 : 64 * a_ks * 2, step_b = BKM ? 128 : 64 * b_ks * 2;
+    const int nk = g.K / 64;
+    const unsigned lds0 =
+        __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(fsm) + l * 1024);
+    auto issue = [&](int t, int stage) {
+        const unsigned dst = lds0 + stage * STAGE_B;
+        const int oa = __builtin_amdgcn_readfirstlane(t * step_a), ob = __builtin_amdgcn_readfirstlane(t * step_b);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) glds16(ra, dst + i * 4096, va[i], oa);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) glds16(rb, dst + BM * 128 + i * 4096, vb[i], ob);
+    };
+    // tile 0 alone first: the compute waves start on it while tiles 1 .. NS - 1 are being issued
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int s = 1; s < NS; ++s)
+        if (s < nk) issue(s, s);
+    int stage = 0;
+    for (int t = 0; t < nk; ++t) {
+        // tile t + 1 has landed once at most the younger tiles t + 2 .. t + NS - 1 are in flight
+        if (t + NS - 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * P) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + NS < nk) issue(t + NS, stage);
+        stage = stage + 1 == NS ? 0 : stage + 1;
+    }
+}
+
+// The order hipcc is asked to emit for group Q of a k-step (it otherwise sinks every read below the MFMAs, i.e. back to
+// "all reads, then all MFMAs" with the read latency exposed): one MFMA, the reads of one fragment, one MFMA, the reads
+// of the next fragment, ..., the group's remaining MFMAs.  A k-major fragment is one ds_read_b128, an r-major one two
+// ds_read_b64_tr_b16.  Fragment order as in gemm_role_compute: b0 a0 b1 .. b(TN-1) a1 .. a(TM-1).
+template <int TM, int TN, bool AK, bool BKM, int Q> __device__ __forceinline__ void role_interleave() {
+    constexpr int NR = TM + TN, RPG = (NR + TM - 1) / TM;
+    constexpr int r0 = Q * RPG, n = (NR - r0) < RPG ? ((NR - r0) > 0 ? NR - r0 : 0) : RPG;
+    static_assert(RPG <= 3, "at most three fragments per group");
+#define XGGM_FRAG_INS(r) ((((r) == 0 || ((r) >= 2 && (r) <= TN)) ? BKM : AK) ? 1 : 2)
+    if constexpr (n >= 1) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, XGGM_FRAG_INS(r0), 0);
+    }
+    if constexpr (n >= 2) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, XGGM_FRAG_INS(r0 + 1), 0);
+    }
+    if constexpr (n >= 3) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, XGGM_FRAG_INS(r0 + 2), 0);
+    }
+#undef XGGM_FRAG_INS
+    if constexpr (TN - n > 0) __builtin_amdgcn_sched_group_barrier(0x008, TN - n, 0);
+}
+
+template <int BM, int BN, bool AK, bool BKM, int NS>
+__device__ __forceinline__ void gemm_role_compute(const GemmArgs& g, bf16* fsm, float4_t (&acc)[BM / 32][BN / 32]) {
+    constexpr int TM = BM / 32, TN = BN / 32;  // 16 x 16 blocks per wave (wave tile BM / 2 x BN / 2)
+    constexpr int AEL = BM * 64, STAGE = (BM + BN) * 64;
+    constexpr int NR = TM + TN, RPG = (NR + TM - 1) / TM;  // fragments per k-step; fragments requested per group of TN MFMAs
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wid >> 1) * (BM / 2), wn = (wid & 1) * (BN / 2);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    bf16x8_t a0[TM], b0[TN], a1[TM], b1[TN];
+    // fragment r of a k-step in the order the MFMAs need them (i-major over the blocks): b0 a0 b1 .. b(TN-1) a1 .. a(TM-1)
+    auto rd = [&](bf16x8_t (&a)[TM], bf16x8_t (&b)[TN], const bf16* st, int ks, int r) {
+        if (r == 0) b[0] = glds_frag<BN, BKM>(st + AEL, wn, ks, lane);
+        else if (r == 1) a[0] = glds_frag<BM, AK>(st, wm, ks, lane);
+        else if (r <= TN) b[r - 1] = glds_frag<BN, BKM>(st + AEL, wn + (r - 1) * 16, ks, lane);
+        else a[r - TN] = glds_frag<BM, AK>(st, wm + (r - TN) * 16, ks, lane);
+    };
+    const int nk = g.K / 64;
+    __builtin_amdgcn_s_barrier();  // tile 0 has landed (the loaders waited for it)
+    asm volatile("" ::: "memory");
+    STAMP(g, 1);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) rd(a0, b0, fsm, 0, r);
+    int stage = 0;
+    for (int t = 0; t < nk; ++t) {
+        const bf16* sc = fsm + stage * STAGE;
+        stage = stage + 1 == NS ? 0 : stage + 1;
+        const bf16* sn = fsm + stage * STAGE;
+        // k-step 0 on (a0, b0); the fragments of k-step 1 are requested between the MFMAs
+#define XGGM_ROLE_GROUP(q, FA, FB, NA_, NB_, st, ks)                                                                   \
+    if constexpr ((q) < TM) {                                                                                         \
+        _Pragma("unroll") for (int r = (q) * RPG; r < ((q) + 1) * RPG && r < NR; ++r) rd(NA_, NB_, st, ks, r);         \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                \
+            acc[q][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j], FA[q], acc[q][j], 0, 0, 0);                    \
+        role_interleave<TM, TN, AK, BKM, (q)>();                                                                      \
+    }
+        XGGM_ROLE_GROUP(0, a0, b0, a1, b1, sc, 32)
+        XGGM_ROLE_GROUP(1, a0, b0, a1, b1, sc, 32)
+        XGGM_ROLE_GROUP(2, a0, b0, a1, b1, sc, 32)
+        XGGM_ROLE_GROUP(3, a0, b0, a1, b1, sc, 32)
+        // every fragment of tile t is in registers: its stage may be refilled; tile t + 1 is visible after the barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // k-step 1 on (a1, b1); the fragments of (t + 1, k-step 0) under them (after the last tile: stale bytes, unused)
+        XGGM_ROLE_GROUP(0, a1, b1, a0, b0, sn, 0)
+        XGGM_ROLE_GROUP(1, a1, b1, a0, b0, sn, 0)
+        XGGM_ROLE_GROUP(2, a1, b1, a0, b0, sn, 0)
+        XGGM_ROLE_GROUP(3, a1, b1, a0, b0, sn, 0)
+#undef XGGM_ROLE_GROUP
+    }
+    lds_barrier();  // the compute waves are done with LDS (the loaders have exited or are about to): free for the epilogue
+    STAMP(g, 2);
+}
+
 // K a whole number of k-tiles (no partial chunk to zero on the way, no tile to skip), r-major rows readable in
 // whole 16-byte chunks
 template <bool F8> __host__ __device__ __forceinline__ bool glds_ok(const GemmArgs& g) {
@@ -1193,6 +1370,68 @@ __device__ __forceinline__ void tile_of_position(int p, int gx, int gy, int M, i
     tile_n = cg * rw + (r - dr * wb);
 }
 
+// The same map for the grouped kernels with every per-problem constant computed on the HOST (set_tile_map): in-kernel
+// cycle stamps (tools/micro/kloop_pipe.hip, profiles/r04_experiments/kloop_role_prologue.txt) put the first LDS-DMA
+// instruction of a workgroup 3 000 cycles after kernel entry, 2 300 of them between "kernel arguments visible" and "tile
+// known": the rectangle shape, rh, rw and r / wb are four or five integer divisions, each a dependent chain of ~30
+// vector and scalar instructions (there is no scalar divide).  With the constants in the arguments the map is a dozen
+// scalar compares and ONE multiply-high per quotient (n / d = umulhi(n, ceil(2^32 / d)), exact while n * d < 2^32).
+__device__ __forceinline__ int div_magic(int n, int d, unsigned m) { return d == 1 ? n : (int)__umulhi((unsigned)n, m); }
+
+__device__ __forceinline__ void tile_from_map(const GemmArgs& g, int local, int nblk, int& tile_m, int& tile_n, int& bz) {
+    const GemmArgs::TileMap& tm = g.tm;
+    const int L = g.xcd_swizzle ? xcd_remap(local, nblk) : local;
+    bz = g.batch == 1 ? 0 : div_magic(L, tm.gxy, tm.m_gxy);
+    const int p = L - bz * tm.gxy;
+    if (!g.xcd_swizzle) {  // test hook (xggm_gemm_set_tile(| 0x100)): row-major tiles
+        tile_m = p / tm.gx;
+        tile_n = p - tile_m * tm.gx;
+        return;
+    }
+    const int band_sz = tm.rh * tm.gx;
+    int band = 0;
+#pragma unroll
+    for (int b = 1; b < 8; ++b)
+        if (b < tm.xr && p >= b * band_sz) band = b;
+    const int q = p - band * band_sz;
+    const int hb = min(tm.rh, tm.gy - band * tm.rh);
+    const int grp = tm.rw * hb;
+    int cg = 0;
+#pragma unroll
+    for (int c = 1; c < 8; ++c)
+        if (c < tm.xc && q >= c * grp) cg = c;
+    const int r = q - cg * grp;
+    const bool last = cg == tm.ncg - 1;
+    const int wb = last ? tm.wb_last : tm.rw;
+    const int dr = div_magic(r, wb, last ? tm.m_wbl : tm.m_rw);
+    tile_m = band * tm.rh + dr;
+    tile_n = cg * tm.rw + (r - dr * wb);
+}
+
+inline unsigned magic_of(int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); }
+inline void set_tile_map(GemmArgs& g, int bm, int bn) {
+    GemmArgs::TileMap& tm = g.tm;
+    tm.gx = ceil_div(g.N, bn);
+    tm.gy = ceil_div(g.M, bm);
+    tm.gxy = tm.gx * tm.gy;
+    // minimise xc * |A| + xr * |B| ~ xc * M + xr * N over xr * xc = 8
+    int xr = 1;
+    long best = 8l * g.M + g.N;
+    for (int r = 2; r <= 8; r *= 2) {
+        const long c = (long)(8 / r) * g.M + (long)r * g.N;
+        if (c < best) { best = c; xr = r; }
+    }
+    tm.xr = xr;
+    tm.xc = 8 / xr;
+    tm.rh = ceil_div(tm.gy, tm.xr);
+    tm.rw = ceil_div(tm.gx, tm.xc);
+    tm.ncg = ceil_div(tm.gx, tm.rw);
+    tm.wb_last = tm.gx - (tm.ncg - 1) * tm.rw;
+    tm.m_rw = magic_of(tm.rw);
+    tm.m_wbl = magic_of(tm.wb_last);
+    tm.m_gxy = magic_of(tm.gxy);
+}
+
 // waves per SIMD the register allocation must leave room for: a second (third, fourth) resident
 // workgroup runs its k-loop under this one's prologue and epilogue
 template <int BM, int BN> constexpr int min_waves() { return BM * BN >= 128 * 128 ? 2 : 3; }
@@ -1266,17 +1505,8 @@ __global__ __launch_bounds__(64 * W, (W == 8 ? 2 : min_waves<BM, BN>())) void ge
     for (int k = 1; k < MAX_GROUP; ++k)
         if (k < ga.nprob && b >= ga.tile_start[k]) { i = k; t0 = ga.tile_start[k]; t1 = ga.tile_start[k + 1]; }
     const GemmArgs g = ga.p[i];
-    const int local = g.xcd_swizzle ? xcd_remap(b - t0, t1 - t0) : b - t0;
-    const int gx = (g.N + BN - 1) / BN, gy = (g.M + BM - 1) / BM;
-    const int bz = g.batch == 1 ? 0 : local / (gx * gy);
-    const int lt = local - bz * gx * gy;
-    int tile_m, tile_n;
-    if (g.xcd_swizzle) {
-        tile_of_position(lt, gx, gy, g.M, g.N, tile_m, tile_n);
-    } else {
-        tile_m = lt / gx;
-        tile_n = lt - tile_m * gx;
-    }
+    int tile_m, tile_n, bz;
+    tile_from_map(g, b - t0, t1 - t0, tile_m, tile_n, bz);
     constexpr int DK = (BM * BN <= 64 * 64) ? 4 : 2;  // prefetch depth when an operand is k-major
     float4_t acc[BM / (8 * W)][BN / 32];
     if (glds_ok<false>(g)) {
@@ -1306,7 +1536,8 @@ template <int BM, int BN, int W = 4> int launch_grouped_tile(GroupArgs& ga, hipS
     int total = 0;
     for (int i = 0; i < ga.nprob; ++i) {
         ga.tile_start[i] = total;
-        total += ceil_div(ga.p[i].M, BM) * ceil_div(ga.p[i].N, BN) * ga.p[i].batch;
+        set_tile_map(ga.p[i], BM, BN);
+        total += ga.p[i].tm.gxy * ga.p[i].batch;
     }
     ga.tile_start[ga.nprob] = total;
     // Stages of the LDS-DMA k-loop (NS - 1 k-tiles in flight per workgroup).  On L2-hot operands (a micro-benchmark
@@ -1339,6 +1570,67 @@ template <int BM, int BN, int W = 4> int launch_grouped_tile(GroupArgs& ga, hipS
     return xggm_check_launch("xggm_gemm_grouped");
 }
 
+// The grouped launch on the role k-loop: 512 threads, waves 4-7 load (gemm_role_load), waves 0-3 compute and run the
+// epilogue of the four-wave tiles.  Every problem of the group must pass glds_ok (whole k-tiles).
+constexpr int ROLE_NS = 3;
+template <int BM, int BN> constexpr int role_min_waves() { return BM * BN >= 128 * 128 ? 2 : 4; }  // workgroups per CU x 2
+
+template <int BM, int BN>
+__global__ __launch_bounds__(512, (role_min_waves<BM, BN>())) void gemm_grouped_role_kernel(GroupArgs ga) {
+    extern __shared__ __attribute__((aligned(16))) bf16 fsm[];
+    const int b = blockIdx.x;
+    int i = 0, t0 = 0, t1 = ga.tile_start[1];
+#pragma unroll
+    for (int k = 1; k < MAX_GROUP; ++k)
+        if (k < ga.nprob && b >= ga.tile_start[k]) { i = k; t0 = ga.tile_start[k]; t1 = ga.tile_start[k + 1]; }
+    const GemmArgs g = ga.p[i];
+    int tile_m, tile_n, bz;
+    tile_from_map(g, b - t0, t1 - t0, tile_m, tile_n, bz);
+    STAMP(g, 0);
+    STAMP_HW(g);
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (wid >= 4) {
+        if (g.a_mode == 1) {
+            if (g.b_mode == 1) gemm_role_load<BM, BN, true, true, ROLE_NS>(g, tile_m, tile_n, bz, fsm, wid - 4);
+            else gemm_role_load<BM, BN, true, false, ROLE_NS>(g, tile_m, tile_n, bz, fsm, wid - 4);
+        } else {
+            if (g.b_mode == 1) gemm_role_load<BM, BN, false, true, ROLE_NS>(g, tile_m, tile_n, bz, fsm, wid - 4);
+            else gemm_role_load<BM, BN, false, false, ROLE_NS>(g, tile_m, tile_n, bz, fsm, wid - 4);
+        }
+        return;
+    }
+    float4_t acc[BM / 32][BN / 32];
+    if (g.a_mode == 1) {
+        if (g.b_mode == 1) gemm_role_compute<BM, BN, true, true, ROLE_NS>(g, fsm, acc);
+        else gemm_role_compute<BM, BN, true, false, ROLE_NS>(g, fsm, acc);
+    } else {
+        if (g.b_mode == 1) gemm_role_compute<BM, BN, false, true, ROLE_NS>(g, fsm, acc);
+        else gemm_role_compute<BM, BN, false, false, ROLE_NS>(g, fsm, acc);
+    }
+    gemm_finish<BM, BN, 4>(g, tile_m, tile_n, bz, fsm, acc);
+}
+
+template <int BM, int BN> int launch_grouped_role(GroupArgs& ga, hipStream_t stream) {
+    int total = 0;
+    for (int i = 0; i < ga.nprob; ++i) {
+        ga.tile_start[i] = total;
+        set_tile_map(ga.p[i], BM, BN);
+        total += ga.p[i].tm.gxy * ga.p[i].batch;
+    }
+    ga.tile_start[ga.nprob] = total;
+    ga.stages = ROLE_NS;
+    // the stages, or the staged epilogue's (BM / 2) x (BN + 4) floats of the same memory
+    constexpr size_t lds = std::max(ROLE_NS * sizeof(bf16) * (BM + BN) * 64, sizeof(float) * (BM / 2) * (BN + 4));
+    static bool attr_set = false;
+    if (lds > 48 * 1024 && !attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_grouped_role_kernel<BM, BN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_grouped_role_kernel<BM, BN>), dim3(total), dim3(512), lds, stream, ga);
+    return xggm_check_launch("xggm_gemm_grouped(role)");
+}
+
 // The grouped launch with e4m3 operands (forward products of both modality streams of one layer): every problem
 // is k-major on both sides, so there is ONE k-loop instantiation; the per-problem dequantisation factor
 // scale_a * scale_b is folded into alpha before the (shared) epilogue.
@@ -1351,17 +1643,8 @@ __global__ __launch_bounds__(64 * W, (W == 8 ? 2 : min_waves<BM, BN>())) void ge
     for (int k = 1; k < MAX_GROUP; ++k)
         if (k < ga.nprob && b >= ga.tile_start[k]) { i = k; t0 = ga.tile_start[k]; t1 = ga.tile_start[k + 1]; }
     GemmArgs g = ga.p[i];
-    const int local = g.xcd_swizzle ? xcd_remap(b - t0, t1 - t0) : b - t0;
-    const int gx = (g.N + BN - 1) / BN, gy = (g.M + BM - 1) / BM;
-    const int bz = g.batch == 1 ? 0 : local / (gx * gy);
-    const int lt = local - bz * gx * gy;
-    int tile_m, tile_n;
-    if (g.xcd_swizzle) {
-        tile_of_position(lt, gx, gy, g.M, g.N, tile_m, tile_n);
-    } else {
-        tile_m = lt / gx;
-        tile_n = lt - tile_m * gx;
-    }
+    int tile_m, tile_n, bz;
+    tile_from_map(g, b - t0, t1 - t0, tile_m, tile_n, bz);
     constexpr int DK = (BM * BN <= 64 * 64) ? 4 : 2;
     float4_t acc[BM / (8 * W)][BN / 32];
     // the dequantisation factor is fetched before the k-loop, not in front of the epilogue
@@ -1380,7 +1663,8 @@ template <int BM, int BN, int W = 4> int launch_grouped_fp8_tile(GroupArgs& ga, 
     int total = 0;
     for (int i = 0; i < ga.nprob; ++i) {
         ga.tile_start[i] = total;
-        total += ceil_div(ga.p[i].M, BM) * ceil_div(ga.p[i].N, BN) * ga.p[i].batch;
+        set_tile_map(ga.p[i], BM, BN);
+        total += ga.p[i].tm.gxy * ga.p[i].batch;
     }
     ga.tile_start[ga.nprob] = total;
     // k-major images of 128 bytes per row (128 e4m3 values), double buffered; the staged epilogue needs
@@ -1688,6 +1972,12 @@ template <typename T> int grouped(const xggm_gemm_problem* probs, int n, hipStre
     if (v == 5) return launch_grouped_tile<128, 256, 8>(ga, stream);
     if (v == 6) return launch_grouped_tile<256, 128, 8>(ga, stream);
 #endif
+    if (v == 7 || v == 8) {  // role k-loop: whole k-tiles in every problem, otherwise the four-wave tile of the same shape
+        bool ok = true;
+        for (int i = 0; i < n; ++i) ok = ok && glds_ok<false>(ga.p[i]);
+        if (ok) return v == 7 ? launch_grouped_role<128, 128>(ga, stream) : launch_grouped_role<128, 64>(ga, stream);
+        v = v == 7 ? 3 : 2;
+    }
     if (v == 4) return launch_grouped_tile<128, 128, 8>(ga, stream);
     if (v == 3) return launch_grouped_tile<128, 128>(ga, stream);
     if (v == 2) return launch_grouped_tile<128, 64>(ga, stream);
