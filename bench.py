@@ -60,12 +60,14 @@ def parse(argv=None):
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-timing", action="store_true")
+    p.add_argument("--cpu-warmup", type=int, default=3, help="CPU baseline: warm-up iterations per branch (BASELINE.md section 3)")
+    p.add_argument("--cpu-iters", type=int, default=10, help="CPU baseline: timed iterations per branch, the median is reported")
     p.add_argument("--no-loader", action="store_true", help="skip the loader-inclusive leg")
     p.add_argument("--no-ref-batch", action="store_true", help="skip the leg at the reference's own training batch size")
     p.add_argument("--wire", default="bf16", choices=["bf16", "f32"], help="gradient all-reduce dtype")
     p.add_argument("--zero1", type=int, default=None, help="1: shard the update over the ranks (reduce-scatter -> "
                    "BertAdam on the shard -> all-gather of the weights, stage by stage beside the next forward); "
-                   "default: on from 4 ranks, off below (see DESIGN.md section 6)")
+                   "default: off at every world size until an N >= 4 scaling record exists (DESIGN.md section 6)")
     p.add_argument("--seed", type=int, default=9595)
     a = p.parse_args(argv)
     if a.answers is None:
@@ -117,8 +119,10 @@ def spawn_ranks(args):
 
 # ------------------------------------------------------------------------------------------ model / data
 def zero1_default(world):
-    """sharded update (ZeRO-1) unless --zero1 says otherwise: from 4 ranks (see the comment in ``main``)"""
-    return world >= 4
+    """The sharded update (ZeRO-1) is OPT-IN (``--zero1 1``) at every world size: no scaling run on more than one real
+    GPU exists yet (SCALE_r03 is a skipped record) and the one measurement there is -- one rank on RCCL -- has it
+    slower (12.4 against 11.8 ms per iteration).  A default belongs to a measured N >= 4 record, not to a model."""
+    return False
 
 
 def build(args, device):
@@ -325,29 +329,77 @@ def cpu_baseline(args):
         for kind, kw in passes:
             O.train_pass(P, M, V, step, b, cfg, kind, 1e-6, 100, **kw)
 
-    def timed(b, branch, budget, max_iters):
-        t0 = time.perf_counter()
-        n = 0
-        while n < max_iters and (n == 0 or time.perf_counter() - t0 < budget):
+    def timed(b, branch, warm, iters):
+        """warm-up iterations at the measured batch, then `iters` timed ones; the median"""
+        for _ in range(warm):
             iteration(b, branch)
-            n += 1
-        return (time.perf_counter() - t0) / n, n
+        ts = []
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            iteration(b, branch)
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        return ts[len(ts) // 2], ts
 
     t_all = time.perf_counter()
     b2, b1 = batch_of(args.batch), batch_of(4)
-    iteration(b1, "rel")  # warm-up: thread pool, allocator
-    s_rel, n_rel = timed(b2, "rel", 6.0, 3)
-    s_node, n_node = timed(b2, "node", 6.0, 3)
-    s_c1, n_c1 = timed(b1, "node", 3.0, 3)
+    warm, iters = args.cpu_warmup, args.cpu_iters
+    s_rel, t_rel = timed(b2, "rel", warm, iters)
+    s_node, t_node = timed(b2, "node", warm, iters)
+    s_c1, t_c1 = timed(b1, "node", 1, 3)
     mix = 0.5 * (s_rel + s_node)
+    model, phys = cpu_info()
+    log("cpu baseline host: %s, %s physical cores, %d threads used" % (model, phys, cores))
     return {"value": round(args.batch / mix, 3), "unit": "samples/s", "cores": cores, "kind": "port",
-            "by_branch": {"rel": {"s_per_iteration": round(s_rel, 3), "samples_per_s": round(args.batch / s_rel, 3)},
-                          "node": {"s_per_iteration": round(s_node, 3), "samples_per_s": round(args.batch / s_node, 3)}},
+            "cpu_model": model, "physical_cores": phys,
+            "threads_note": "torch.set_num_threads(min(cores this process may run on, 16)): the GPU box gives one GPU a "
+                            "16-core share, more threads than that only thrash",
+            "by_branch": {"rel": {"s_per_iteration": round(s_rel, 3), "samples_per_s": round(args.batch / s_rel, 3),
+                                  "ms_per_pass": round(500 * s_rel, 1), "min_max_s": [round(t_rel[0], 3), round(t_rel[-1], 3)]},
+                          "node": {"s_per_iteration": round(s_node, 3), "samples_per_s": round(args.batch / s_node, 3),
+                                   "ms_per_pass": round(500 * s_node, 1), "min_max_s": [round(t_node[0], 3), round(t_node[-1], 3)]}},
             "c1_batch4": {"s_per_iteration": round(s_c1, 3), "samples_per_s": round(4 / s_c1, 3)},
-            "sample": "torch CPU oracle, fp32, full 9/5/5 model, A=%d, %s order: %d + %d iterations (plain pass + "
-                      "relation / node generation pass, each fwd+bwd+clip+BertAdam) at %d samples, %d at 4 samples "
-                      "(config C1); value = mean of the two branches; %.1f s in all"
-                      % (args.answers, args.order, n_rel, n_node, args.batch, n_c1, time.perf_counter() - t_all)}
+            "sample": "torch CPU oracle, fp32, full 9/5/5 model, A=%d, %s order: per branch %d warm-up + %d timed iterations "
+                      "at %d samples, MEDIAN (plain pass + relation / node generation pass, each fwd+bwd+clip+BertAdam); "
+                      "1 + 3 at 4 samples (config C1); value = mean of the two branch medians; %.1f s in all"
+                      % (args.answers, args.order, warm, iters, args.batch, time.perf_counter() - t_all)}
+
+
+def cpu_info():
+    """CPU model and physical core count of the host (lscpu when present, /proc/cpuinfo otherwise)"""
+    model, phys = "unknown", None
+    try:
+        import subprocess
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = {}
+        for ln in out.splitlines():
+            if ":" in ln:
+                k, v = ln.split(":", 1)
+                kv[k.strip()] = v.strip()
+        model = kv.get("Model name", model)
+        if "Core(s) per socket" in kv and "Socket(s)" in kv:
+            phys = int(kv["Core(s) per socket"]) * int(kv["Socket(s)"])
+    except Exception:
+        pass
+    if phys is None:
+        try:
+            cores = set()
+            pid = cid = None
+            for ln in open("/proc/cpuinfo"):
+                if ln.startswith("model name") and model == "unknown":
+                    model = ln.split(":", 1)[1].strip()
+                elif ln.startswith("physical id"):
+                    pid = ln.split(":", 1)[1].strip()
+                elif ln.startswith("core id"):
+                    cid = ln.split(":", 1)[1].strip()
+                elif not ln.strip():
+                    if cid is not None:
+                        cores.add((pid, cid))
+                    pid = cid = None
+            phys = len(cores) or None
+        except Exception:
+            pass
+    return model, phys
 
 
 def pmc_traffic(family):
@@ -360,7 +412,7 @@ def pmc_traffic(family):
            "xggm_ln_fwd_bf16": "ln_fwd_kernel", "xggm_attn_bwd_bf16": "attn_bwd", "xggm_attn_fwd_bf16": "attn_fwd",
            "xggm_aggregate_bf16": "aggregate_"}.get(family)
     if key is None:
-        return None
+        return None, None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
         tot = n = 0.0
         for name, r in json.load(open(path)).items():
@@ -368,8 +420,21 @@ def pmc_traffic(family):
                 tot += (r["read_bytes_per_launch"] + r["write_bytes_per_launch"]) * r["launches"]
                 n += r["launches"]
         if n:
-            return round(tot / n)
-    return None
+            return round(tot / n), os.path.relpath(path, ROOT)
+    return None, None
+
+
+def roofline_step(args, ms_step):
+    """The whole step against its own floors (SURVEY section 8d / BASELINE.md section 2): the batch-independent HBM
+    traffic of an iteration (bf16 weights read by forward, dgrad and the shadow write, fp32 gradients, the fused
+    clip + BertAdam streams, two passes: 17.7 GB) and its matrix work (65 GFLOP per sample), each at the nominal peak."""
+    hbm_ms = 17.7e9 / (PEAK_HBM_GBS * 1e9) * 1e3
+    mfma_ms = 65e9 * args.batch / (PEAK_BF16_TFLOPS * 1e12) * 1e3
+    floor = max(hbm_ms, mfma_ms)
+    return {"hbm_floor_ms": round(hbm_ms, 3), "mfma_floor_ms": round(mfma_ms, 3), "bound": "hbm" if hbm_ms >= mfma_ms else "mfma",
+            "frac_of_step": round(floor / ms_step, 4),
+            "note": "17.7 GB at 8 TB/s and 65 GFLOP per sample at 2.5 PFLOP/s dense bf16; the two overlap at best, so the "
+                    "larger one is the floor"}
 
 
 def log(msg):
@@ -388,13 +453,20 @@ def roofline_of(fam, prefer=None):
     f = fam[dom]
     if dom.startswith("xggm_gemm_"):
         ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
+        traffic, src = pmc_traffic(dom)
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(dom),
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                    "traffic_source": src and (src + " (PMC passes of an earlier run of this command, not of this run)"),
+                    "timing": "HIP events around the eager C-ABI launches of one un-captured iteration (plain + rel + node "
+                              "passes); the replayed graphs run the same kernels without the eager launch overhead: "
+                              "profiles/README.md gives the rocprofv3 durations",
                     "launches": f["n"], "avg_us": round(1000 * f["ms"] / f["n"], 2)}
     else:
         ach = f["bytes"] / (f["ms"] * 1e-3) / 1e9 if f["bytes"] else 0.0
+        traffic, src = pmc_traffic(dom)
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
-                    "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": pmc_traffic(dom),
+                    "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
+                    "traffic_source": src and (src + " (PMC passes of an earlier run of this command, not of this run)"),
                     "launches": f["n"], "avg_us": round(1000 * f["ms"] / f["n"], 2)}
     for k in ("xggm_bertadam_f32", "xggm_bertadam_ex", "xggm_aggregate_bf16"):  # the HBM-bound families: always with their rate
         if k in fam and fam[k]["ms"] > 0 and fam[k]["bytes"]:
@@ -556,7 +628,8 @@ def main():
         # an all-gather of the bf16 matrix weights (388 MB) -- the same bytes on the links as the all-reduce it replaces,
         # split into a reduce-scatter under the backward stages and a gather that now runs stage by stage under the NEXT
         # pass's forward graphs (engine.CapturedTrainer).  At 2 ranks half of the update is too little to pay for the two
-        # extra graph boundaries and the norm's scalar exchange (+0.45 ms per iteration measured at one rank): on from 4.
+        # extra graph boundaries and the norm's scalar exchange (+0.45 ms per iteration measured at one rank).  Opt-in
+        # (--zero1 1) at every world size until it has been measured on a real multi-GPU node: zero1_default.
         zero1 = bool(args.zero1) if args.zero1 is not None else zero1_default(world)
         enable_data_parallel(model, wire_dtype=torch.bfloat16 if args.wire == "bf16" else None, zero1=zero1)
     loader_parts = None
@@ -733,7 +806,7 @@ def main():
                        "hip_graph": not args.no_graph, "grad_wire": args.wire if (world > 1 or force_dp) else None},
             "ms_per_step_by_branch": per_branch, "ms_per_pass": per_pass, "value_with_loader": with_loader,
             "value_ref_batch": ref_batch,
-            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_step": roofline_step(args, ms_step), "kernels": kernels, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if world > 1 or force_dp:

@@ -231,10 +231,13 @@ def test_staged_gradient_exchange_of_the_data_parallel_engine_is_waited_for(brok
         assert r.returncode == 0 and "overlap=True: replicas identical: True" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-def test_bench_on_a_one_rank_rccl_group():
+@pytest.mark.parametrize("zero1", [0, 1])
+def test_bench_on_a_one_rank_rccl_group(zero1):
     """bench.py with XGGM_DP_FORCE=1: a real ``nccl`` (RCCL) process group of one rank, so the staged capture, the
     collectives on RCCL's stream between the replayed stage graphs and the watchdog thread are all live on one GPU;
-    the JSON line must come out with the data-parallel configuration."""
+    the JSON line must come out with the data-parallel configuration.  ``--zero1 1``: the sharded update's nccl
+    branches (reduce-scatter of the stages, ``gather_begin`` / ``take_pending`` under the next forward,
+    ``exchange_norm``) run on the one rank as well -- the opt-in path is exercised on RCCL before anyone measures it."""
     import json
     import os
     import subprocess
@@ -242,10 +245,12 @@ def test_bench_on_a_one_rank_rccl_group():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, XGGM_DP_FORCE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-                        "--no-kernel-timing"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+                        "--no-kernel-timing", "--no-ref-batch", "--zero1", str(zero1)], capture_output=True, text=True,
+                       timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["steps"] == 2 and line["value"] > 0 and line["config"]["hip_graph"] is True
+    assert line["config"]["zero1"] is bool(zero1) and line["config"]["backend"] == "nccl"
     assert set(line["ms_per_pass"]) == {"plain", "rel", "node"} and all(v > 0 for v in line["ms_per_pass"].values())
 
 
