@@ -150,6 +150,86 @@ def test_stage_ranges_tile_the_full_size_arena():
     assert [len(x) for x in st[:2]] == [0, 0] and sum(e - s_ for s_, e in st[2]) == sum(e - s_ for s_, e in active)
 
 
+def _full_size_arena():
+    """the flat-buffer layout of the full 9/5/5 model (names and sizes from oracle.shapes), without any tensor"""
+    from oracle import shapes
+    from xggm_amd import arena as A
+
+    class G:
+        pass
+
+    class FakeModel:
+        _enc_tail_prefixes = tuple("lxrt_encoder.model.bert.encoder.x_layers.4." + s
+                                   for s in ("visn_self_att.", "visn_inter.", "visn_output."))
+
+    class FakeParam:
+        def __init__(self, shape):
+            self.shape = tuple(shape)
+
+        def dim(self):
+            return len(self.shape)
+
+        def numel(self):
+            n = 1
+            for d in self.shape:
+                n *= d
+            return n
+
+    named = [(k, FakeParam(v)) for k, v in shapes.model_shapes(shapes.FULL, 2274).items()]
+    _, groups, info, total = A.layout(named, A.default_group_of, FakeModel)
+    fake = G()
+    fake.groups, fake.info, fake.total = groups, info, total
+    return fake
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_slices_tile_the_full_size_arena(world):
+    """the slicing of the sharded update on the REAL layout at 4 and 8 ranks (the other tests run it
+    on a 2048-element toy arena at world size 2).  For every backward stage of the five-stage cut: the matrix runs are
+    whole 256-element chunks, every run divides by the world size, the ranks' own slices tile it without gap or
+    overlap, every slice starts on a 32-element (64-byte bf16) border -- so a 4-element quad of the update kernel never
+    straddles two chunks of the e4m3 scale-id table, which is indexed by absolute element offset
+    (loss_optim.hip: w8_id[(elem0 + 4 i) >> 8]) -- and the batches, walked in reverse, visit the encoder in forward
+    order (what the staged all-gather under the next forward relies on)."""
+    from xggm_amd import arena as A
+    from xggm_amd.dist import ShardedUpdate, stage_ranges
+    fake = _full_size_arena()
+    active = [(g.start, g.end) for g in fake.groups.values()]
+    stages = stage_ranges(fake, active, dict(pair_cut=2, x_mid=3, emb_cut=True), 5)
+    pair_cut, x_mid = A.encoder_cuts(list(fake.info))
+    assert (pair_cut, x_mid) == (2, 3)
+    by_offset = sorted((o, k, n) for n, (o, k, g, atomic) in fake.info.items())
+    n_mat = n_own = 0
+    first_region = []
+    for rank in range(world):
+        z = ShardedUpdate.__new__(ShardedUpdate)  # the slicing logic only: no process group, no tensors
+        z.arena, z.world, z.rank = fake, world, rank
+        regions = []
+        for st in stages:
+            mats, vecs = z.split(st)
+            assert sum(e - s for s, e in mats + vecs) == sum(e - s for s, e in st)
+            for a, b in mats:
+                assert a % A.ALIGN_MAT == 0 and (b - a) % A.ALIGN_MAT == 0, (a, b)
+                o0, o1 = z.own((a, b))
+                c = (b - a) // world
+                assert (o0, o1) == (a + rank * c, a + (rank + 1) * c) and c * world == b - a
+                assert o0 % 32 == 0 and c % 32 == 0
+                if rank == 0:
+                    n_mat += b - a
+                n_own += o1 - o0
+            # forward regions of the encoder matrices this stage exchanges
+            rs = [A.region_of(n, pair_cut, x_mid) for o, k, n in by_offset
+                  if ".encoder." in n and any(a <= o < b for a, b in mats)]
+            regions.append((min(rs), max(rs)) if rs else None)
+        if rank == 0:
+            first_region = regions
+    assert n_own == n_mat and n_mat > 1.9e8  # the ranks' slices add up to every matrix element, 88 % of the model
+    # backward stage k + 1 holds LOWER forward regions than stage k: reversed = the order the next forward reads them
+    enc = [r for r in first_region if r is not None]
+    assert all(lo_next <= lo and hi_next <= lo for (lo, hi), (lo_next, hi_next) in zip(enc, enc[1:])), first_region
+    assert enc[0][1] == 4 and enc[-1][0] <= 1
+
+
 def _sharded_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -276,6 +356,22 @@ def test_sharded_update_bookkeeping_world2():
     for p in procs:
         p.join(60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_sharded_update_bookkeeping_world4():
+    """the same worker at FOUR ranks over gloo: quarter slices, the reduce-scatter emulation, the
+    scalar norm exchange, the all-gather of shadow weights and optimiser state from four owners"""
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(r for r, _ in res) == list(range(world)) and all(ok for _, ok in res), res
 
 
 def _sparse_table_worker(rank, world, port, q):

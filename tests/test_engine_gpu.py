@@ -168,7 +168,7 @@ def test_two_data_parallel_ranks_on_one_gpu_stay_identical():
     ds = [float(v) for v in re.findall(r"overlapped vs plain exchange: relative parameter difference ([0-9.e+-]+)", r.stdout)]
     assert len(ds) == 2 and max(ds) == 0.0, ds
     # the sharded update (ZeRO-1) on the wire arena: eager, two-graph and staged engines
-    assert r.stdout.count("bf16 weights identical on both ranks: True") == 3
+    assert r.stdout.count("bf16 weights identical on all 2 ranks: True") == 3
     assert "sharded == replicated update bit for bit (clip not binding), 3 iterations: True" in r.stdout
     assert "sharded vs replicated update, one pass with the clip binding" in r.stdout
     assert "fp8 forward: sharded == replicated update bit for bit (clip not binding), 3 iterations: True" in r.stdout
@@ -194,7 +194,7 @@ def test_staged_all_gather_of_the_sharded_update_is_waited_for(nowait):
                        env=env, cwd=root)
     ok = "sharded == replicated update bit for bit (clip not binding), 3 iterations: True"
     bad = "sharded == replicated update bit for bit (clip not binding), 3 iterations: False"
-    assert "bf16 weights identical on both ranks: True (forward cut into 4 + 1 graphs)" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "bf16 weights identical on all 2 ranks: True (forward cut into 4 + 1 graphs)" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     if nowait:
         # a CONTROL, not a requirement on the product: whether the unwaited forward really overtakes the delayed copies
         # depends on the box (it did on every box of the round); where it does not, the control says nothing
@@ -203,6 +203,25 @@ def test_staged_all_gather_of_the_sharded_update_is_waited_for(nowait):
         assert r.returncode != 0 and bad in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     else:
         assert r.returncode == 0 and ok in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_sharded_update_at_four_ranks_equals_the_replicated_one():
+    """FOUR ranks share the one GPU (gloo; the box allows six processes on the card) and run the
+    sharded update of tools/dp_rehearsal.py -- quarter slices of every matrix run, the staged all-gather from four
+    owners beside the next forward's graphs: the bf16 weights must be identical on all four ranks under the eager, the
+    two-graph and the staged engine, and three iterations must equal the replicated update bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", XGGM_REHEARSE_ONLY="sharded")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                        os.path.join(root, "tools", "dp_rehearsal.py")], capture_output=True, text=True, timeout=900,
+                       env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("bf16 weights identical on all 4 ranks: True") == 3, r.stdout[-2000:]
+    assert "sharded == replicated update bit for bit (clip not binding), 3 iterations: True" in r.stdout
 
 
 @pytest.mark.parametrize("broken", ["", "NOJOIN", "NOAFTER"])

@@ -153,12 +153,18 @@ def test_generator_against_reference_golden(tag, dt):
     if dt == F32:
         check_grad_summary(g, G, seed, 2e-3)
     else:
+        # GIN's scalar eps: d eps = sum over all B * N * H products dh * (A x) -- ONE cancelling sum.  xggm_agg_dot already
+        # takes the products and the sum in fp32 from the bf16 operands (fp32 mode: 1e-5 of the reference); what is
+        # left in bf16 mode is the noise the bf16-stored activations and upstream gradients carry INTO the sum, an
+        # ABSOLUTE floor set by the sum's mass, not by its value: measured (tools/exp_gin_eps.py, gen_gin36) 2.6 on the
+        # first layer's 179.9 (1.5 %) and 3.2 on the second layer's 9.9 (32 % of a sum that cancels twenty times
+        # harder).  So the bound for eps is absolute, against the generator's largest eps gradient: 3 %.
+        eps_ref = max([float(rn) for n, rn in zip(g["grad_names"], g["grad_norms"]) if str(n).endswith("eps")] or [0.0])
         for n, rn in zip(g["grad_names"], g["grad_norms"]):
-            # GIN's scalar eps: its gradient is ONE cancelling sum over all B*N*H products of
-            # bf16-rounded factors, so bf16 storage noise is O(30 %) of it; everything else 8 %
-            lim = 0.4 if str(n).endswith("eps") else 8e-2
-            if rn > 1e-3:
-                assert abs(float(G[str(n)].norm()) - rn) < lim * rn, (n, float(G[str(n)].norm()), rn)
+            if str(n).endswith("eps"):
+                assert abs(float(G[str(n)].norm()) - rn) < 3e-2 * eps_ref, (n, float(G[str(n)].norm()), rn, eps_ref)
+            elif rn > 1e-3:
+                assert abs(float(G[str(n)].norm()) - rn) < 8e-2 * rn, (n, float(G[str(n)].norm()), rn)
 
 
 @pytest.mark.parametrize("dt", [F32, BF16])

@@ -52,6 +52,8 @@ def run(overlap, rank, use_graph=True, iters=("rel", "node", "rel"), layers=(2, 
     run.n_fwd = g[5] if g is not None and g[0] == "staged" else 0  # forward graphs in front of the backward (sharded update)
     run.names = [(n, p.numel()) for n, p in m.named_parameters()]
     arena = m.arena()
+    run.info = dict(arena.info)
+    run.runs = list(arena.zero1.all_runs) if getattr(arena, "zero1", None) is not None else []
     if want == "shadow":  # what the GEMMs read: must be identical on every rank after the all-gather
         return arena.shadow.float().clone()
     # what a checkpoint writes: under the sharded update state_dict() first gathers the fp32 masters of the other ranks'
@@ -64,12 +66,22 @@ def run(overlap, rank, use_graph=True, iters=("rel", "node", "rel"), layers=(2, 
     return torch.cat([sd[n].detach().float().flatten() for n, _ in m.named_parameters()])
 
 
-def report(v, rank, tag):
-    other = [torch.empty_like(v) for _ in range(2)]
+def gather_all(v):
+    """v of every rank (world size 2 by default; XGGM_REHEARSE_ONLY=sharded also runs at 4 ranks sharing the GPU)"""
+    other = [torch.empty_like(v) for _ in range(dist.get_world_size())]
     dist.all_gather(other, v)
+    return other
+
+
+def all_equal(other):
+    return all(torch.equal(other[0], o) for o in other[1:])
+
+
+def report(v, rank, tag):
+    other = gather_all(v)
     if rank == 0:
-        d = (other[0] - other[1]).abs()
-        print("%s: max |rank0 - rank1| = %.3e" % (tag, float(d.max())), flush=True)
+        d = torch.stack([(other[0] - o).abs() for o in other[1:]]).max(0).values
+        print("%s: max |rank0 - rank r| = %.3e" % (tag, float(d.max())), flush=True)
         o, worst = 0, []
         for n, k in run.names:
             worst.append((float(d[o:o + k].max()), n))
@@ -141,9 +153,8 @@ def check_sharded_fp8(rank):
     gathered with the bf16 ones -- the training must equal the replicated fp8 run bit for bit (clip not binding)."""
     ref = run(True, rank, layers=(2, 2, 1), clip=1e9, fp8=True)
     got = run(True, rank, layers=(2, 2, 1), zero1=True, clip=1e9, fp8=True)
-    other = [torch.empty_like(got) for _ in range(2)]
-    dist.all_gather(other, got)
-    assert torch.equal(other[0], other[1]), "fp32 masters differ after gather_state (fp8)"
+    other = gather_all(got)
+    assert all_equal(other), "fp32 masters differ after gather_state (fp8)"
     same = bool(torch.equal(got, ref))
     if rank == 0:
         print("fp8 forward: sharded == replicated update bit for bit (clip not binding), 3 iterations: %s" % same, flush=True)
@@ -157,12 +168,21 @@ def check_sharded(rank):
     another order)."""
     for overlap, use_graph in ((False, False), (False, True), (True, True)):
         sh = run(overlap, rank, use_graph=use_graph, layers=(5, 4, 4), zero1=True, want="shadow")
-        other = [torch.empty_like(sh) for _ in range(2)]
-        dist.all_gather(other, sh)
-        same = bool(torch.equal(other[0], other[1]))
+        other = gather_all(sh)
+        same = bool(all_equal(other))
         if rank == 0:
-            print("sharded update overlap=%s graphs=%s: bf16 weights identical on both ranks: %s (forward cut into %d + 1 graphs)"
-                  % (overlap, use_graph, same, run.n_fwd), flush=True)
+            print("sharded update overlap=%s graphs=%s: bf16 weights identical on all %d ranks: %s (forward cut into %d + 1 graphs)"
+                  % (overlap, use_graph, dist.get_world_size(), same, run.n_fwd), flush=True)
+            if not same:  # which tensors, which ranks, where inside them
+                for r, o_ in enumerate(other[1:], 1):
+                    d = (other[0] != o_)
+                    for n, (off, k, g, atomic) in sorted(run.info.items(), key=lambda kv: kv[1][0]):
+                        nd = int(d[off:off + k].sum())
+                        if nd:
+                            idx = torch.nonzero(d[off:off + k]).flatten()
+                            print("   rank %d differs from rank 0 in %s (group %s, offset %d, %d elements): %d elements, first %d last %d"
+                                  % (r, n, g, off, k, nd, int(idx[0]), int(idx[-1])), flush=True)
+                print("   runs:", sorted(run.runs), flush=True)
         assert same
         # with the staged exchange the forward is cut too: the all-gather of stage i + 1 runs beside forward graph i
         assert run.n_fwd == (4 if overlap and use_graph else 0), run.n_fwd
@@ -177,9 +197,8 @@ def check_sharded(rank):
     # arg-max amplifies an ulp unpredictably).
     ref = run(True, rank, layers=(5, 4, 4), clip=1e9)
     got = run(True, rank, layers=(5, 4, 4), zero1=True, clip=1e9)
-    other = [torch.empty_like(got) for _ in range(2)]
-    dist.all_gather(other, got)
-    assert torch.equal(other[0], other[1]), "fp32 masters differ after gather_state"
+    other = gather_all(got)
+    assert all_equal(other), "fp32 masters differ after gather_state"
     same = bool(torch.equal(got, ref))
     if rank == 0:
         print("sharded == replicated update bit for bit (clip not binding), 3 iterations: %s" % same, flush=True)
@@ -210,9 +229,7 @@ def check(rank, layers, modes=(False, True)):
         v = run(overlap, rank, layers=layers)
         if os.environ.get("XGGM_DEBUG_RUNS"):
             print("rank %d overlap=%s clip norms %s" % (rank, overlap, " ".join("%.6f" % x for x in run.norms)), flush=True)
-        other = [torch.empty_like(v) for _ in range(2)]
-        dist.all_gather(other, v)
-        same = bool(torch.equal(other[0], other[1]))
+        same = bool(all_equal(gather_all(v)))
         out[overlap] = v
         if rank == 0:
             print("layers %s overlap=%s: replicas identical: %s, |params| = %.6f" % (layers, overlap, same, float(v.double().norm())),

@@ -422,6 +422,25 @@ __device__ __forceinline__ bf16x8_t fast_frag(const bf16* lds, int row0, int ks,
     }
 }
 
+// e4m3 operands on the block-scaled matrix instruction.  v_mfma_f32_16x16x32_fp8_fp8 runs at the bf16 rate
+// (MI355X_MICROARCH.md, Matrix cores); v_mfma_scale_f32_16x16x128_f8f6f4 with e4m3 operands does 4 x the K in twice the
+// cycles: twice the bf16 rate, and ONE instruction where the plain form needs four.  A lane supplies 32 bytes per operand:
+// row (lane & 15), k-bytes [32 q, 32 q + 32) with q = lane >> 4 (tools/micro/mfma_scale_check.hip: exact against the
+// host's dot products with this assignment; a reduction only needs A and B to agree on it).  In the k-major LDS image
+// (128-byte rows, 16-byte chunks XORed by (row >> 1) & 7) that is chunks 2 q and 2 q + 1 of the row: two ds_read_b128.
+// The block scales are E8M0 bytes, 0x7f = 2^0: the per-tensor scales stay fp32 factors of the epilogue.
+typedef int int8v_t __attribute__((ext_vector_type(8)));
+typedef int int4w_t __attribute__((ext_vector_type(4)));
+template <int R> __device__ __forceinline__ int8v_t frag_e4m3(const bf16* lds, int row0, int lane) {
+    const int fr = lane & 15, fq = lane >> 4, row = row0 + fr, s = (row >> 1) & 7;
+    const int4w_t lo = *reinterpret_cast<const int4w_t*>(lds + row * 64 + (((2 * fq) ^ s) << 3));
+    const int4w_t hi = *reinterpret_cast<const int4w_t*>(lds + row * 64 + (((2 * fq + 1) ^ s) << 3));
+    return (int8v_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+__device__ __forceinline__ float4_t mfma_e4m3_k128(const int8v_t& first, const int8v_t& second, const float4_t& c) {
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(first, second, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+}
+
 // workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also waits
 // vmcnt(0), i.e. for the global prefetches that are supposed to stay in flight across it.
 __device__ __forceinline__ void lds_barrier() {
@@ -882,6 +901,17 @@ __device__ __forceinline__ void gemm_kloop(const GemmArgs& g, int tile_m, int ti
             // tile; running the two wave groups half an iteration apart with a barrier per half -- slower still,
             // 22.2 k: the iteration is a LATENCY chain (barrier, fragment reads, dependent MFMAs, writes), not an LDS
             // throughput limit, and a second barrier lengthens it.)
+            if constexpr (F8) {  // one 128-deep step per k-tile on the block-scaled instruction
+                int8v_t a8[TM], b8[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a8[i] = frag_e4m3<BM>(Ac, wm + i * 16, lane);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b8[j] = frag_e4m3<BN>(Bc, wn + j * 16, lane);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma_e4m3_k128(b8[j], a8[i], acc[i][j]);
+            } else
 #pragma unroll
             for (int ks = 0; ks < 64; ks += 32) {
                 bf16x8_t a[TM], b[TN];
@@ -1066,6 +1096,17 @@ __device__ __forceinline__ void gemm_kloop_glds(const GemmArgs& g, int tile_m, i
         TRACE(g, 19 + 4 * t);
         const bf16* Ac = fsm + stage * STAGE;
         const bf16* Bc = Ac + AEL;
+        if constexpr (F8) {  // one 128-deep step per k-tile on the block-scaled instruction
+            int8v_t a8[TM], b8[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a8[i] = frag_e4m3<BM>(Ac, wm + i * 16, lane);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b8[j] = frag_e4m3<BN>(Bc, wn + j * 16, lane);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma_e4m3_k128(b8[j], a8[i], acc[i][j]);
+        } else
 #pragma unroll
         for (int ks = 0; ks < 64; ks += 32) {
             bf16x8_t a[TM], b[TN];

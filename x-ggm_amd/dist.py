@@ -24,6 +24,31 @@ import torch.distributed as dist
 DEFAULT_BUCKET = 32 * 1024 * 1024  # elements (128 MB fp32 / 64 MB bf16 on the wire)
 
 
+class _Done:
+    """work handle of a collective that has already completed"""
+
+    def wait(self):
+        return True
+
+
+def all_reduce_sum(t, group, backend, world, async_op=False):
+    """SUM all-reduce whose result is the SAME BITS on every rank.  RCCL gives that (every element is reduced along one
+    fixed path and the result broadcast).  gloo does not once more than two ranks add floating-point numbers: its ring
+    accumulates in a rank-dependent order, and the four-rank rehearsal (tools/dp_rehearsal.py, four processes on one
+    GPU) found a few elements per bias / LayerNorm / embedding tensor an ulp apart between replicas after ONE update.
+    gloo is this package's test transport, so there the sum is taken in rank order from an all-gather: identical on
+    every rank, accumulated in fp32 and rounded once.  Two ranks: a + b == b + a, the plain all-reduce stays."""
+    if backend == "nccl" or world <= 2:
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t.contiguous(), group=group)
+    acc = parts[0].to(torch.float32, copy=True)
+    for p in parts[1:]:
+        acc += p
+    t.copy_(acc)
+    return _Done() if async_op else None
+
+
 def ranges_to_buckets(ranges, bucket_elems=DEFAULT_BUCKET):
     """split [(start, end)] element ranges into chunks of at most ``bucket_elems``."""
     out = []
@@ -147,7 +172,7 @@ class GradSync:
             rows = ops.gather_rows(g, ids_all)
         else:
             rows = g[ids_all].to(torch.bfloat16)
-        work = dist.all_reduce(rows, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        work = all_reduce_sum(rows, self.group, self.backend, self.world, async_op=True)
         return (rows, ids_all, work)
 
     def _finish_table(self, h):
@@ -207,8 +232,8 @@ class GradSync:
         exchange that started before the backward stage had written its gradients) could not be caught."""
         if self.backend != "nccl" and t.is_cuda:
             st = t.clone()
-            return dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group, async_op=True), (t, st)
-        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None
+            return all_reduce_sum(st, self.group, self.backend, self.world, async_op=True), (t, st)
+        return all_reduce_sum(t, self.group, self.backend, self.world, async_op=True), None
 
     def _finish_inplace(self, handle):
         for wk in handle[2]:
@@ -429,7 +454,7 @@ class ShardedUpdate(GradSync):
 
     def exchange_norm(self, sq):
         if self.world > 1 or self.force:
-            dist.all_reduce(sq, op=dist.ReduceOp.SUM, group=self.group)
+            all_reduce_sum(sq, self.group, self.backend, self.world)
             f8 = getattr(self.arena, "fp8", None)
             if f8 is not None:
                 # fp8 forward: every rank quantises only its slices of the weights and records their maxima; the scale of
