@@ -214,6 +214,11 @@ def test_sharded_slices_tile_the_full_size_arena(world):
                 c = (b - a) // world
                 assert (o0, o1) == (a + rank * c, a + (rank + 1) * c) and c * world == b - a
                 assert o0 % 32 == 0 and c % 32 == 0
+                # runs of encoder matrices carry e4m3 copies under the fp8 forward: xggm_bertadam_ex takes the scale-table
+                # entry per 256-element chunk and per WAVE (elem0 % 256 == 0 is a checked argument), so there a slice must
+                # be whole chunks -- every encoder matrix is a multiple of 8 * 256 elements, hence so is every run
+                if any(G.name in ("enc_main", "enc_tail") and G.start <= a and b <= G.vec_start for G in fake.groups.values()):
+                    assert o0 % A.ALIGN_MAT == 0 and c % A.ALIGN_MAT == 0, (a, b, world)
                 if rank == 0:
                     n_mat += b - a
                 n_own += o1 - o0

@@ -314,6 +314,18 @@ __global__ __launch_bounds__(NT) void bertadam_kernel(AdamArgs a) {
     for (int64_t b0 = (int64_t)blockIdx.x * NT; b0 < n4; b0 += stride * UNR) {
         const int64_t i0 = b0 + threadIdx.x;
         f4 p[UNR], g[UNR], m[UNR], v[UNR];
+        // e4m3 copy: the chunk's scale-table entry and its scale are fetched FIRST -- the oldest loads of the iteration,
+        // so waiting for them (to issue the dependent scale load) leaves the streams below in flight, and both are long
+        // back when the packed bytes are stored (they sat behind the update's arithmetic before: a dependent L2 round
+        // trip or two at the end of every step)
+        unsigned w8id[UNR];
+        if (a.shadow8) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int64_t iw = (b0 + (threadIdx.x & ~63)) + u * stride;
+                w8id[u] = iw < n4 ? a.w8_id[(a.elem0 + 4 * iw) >> 8] : 0u;
+            }
+        }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int64_t i = i0 + u * stride;
@@ -336,6 +348,11 @@ __global__ __launch_bounds__(NT) void bertadam_kernel(AdamArgs a) {
                     v[u] = reinterpret_cast<const f4*>(a.v)[i];
                 }
             }
+        }
+        float w8q[UNR];
+        if (a.shadow8) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) w8q[u] = w8id[u] ? a.w8_qscale[w8id[u]] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
@@ -368,10 +385,9 @@ __global__ __launch_bounds__(NT) void bertadam_kernel(AdamArgs a) {
             }
             if (a.shadow8) {
                 // chunk of lane 0 == chunk of every lane of the wave; lanes past the end contribute nothing
-                const int64_t iw = (b0 + (threadIdx.x & ~63)) + u * stride;
-                const unsigned id = iw < n4 ? a.w8_id[(a.elem0 + 4 * iw) >> 8] : 0u;
+                const unsigned id = w8id[u];
                 if (id) {
-                    const float q = a.w8_qscale[id];
+                    const float q = w8q[u];
                     float mx = 0.f;
                     if (on) {
                         mx = fmaxf(fmaxf(fabsf(p[u][0]), fabsf(p[u][1])), fmaxf(fabsf(p[u][2]), fabsf(p[u][3])));
@@ -406,30 +422,43 @@ __global__ __launch_bounds__(NT) void bertadam_kernel(AdamArgs a) {
 // history -> the range halves when `shrink` (values have shrunk a lot; still no overflow, finer subnormals) or stays
 // (weights).  qscale <= 0 marks an entry that has not been calibrated: its producers quantise with 1 and record
 // every maximum, and it stays uncalibrated until something was recorded.
-__global__ void fp8_scale_update_kernel(float* amax, float* hist, float* qscale, float* dscale, int64_t* pos, int n,
-                                        int hist_len, float margin, int shrink, int bump, int slots) {
-    const int i = threadIdx.x;
+// One workgroup of 16 waves; a wave takes FOUR entries per round with all eight loads in flight together (lane s reads
+// slot s of an entry's maximum, lane j element j of its history: coalesced, reduced with wave_max).  The first form --
+// one thread per entry walking its 64 slots -- took 12.8 us per launch, five launches per iteration of the fp8 step.
+__global__ __launch_bounds__(1024) void fp8_scale_update_kernel(float* amax, float* hist, float* qscale, float* dscale, int64_t* pos,
+                                                                int n, int hist_len, float margin, int shrink, int bump, int slots) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int slot = (int)(*pos % hist_len);
-    if (i < n) {
-        const float q0 = qscale[i];
-        float am = 0.f;
-        for (int s = 0; s < slots; ++s) {  // the entry's maximum is spread over `slots` floats (producers' atomics)
-            am = fmaxf(am, amax[(int64_t)i * slots + s]);
-            amax[(int64_t)i * slots + s] = 0.f;
+    constexpr int E = 4;
+    for (int i0 = wid * E; i0 < n; i0 += 16 * E) {
+        float am[E], h[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = i0 + e;
+            am[e] = (i < n && lane < slots) ? amax[(int64_t)i * slots + lane] : 0.f;
+            h[e] = (i < n && lane < hist_len) ? hist[(int64_t)i * hist_len + lane] : 0.f;
         }
-        hist[(int64_t)i * hist_len + slot] = am;
-        float m = 0.f;
-        for (int j = 0; j < hist_len; ++j) m = fmaxf(m, hist[(int64_t)i * hist_len + j]);
-        float q = q0;
-        if (m > 0.f) q = 448.f / (m * margin);
-        else if (q0 > 0.f && shrink && slot == hist_len - 1) q = fminf(q0 * 2.f, 1.0995e12f);
-        if (q > 0.f) {
-            qscale[i] = q;
-            dscale[i] = 1.f / q;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = i0 + e;
+            if (i < n && lane < slots) amax[(int64_t)i * slots + lane] = 0.f;
+            const float a = wave_max(am[e]);
+            const float m = wave_max(lane == slot ? a : h[e]);  // the history with this step's maximum in its slot
+            if (i < n && lane == 0) {
+                hist[(int64_t)i * hist_len + slot] = a;
+                const float q0 = qscale[i];
+                float q = q0;
+                if (m > 0.f) q = 448.f / (m * margin);
+                else if (q0 > 0.f && shrink && slot == hist_len - 1) q = fminf(q0 * 2.f, 1.0995e12f);
+                if (q > 0.f) {
+                    qscale[i] = q;
+                    dscale[i] = 1.f / q;
+                }
+            }
         }
     }
-    __syncthreads();  // every thread has read *pos
-    if (bump && i == 0) *pos += 1;
+    __syncthreads();  // every wave has read *pos
+    if (bump && threadIdx.x == 0) *pos += 1;
 }
 
 // lr_scale = warmup_linear(step / t_total, warmup); step += 1   (t_total <= 0: scale = 1)

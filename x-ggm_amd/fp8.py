@@ -155,8 +155,11 @@ class Fp8State:
         """(e4m3 copy, reciprocal scale) of activation ``x``: from its producer when one registered it, else through
         the quantiser under site ``key``"""
         hit = self._q8.get(x.data_ptr())
-        if hit is not None and hit[0].shape == x.shape:
-            return hit[0], self.dscale[hit[1]:hit[1] + 1]
+        if hit is not None and hit[0].numel() == x.numel() and x.is_contiguous():
+            # same bytes, possibly another view of them: the embedding kernels hand out [B, T, H], the first layer's
+            # products ask with [B * T, H] (the shape test that stood here sent both streams of every pass through
+            # the stand-alone quantiser: 4 launches of 13 us per iteration, tools/exp_fp8_quantize_sites.py)
+            return hit[0].view(x.shape), self.dscale[hit[1]:hit[1] + 1]
         (q, amax), e = self.emit(key)
         x8 = ops.quantize_fp8(x if x.is_contiguous() else x.contiguous(), qscale=q, amax=amax).view(torch.uint8)
         self.put(x, x8, e)

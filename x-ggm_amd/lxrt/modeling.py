@@ -355,8 +355,6 @@ class LXRTEncoder(nn.Module):
         # the vector region are the only gradients that are final last: the exposed tail of the exchange), after
         # the first two layer pairs, before the first and before the second-to-last cross-modality layer.
         rt = runtime_of(self)
-        if rt.arena.fp8 is not None:
-            rt.arena.fp8.begin_forward()
         cutting = rt.cut_enabled and torch.is_grad_enabled()
         pair_cut = 2 if n_pair >= 4 else None
         x_mid = self.num_x_layers - 2 if self.num_x_layers >= 4 else None
@@ -477,6 +475,12 @@ class LXRTModel(BertPreTrainedModel):
                 torch.float32)) * -10000.0
         else:
             extended_visual_attention_mask = None
+        # fp8 forward: the producers' e4m3 copies of THIS forward start here -- in front of the embeddings, whose kernels
+        # write the first two (begun inside the encoder, as it was, the registry was cleared right after they had
+        # registered, and both streams of every pass went through the stand-alone quantiser)
+        rt = runtime_of(self)
+        if rt.arena.fp8 is not None:
+            rt.arena.fp8.begin_forward()
         embedding_output = self.embeddings(input_ids, token_type_ids)
         lang_feats, visn_feats = self.encoder(embedding_output, extended_attention_mask, visn_feats=visual_feats,
                                               visn_attention_mask=extended_visual_attention_mask)
