@@ -520,6 +520,10 @@ typedef struct xggm_adam_args {
     int w8_amax_slots; /* entry id of w8_amax starts at w8_amax[id * max(1, w8_amax_slots)]; see xggm_gemm_problem.amax_slots */
 } xggm_adam_args;
 int xggm_bertadam_ex(const xggm_adam_args* args, xggm_stream_t stream);
+/* the same update for n spans (HOST array; every arena group a pass updates, or a rank's slices of them under the sharded
+ * update) in ONE launch: src/lxrt/optimization.py:159-193 loops over param_groups, each span carries its own group's
+ * lr / schedule value / weight decay.  All spans of a call share the gradient type (g_bf16). */
+int xggm_bertadam_multi(const xggm_adam_args* args, int n, xggm_stream_t stream);
 /* *out += sum g^2 of a flat bf16 range (the wire arena), same fixed summation order as xggm_sqnorm_f32 */
 int xggm_sqnorm_bf16(const void* g, int64_t n, float* out, float* ws, xggm_stream_t stream);
 /* *lr_scale = warmup_linear(*step / t_total, warmup); *step += 1 (optimization.py:42-48) */

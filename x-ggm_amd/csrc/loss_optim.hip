@@ -291,11 +291,23 @@ struct AdamArgs {
     int w8_slots;               // floats every w8_amax entry is spread over (>= 1)
 };
 
+// One element of src/lxrt/optimization.py:159-193 (no bias correction, decoupled weight decay) with the shape of every
+// multiply-add PINNED: which products fuse into an fma is otherwise the compiler's choice per instantiation under
+// -ffp-contract=fast (the backend fuses whatever the source says), and the fp32- and the bf16-gradient instantiation of
+// this template then differed in the last bit of v and p.  __fmul_rn / __fadd_rn are rounded on their own and never
+// fused; the three fmaf are the fusions wanted.
+__device__ __forceinline__ void adam_update(float& p, float& m, float& v, float gk, float b1, float b2, float eps, float wd, float lr) {
+    m = __fmaf_rn(m, b1, __fmul_rn(1.f - b1, gk));
+    v = __fmaf_rn(v, b2, __fmul_rn(__fmul_rn(1.f - b2, gk), gk));
+    const float upd = __fadd_rn(m / __fadd_rn(sqrtf(v), eps), __fmul_rn(wd, p));
+    p = __fmaf_rn(-lr, upd, p);
+}
+
 // One float4 of each of p, g, m, v per step; UNR independent float4 quadruples per thread and
 // iteration (loads issued before any use).  g is read once and m, v, shadow are not re-read before the
 // next step: non-temporal accesses keep them from displacing the weights' bf16 shadow in L2/MALL.
 template <int UNR, bool NTMP, bool GB16>
-__global__ __launch_bounds__(NT) void bertadam_kernel(AdamArgs a) {
+__device__ __forceinline__ void bertadam_body(const AdamArgs& a, const int blk, const int nblk) {
     float coef = 1.f;
     if (a.sqnorm) {
         const float total = sqrtf(*a.sqnorm);
@@ -306,12 +318,12 @@ __global__ __launch_bounds__(NT) void bertadam_kernel(AdamArgs a) {
     const int64_t n4 = a.n >> 2;
     typedef float __attribute__((ext_vector_type(4))) f4;
     typedef short __attribute__((ext_vector_type(4))) s4;
-    const int64_t stride = (int64_t)gridDim.x * NT;
+    const int64_t stride = (int64_t)nblk * NT;
     const int lane = threadIdx.x & 63;
     // every wave handles 64 consecutive float4 = one 256-element chunk of the arena per unrolled step, so the
     // chunk's scale-table entry is wave-uniform.  The trip count is made block-uniform (i0 of thread 0) so that
     // the wave reduction below runs with all lanes present; lanes beyond n4 only idle.
-    for (int64_t b0 = (int64_t)blockIdx.x * NT; b0 < n4; b0 += stride * UNR) {
+    for (int64_t b0 = (int64_t)blk * NT; b0 < n4; b0 += stride * UNR) {
         const int64_t i0 = b0 + threadIdx.x;
         f4 p[UNR], g[UNR], m[UNR], v[UNR];
         // e4m3 copy: the chunk's scale-table entry and its scale are fetched FIRST -- the oldest loads of the iteration,
@@ -361,11 +373,11 @@ __global__ __launch_bounds__(NT) void bertadam_kernel(AdamArgs a) {
             if (on) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float gk = g[u][k] * coef;
-                    m[u][k] = m[u][k] * a.b1 + (1.f - a.b1) * gk;
-                    v[u][k] = v[u][k] * a.b2 + (1.f - a.b2) * gk * gk;
-                    const float upd = m[u][k] / (sqrtf(v[u][k]) + a.eps) + a.wd * p[u][k];
-                    p[u][k] -= lr * upd;
+                    float pk = p[u][k], mk = m[u][k], vk = v[u][k];
+                    adam_update(pk, mk, vk, __fmul_rn(g[u][k], coef), a.b1, a.b2, a.eps, a.wd, lr);
+                    p[u][k] = pk;
+                    m[u][k] = mk;
+                    v[u][k] = vk;
                 }
                 if (NTMP) __builtin_nontemporal_store(p[u], reinterpret_cast<f4*>(a.p) + i);
                 else reinterpret_cast<f4*>(a.p)[i] = p[u];
@@ -397,23 +409,44 @@ __global__ __launch_bounds__(NT) void bertadam_kernel(AdamArgs a) {
                     // floating-point format: a stale smaller range costs nothing until values shrink by orders of
                     // magnitude, see xggm_fp8_scale_update): a few per cent of the waves issue the atomic.
                     mx = wave_max(mx);
-                    if (lane == 0 && mx > 0.75f * 448.f / q) amax_record(a.w8_amax + (int64_t)id * a.w8_slots, a.w8_slots, (int)blockIdx.x, mx);
+                    if (lane == 0 && mx > 0.75f * 448.f / q) amax_record(a.w8_amax + (int64_t)id * a.w8_slots, a.w8_slots, blk, mx);
                 }
             }
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {  // (ranges with an e4m3 copy are multiples of 256: no tail there)
+    if (blk == 0 && threadIdx.x < (a.n & 3)) {  // (ranges with an e4m3 copy are multiples of 256: no tail there)
         const int64_t i = (n4 << 2) + threadIdx.x;
         const float gi = GB16 ? __bfloat162float(reinterpret_cast<const bf16*>(a.g)[i]) : reinterpret_cast<const float*>(a.g)[i];
-        const float gk = gi * coef;
-        const float m = a.m[i] * a.b1 + (1.f - a.b1) * gk;
-        const float v = a.v[i] * a.b2 + (1.f - a.b2) * gk * gk;
-        const float p = a.p[i] - lr * (m / (sqrtf(v) + a.eps) + a.wd * a.p[i]);
+        float p = a.p[i], m = a.m[i], v = a.v[i];
+        adam_update(p, m, v, __fmul_rn(gi, coef), a.b1, a.b2, a.eps, a.wd, lr);
         a.m[i] = m;
         a.v[i] = v;
         a.p[i] = p;
         if (a.shadow) a.shadow[i] = __float2bfloat16(p);
     }
+}
+
+template <int UNR, bool NTMP, bool GB16>
+__global__ __launch_bounds__(NT) void bertadam_kernel(AdamArgs a) {
+    bertadam_body<UNR, NTMP, GB16>(a, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// several spans (the arena groups a pass updates, or a rank's slices of them) in ONE launch: a workgroup finds its span
+// in the prefix table and runs the same body on its share of that span's grid.  Four launches per pass before; every
+// launch boundary leaves the chip draining one update's tail while the next one's first loads have not been issued.
+constexpr int ADAM_MULTI = 8;
+struct AdamMulti {
+    AdamArgs a[ADAM_MULTI];
+    int blk0[ADAM_MULTI + 1];
+    int n;
+};
+template <int UNR, bool NTMP, bool GB16>
+__global__ __launch_bounds__(NT) void bertadam_multi_kernel(AdamMulti am) {
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < ADAM_MULTI; ++k)
+        if (k < am.n && (int)blockIdx.x >= am.blk0[k]) j = k;
+    bertadam_body<UNR, NTMP, GB16>(am.a[j], (int)blockIdx.x - am.blk0[j], am.blk0[j + 1] - am.blk0[j]);
 }
 
 // Delayed scaling of the e4m3 operands (weights and activation sites share one table).  Producers record the
@@ -654,6 +687,44 @@ extern "C" int xggm_bertadam_ex(const xggm_adam_args* x, hipStream_t st) {
                x->b1, x->b2, x->eps, x->weight_decay, (unsigned char*)x->shadow8, x->w8_id, x->w8_qscale, x->w8_amax, x->elem0,
                x->g_scale > 0.f ? x->g_scale : 1.f, x->w8_amax_slots > 1 ? x->w8_amax_slots : 1};
     return launch_adam(a, x->g_bf16 != 0, st);
+}
+
+namespace {
+int adam_args_of(const xggm_adam_args* x, AdamArgs& a) {
+    XGGM_REQUIRE(x && x->p && x->g && x->m && x->v && x->n > 0, "xggm_bertadam: bad arguments");
+    XGGM_REQUIRE((reinterpret_cast<uintptr_t>(x->p) | reinterpret_cast<uintptr_t>(x->m) | reinterpret_cast<uintptr_t>(x->v)) % 16 == 0 &&
+                     reinterpret_cast<uintptr_t>(x->g) % (x->g_bf16 ? 8 : 16) == 0,
+                 "xggm_bertadam: pointers must be 16-byte aligned (bf16 gradients: 8)");
+    XGGM_REQUIRE(!x->shadow_bf16 || reinterpret_cast<uintptr_t>(x->shadow_bf16) % 8 == 0, "xggm_bertadam: shadow misaligned");
+    XGGM_REQUIRE(!x->shadow8 || (x->w8_id && x->w8_qscale && x->w8_amax && x->elem0 % 256 == 0 && x->n % 4 == 0 &&
+                                 reinterpret_cast<uintptr_t>(x->shadow8) % 4 == 0),
+                 "xggm_bertadam: the e4m3 copy needs the chunk table, the scale table and a range that starts on a "
+                 "256-element chunk of the arena");
+    a = AdamArgs{x->p, x->g, x->m, x->v, (bf16*)x->shadow_bf16, x->n, x->sqnorm, x->max_norm, x->lr, x->lr_dev, x->lr_scale,
+                 x->b1, x->b2, x->eps, x->weight_decay, (unsigned char*)x->shadow8, x->w8_id, x->w8_qscale, x->w8_amax, x->elem0,
+                 x->g_scale > 0.f ? x->g_scale : 1.f, x->w8_amax_slots > 1 ? x->w8_amax_slots : 1};
+    return XGGM_OK;
+}
+}  // namespace
+
+extern "C" int xggm_bertadam_multi(const xggm_adam_args* args, int n, hipStream_t st) {
+    XGGM_REQUIRE(args && n > 0, "xggm_bertadam_multi: no spans");
+    for (int i0 = 0; i0 < n; i0 += ADAM_MULTI) {
+        AdamMulti am;
+        am.n = std::min(ADAM_MULTI, n - i0);
+        int nblk = 0;
+        for (int i = 0; i < am.n; ++i) {
+            if (int e = adam_args_of(args + i0 + i, am.a[i])) return e;
+            XGGM_REQUIRE(args[i0 + i].g_bf16 == args[i0].g_bf16, "xggm_bertadam_multi: the spans of one call share the gradient type");
+            am.blk0[i] = nblk;
+            nblk += grid1d(am.a[i].n / 8 + 1, 65536);
+        }
+        am.blk0[am.n] = nblk;
+        if (args[i0].g_bf16) hipLaunchKernelGGL((bertadam_multi_kernel<2, true, true>), dim3(nblk), dim3(NT), 0, st, am);
+        else hipLaunchKernelGGL((bertadam_multi_kernel<2, true, false>), dim3(nblk), dim3(NT), 0, st, am);
+        if (int e = xggm_check_launch("xggm_bertadam_multi")) return e;
+    }
+    return XGGM_OK;
 }
 
 extern "C" int xggm_sqnorm_bf16(const void* g, int64_t n, float* out, float* ws, hipStream_t st) {

@@ -130,6 +130,21 @@ class Fp8State:
             ops.fp8_scale_update(self.amax, self.hist, self.qscale, self.dscale, self.pos, i0, n, HIST, MARGIN_W, 0, 0,
                                  slots=AMAX_SLOTS)
 
+    def update_weight_scales_of(self, gnames):
+        """the same for several arena groups: their entries of the table as few launches as the ranges allow (adjacent
+        ranges merge; the groups of a pass are laid out back to back: one launch)"""
+        rs = sorted(self.w_range[g] for g in gnames if g in self.w_range)
+        merged = []
+        for i0, n in rs:
+            if merged and merged[-1][0] + merged[-1][1] == i0:
+                merged[-1][1] += n
+            else:
+                merged.append([i0, n])
+        for i0, n in merged:
+            for j in range(0, n, 1024):  # the kernel takes at most 1024 entries
+                ops.fp8_scale_update(self.amax, self.hist, self.qscale, self.dscale, self.pos, i0 + j, min(1024, n - j), HIST,
+                                     MARGIN_W, 0, 0, slots=AMAX_SLOTS)
+
     # ------------------------------------------------------------------ activations
     def site(self, key):
         e = self.sites.get(key)

@@ -298,6 +298,10 @@ class BertAdam(Optimizer):
         gbuf = arena.wire if arena.wire is not None else arena.grads  # bf16 wire arena: the update reads it directly
         gscale = arena.grad_scale if arena.wire is not None else 1.0     # ... and holds sums over the ranks
         z = arena.zero1
+        jobs = []  # every span of this step: ONE launch (xggm_bertadam_multi)
+        if f8 is not None:
+            # new scales of the weight operands of every group, before the update rewrites their e4m3 copies
+            f8.update_weight_scales_of([G.name for G, _, _ in todo])
         for G, pg, gi in todo:
             scale_t = arena.lr_scale[gi:gi + 1]
             if z is not None:
@@ -306,28 +310,26 @@ class BertAdam(Optimizer):
                 # of the scale-id table) under scales derived from maxima that ShardedUpdate.exchange_norm has just
                 # MAX-reduced over the ranks -- identical tables on every rank; gather() brings the other slices over
                 w8g = f8.adam_w8(G.name) if f8 is not None else None
-                if w8g is not None:
-                    f8.update_weight_scales(G.name)
                 pieces = [z.own(r) + (True,) for r in z.runs if r[0] >= G.start and r[1] <= G.vec_start]
                 pieces.append((G.vec_start, G.end, False))
                 for a, b, is_mat in pieces:
                     if b > a:
                         sl = slice(a, b)
                         w8 = ((f8.shadow8[sl],) + w8g) if (w8g is not None and is_mat) else None
-                        ops.bertadam_ex(arena.params[sl], gbuf[sl], arena.m[sl], arena.v[sl], arena.shadow[sl], sq, max_norm,
-                                        pg['lr'], scale_t, pg['b1'], pg['b2'], pg['e'], pg['weight_decay'],
-                                        lr_dev=arena.lr_table[gi:gi + 1], w8=w8, elem0=a, g_scale=gscale)
+                        jobs.append(((arena.params[sl], gbuf[sl], arena.m[sl], arena.v[sl], arena.shadow[sl], sq, max_norm,
+                                      pg['lr'], scale_t, pg['b1'], pg['b2'], pg['e'], pg['weight_decay']),
+                                     dict(lr_dev=arena.lr_table[gi:gi + 1], w8=w8, elem0=a, g_scale=gscale)))
                 continue
             sl = slice(G.start, G.end)
             w8 = f8.adam_w8(G.name) if f8 is not None else None
             if w8 is not None:
                 # fp8 forward: this group's weight operands get their e4m3 copies from the same pass over p, with
                 # the scales the delayed update derives from the maxima earlier steps recorded
-                f8.update_weight_scales(G.name)
                 w8 = (f8.shadow8[sl],) + w8
-            ops.bertadam_ex(arena.params[sl], gbuf[sl], arena.m[sl], arena.v[sl],
-                            None if arena.shadow is None else arena.shadow[sl], sq, max_norm, pg['lr'], scale_t,
-                            pg['b1'], pg['b2'], pg['e'], pg['weight_decay'], lr_dev=arena.lr_table[gi:gi + 1], w8=w8,
-                            elem0=G.start, g_scale=gscale)
+            jobs.append(((arena.params[sl], gbuf[sl], arena.m[sl], arena.v[sl],
+                          None if arena.shadow is None else arena.shadow[sl], sq, max_norm, pg['lr'], scale_t,
+                          pg['b1'], pg['b2'], pg['e'], pg['weight_decay']),
+                         dict(lr_dev=arena.lr_table[gi:gi + 1], w8=w8, elem0=G.start, g_scale=gscale)))
+        ops.bertadam_multi(jobs)
         arena.pending_clip = None
         return loss

@@ -1122,9 +1122,28 @@ class AdamArgs(_ct.Structure):
                 ("w8_amax", _ct.c_void_p), ("elem0", _ct.c_int64), ("g_scale", _ct.c_float), ("w8_amax_slots", _ct.c_int)]
 
 
+def bertadam_multi(jobs):
+    """``jobs``: argument tuples of ``bertadam_ex`` (positional, then a dict of its keyword arguments): ONE launch for all
+    of them (xggm_bertadam_multi), in chunks by gradient type"""
+    if not jobs:
+        return
+    structs = [_adam_args(*a, **kw) for a, kw in jobs]
+    for bf in (0, 1):
+        chunk = [a for a in structs if a.g_bf16 == bf]
+        if chunk:
+            arr = (AdamArgs * len(chunk))(*chunk)
+            call("xggm_bertadam_multi", _ct.cast(arr, _ct.c_void_p), len(chunk), stream())
+
+
 def bertadam_ex(p, g, m, v, shadow, sqn, max_norm, lr, lr_scale, b1, b2, eps, wd, lr_dev=None, w8=None, elem0=0, g_scale=1.0):
     """the update with device-resident lr (``lr_dev``), bf16 gradients (``g.dtype``) and/or the e4m3 weight copy
     ``w8`` = (shadow8 slice, id table, qscale table, amax table); ``elem0``: arena offset of p[0]."""
+    a = _adam_args(p, g, m, v, shadow, sqn, max_norm, lr, lr_scale, b1, b2, eps, wd, lr_dev=lr_dev, w8=w8, elem0=elem0,
+                   g_scale=g_scale)
+    call("xggm_bertadam_ex", _ct.byref(a), stream())
+
+
+def _adam_args(p, g, m, v, shadow, sqn, max_norm, lr, lr_scale, b1, b2, eps, wd, lr_dev=None, w8=None, elem0=0, g_scale=1.0):
     for t in (p, m, v):
         _c(t, F32)
         assert t.numel() == p.numel()
@@ -1138,7 +1157,7 @@ def bertadam_ex(p, g, m, v, shadow, sqn, max_norm, lr, lr_scale, b1, b2, eps, wd
         assert s8.numel() == p.numel() and s8.element_size() == 1 and ids.dtype == torch.int16
         a.shadow8, a.w8_id, a.w8_qscale, a.w8_amax = ptr(s8), ptr(ids), ptr(q), ptr(amax)
         a.w8_amax_slots = int(w8[4]) if len(w8) > 4 else 1  # floats per entry of the amax table
-    call("xggm_bertadam_ex", _ct.byref(a), stream())
+    return a
 
 
 def sqnorm_bf16(g, out):
