@@ -50,6 +50,12 @@ typedef struct ihipStream_t* xggm_stream_t; /* == hipStream_t */
 
 int xggm_version(void);
 const char* xggm_last_error(void);
+/* HOST: queue a byte range (16-byte aligned; at most four per launch) that the NEXT xggm_ln_fwd_grouped_* /
+ * xggm_ln_bwd_grouped_* / bf16 xggm_attn_fwd_grouped / xggm_attn_bwd_grouped launch reads beside its own work and
+ * discards: the weights of the Linear products that follow (src/lxrt/modeling.py:344-347, 384-388, 428-445) are then in
+ * the Infinity Cache when those products ask for them.  Speed only -- nothing is written, no result depends on it;
+ * XGGM_PREFETCH=0 in the environment makes this a no-op. */
+int xggm_prefetch_next(const void* ptr, size_t bytes);
 
 /* ---- dense products --------------------------------------------------------------------
  * C[z][m][n] = epilogue( alpha * sum_k A(z,m,k) * B(z,k,n) ),

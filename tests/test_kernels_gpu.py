@@ -1311,6 +1311,49 @@ def test_reductions_are_reproducible_bit_for_bit(ops, dt):
             assert torch.equal(a, b), (i, k, float((a.float() - b.float()).abs().max()))
 
 
+
+def test_prefetch_ranges_ride_on_the_next_row_launch_and_change_nothing(ops):
+    """xggm_prefetch_next queues byte ranges that the next LayerNorm / attention launch reads beside its own rows and
+    discards (weights for the products behind it): same outputs bit for bit with and without a
+    queued range, odd sizes and a fifth range included, and the queue is empty afterwards (a second launch is plain)."""
+    from xggm_amd import _lib
+    dt = torch.bfloat16
+    x, _ = rnd((1152, 768), dt, 1)
+    res, _ = rnd((1152, 768), dt, 2)
+    g = torch.randn(768, generator=torch.Generator().manual_seed(3)).to(DEV)
+    b = torch.randn(768, generator=torch.Generator().manual_seed(4)).to(DEV)
+    w = torch.randn(5 * 768 * 768 + 24, device=DEV).to(dt)
+
+    def ln():
+        out, z, st = ops.ln_fwd(x.clone(), None, res, g, b, 1e-12)
+        torch.cuda.synchronize()
+        return out, st
+
+    ref = ln()
+    for t in (w, w[8:8 + 3 * 768 * 768 + 8], w[:64], w[16:100000], w[:1000]):  # five: the last one is dropped
+        ops.prefetch_next(t)
+    got = ln()
+    again = ln()
+    assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1])
+    assert torch.equal(ref[0], again[0])
+    assert _lib.lib.xggm_prefetch_next(w.data_ptr() + 2, 4096) != 0  # misaligned: refused on the host
+    assert b"16-byte" in _lib.lib.xggm_last_error()
+    # the attention core as carrier
+    B, heads, S, H = 4, 12, 36, 768
+    q, _ = rnd((B * S, H), dt, 5)
+    k, _ = rnd((B * S, H), dt, 6)
+    v, _ = rnd((B * S, H), dt, 7)
+
+    def att():
+        r = ops.AttnFwdReq(q, k, v, None, B, heads, S, S, 0.0, None, 0)
+        ops.launch_row_requests([r])
+        torch.cuda.synchronize()
+        return r.out
+
+    ref_a = att()
+    ops.prefetch_next(w)
+    assert torch.equal(ref_a, att())
+
 def test_tile_choice_changes_speed_only(ops):
     """ops.gemm_group pins the tile of a launch from the measured table (gemm_tiles_gfx950.json).  Every tile walks k
     in the same order and the column sums are taken per 32 output rows whatever the tile, so the heaviest launch of the

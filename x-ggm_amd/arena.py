@@ -220,6 +220,28 @@ class ParamArena:
         _, o, k, _, _, _ = p._xg
         return self.shadow[o:o + k].view(p.shape)
 
+    def after(self, p, n, use8=False, skip=0):
+        """the (up to) ``n`` weight elements that FOLLOW parameter ``p`` in the buffer the products read (bf16 shadow, or
+        the e4m3 copies with ``use8``), inside its group's matrix region: matrices are laid out in forward order within a
+        backward-stage region, so this is what the next products of the forward will ask for (``ops.prefetch_next``).
+        None without a shadow (fp32 mode) or at the end of the region."""
+        buf = (self.fp8.shadow8 if (use8 and self.fp8 is not None) else self.shadow)
+        if buf is None:
+            return None
+        _, o, k, g, _, _ = p._xg
+        a = o + k + int(skip)
+        b = min(a + int(n), self.groups[g].vec_start)
+        return buf[a:b] if b > a else None
+
+    def before(self, p, n):
+        """the (up to) ``n`` bf16 weight elements in FRONT of parameter ``p`` inside its group's matrix region: what the
+        dgrads of the backward ask for next"""
+        if self.shadow is None:
+            return None
+        _, o, k, g, _, _ = p._xg
+        a = max(o - int(n), self.groups[g].start)
+        return self.shadow[a:o] if o > a else None
+
     def fused(self, ps, compute=True):
         """one [sum(rows), cols] view over parameters that are adjacent in the arena
         (query/key/value weights or biases)."""

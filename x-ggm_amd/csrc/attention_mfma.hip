@@ -50,6 +50,8 @@ struct MSeg {
 struct MGroup {
     MSeg s[2];
     int start1;
+    int total;        // workgroups of the two segments; the ones behind them read the queued weight ranges (common.h)
+    PrefetchArgs pf;
 #ifdef XGGM_STAMP
     long long* stamp;
 #endif
@@ -205,6 +207,10 @@ constexpr int ROW_G = 2;  // column groups per lane: 8 lanes x 2 groups x 4 colu
 
 __global__ __launch_bounds__(NT) void attn_fwd_mfma_kernel(MGroup G) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    if ((int)blockIdx.x >= G.total) {
+        prefetch_role(G.pf, (int)blockIdx.x - G.total);
+        return;
+    }
     const int si = (int)blockIdx.x >= G.start1 ? 1 : 0;
     const MSeg sg = G.s[si];
     const MArgs& a = sg.a;
@@ -362,6 +368,10 @@ __global__ __launch_bounds__(NT) void attn_bwd_mfma_kernel(MGroup G) {
     // owns the tile and added in tile order at the end -- the same bits whatever the scheduling
     __shared__ float csum[3][4][D];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    if ((int)blockIdx.x >= G.total) {
+        prefetch_role(G.pf, (int)blockIdx.x - G.total);
+        return;
+    }
     const int si = (int)blockIdx.x >= G.start1 ? 1 : 0;
     const MSeg sg = G.s[si];
     const MArgs& a = sg.a;
@@ -563,7 +573,9 @@ int xggm_attn_fwd_mfma_group(const xggm_attn_problem* probs, int n, const uint64
     G.stamp = g_attn_stamp;
 #endif
     allow_big_lds(attn_fwd_mfma_kernel, lds);
-    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(total), dim3(NT), lds, st, G);
+    G.total = total;
+    G.pf = xggm_take_prefetch();
+    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(total + G.pf.blocks), dim3(NT), lds, st, G);
     return xggm_check_launch("xggm_attn_fwd(mfma)");
 }
 
@@ -589,7 +601,9 @@ int xggm_attn_bwd_mfma_group(const xggm_attn_problem* probs, int n, const uint64
     G.stamp = g_attn_stamp;
 #endif
     allow_big_lds(attn_bwd_mfma_kernel, lds);
-    hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(total), dim3(NT), lds, st, G);
+    G.total = total;
+    G.pf = xggm_take_prefetch();
+    hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(total + G.pf.blocks), dim3(NT), lds, st, G);
     return xggm_check_launch("xggm_attn_bwd(mfma)");
 }
 

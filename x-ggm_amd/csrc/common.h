@@ -269,3 +269,41 @@ __device__ __forceinline__ bool ordered_grid_sum(float part, float* ws, int nblk
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------- weight prefetch beside latency-bound row kernels
+// The step's products wait for weights nobody has touched since the previous pass: tools/exp_weight_prefetch.py puts a
+// launch whose weights already sit in the Infinity Cache 0.3 ... 1.5 us ahead of one that fetches them from HBM.  The
+// kernels between those products -- attention cores, LayerNorm forward / backward -- leave most workgroup slots of the
+// chip empty for microseconds of latency: xggm_prefetch_next() queues up to four byte ranges on the host, the next such
+// launch takes them, appends `blocks` workgroups to its grid, and those read the ranges with plain loads (which
+// allocate on the way) and discard them.  No result depends on it; XGGM_PREFETCH=0 turns the queue into a no-op.
+// What a carrier can take without becoming longer itself was measured (profiles/r04_experiments/prefetch.txt): 19 MB
+// in one LayerNorm launch made the launch 1.8-2.3 us longer and gave back what the products had gained; the same reads
+// on a side stream cost 0.9 ms per iteration in graph branches.  Hence <= ~9 MB per LayerNorm launch, the rest on the
+// (longer) attention launches.
+struct PrefetchArgs {
+    const void* p[4];
+    unsigned long long n[4];  // bytes (whole 16-byte chunks are read)
+    int k;                    // ranges
+    int blocks;               // workgroups appended to the grid (0: nothing queued)
+    int* sink;                // never written in practice: keeps the loads alive
+};
+PrefetchArgs xggm_take_prefetch();  // host: the queued ranges (the queue is cleared)
+
+__device__ __forceinline__ void prefetch_role(const PrefetchArgs& pf, int b) {
+    typedef int i4 __attribute__((ext_vector_type(4)));
+    const int nt = blockDim.x, tid = threadIdx.x;
+    int acc = 0;
+    for (int r = 0; r < pf.k; ++r) {
+        const i4* q = reinterpret_cast<const i4*>(pf.p[r]);
+        const long long n16 = (long long)(pf.n[r] >> 4), step = (long long)pf.blocks * nt;
+        for (long long i = (long long)b * nt + tid; i < n16; i += 8 * step) {  // eight loads in flight per thread
+            i4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = i + u * step < n16 ? q[i + u * step] : (i4){0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc ^= v[u][0] ^ v[u][3];
+        }
+    }
+    if (acc == 0x5a17c3d9 && pf.sink) *pf.sink = acc;
+}

@@ -196,7 +196,11 @@ struct LnFwdGroup {
 constexpr int LN_FWD_W = 8;
 template <typename T, int NV>
 __global__ __launch_bounds__(LN_FWD_W * 64) void ln_fwd_kernel(LnFwdGroup G, int H, float eps, float p_pre, float p_post,
-                                                    const uint64_t* rng, int accumulate, float out_scale) {
+                                                    const uint64_t* rng, int accumulate, float out_scale, PrefetchArgs pf) {
+    if ((int)blockIdx.x >= G.start[G.n]) {  // appended workgroups: read the queued weight ranges (common.h)
+        prefetch_role(pf, (int)blockIdx.x - G.start[G.n]);
+        return;
+    }
     int si = 0;
 #pragma unroll
     for (int k = 1; k < MAX_SEG; ++k)
@@ -417,7 +421,11 @@ constexpr int LN_BWD_W = 8;  // (same-box A/B against 4: 12.32 vs 12.37 ms per i
 __host__ __device__ inline bool ln_bwd_fused_tail(int H) { return (size_t)3 * LN_BWD_W * H * sizeof(float) <= 144 * 1024; }
 template <typename T, int NV>
 __global__ __launch_bounds__(LN_BWD_W * 64) void ln_bwd_kernel(LnBwdGroup G, int H, float p_pre, float p_post,
-                                                             const uint64_t* rng, float out_scale) {
+                                                             const uint64_t* rng, float out_scale, PrefetchArgs pf) {
+    if ((int)blockIdx.x >= G.start[G.n]) {  // appended workgroups: read the queued weight ranges (common.h)
+        prefetch_role(pf, (int)blockIdx.x - G.start[G.n]);
+        return;
+    }
     int si = 0;
 #pragma unroll
     for (int k = 1; k < MAX_SEG; ++k)
@@ -1035,8 +1043,9 @@ int ln_fwd_grouped(const xggm_ln_fwd_problem* probs, int n, int H, float eps, fl
             total += std::min(ceil_div(q.M, LN_FWD_W), 4096);
         }
         G.start[G.n] = total;
-        DISPATCH_NV(H, hipLaunchKernelGGL((ln_fwd_kernel<T, NV>), dim3(total), dim3(LN_FWD_W * 64), 0, st, G, H, eps, p_pre, p_post, rng,
-                                           accumulate, out_scale));
+        const PrefetchArgs pf = xggm_take_prefetch();
+        DISPATCH_NV(H, hipLaunchKernelGGL((ln_fwd_kernel<T, NV>), dim3(total + pf.blocks), dim3(LN_FWD_W * 64), 0, st, G, H, eps, p_pre,
+                                           p_post, rng, accumulate, out_scale, pf));
         if (int e = xggm_check_launch("xggm_ln_fwd")) return e;
     }
     return XGGM_OK;
@@ -1087,8 +1096,9 @@ int ln_bwd_grouped(const xggm_ln_bwd_problem* probs, int n, int H, float p_pre, 
                 big_lds = true;
             }
         });
-        DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), dim3(total), dim3(LN_BWD_W * 64), sizeof(float) * LN_BWD_W * H * (ln_bwd_fused_tail(H) ? 3 : 1), st, G, H,
-                                           p_pre, p_post, rng, out_scale));
+        const PrefetchArgs pf = xggm_take_prefetch();
+        DISPATCH_NV(H, hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), dim3(total + pf.blocks), dim3(LN_BWD_W * 64), sizeof(float) * LN_BWD_W * H * (ln_bwd_fused_tail(H) ? 3 : 1), st, G, H,
+                                           p_pre, p_post, rng, out_scale, pf));
         if (int e = xggm_check_launch("xggm_ln_bwd")) return e;
         for (int i = 0; i < G.n; ++i) {
             const xggm_ln_bwd_problem& q = G.s[i];

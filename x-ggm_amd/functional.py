@@ -283,6 +283,7 @@ def g_attn_fwd(rt, att, outm, xq, xkv, mask, B, Sq, Sk, salt):
     # ``use8`` = the products read them
     f8 = a.fp8 if xq.dtype == torch.bfloat16 else None
     emit, use8 = f8 is not None, f8 is not None and f8.active
+
     if emit:
         xq8, sq = f8.get(xq, ("in", id(att), salt, 0))
         if not self_att:
@@ -312,6 +313,10 @@ def g_attn_fwd(rt, att, outm, xq, xkv, mask, B, Sq, Sk, salt):
     p_att, p_hid = rt.p(rt.p_attn), rt.p(rt.p_hidden)
     e_ctx = f8.emit(("ctx", id(att), salt)) if emit else (None, None)
     core = ops.AttnFwdReq(q, k, v, mask, B, heads, Sq, Sk, p_att, rt.rng, att._sid + salt, emit8=e_ctx[0])
+    # weight prefetch beside the attention core (ops.prefetch_next): behind W_v in the arena lie W_o (H^2 elements) and
+    # this layer's W_1 and W_2 (4 H^2 each) -- the operands of the next three products.  The attention launches are
+    # the long ones of the chain; the LayerNorm launches, half as long, take half a next layer's W_q / W_k / W_v each
+    core.prefetch = (a.after(wv, 9 * H * H, use8),)
     yield core
     c = core.out
     if use8 and core.out8 is not None:
@@ -324,6 +329,7 @@ def g_attn_fwd(rt, att, outm, xq, xkv, mask, B, Sq, Sk, salt):
     e_ln = f8.emit(("ln", id(outm), salt)) if emit else (None, None)
     ln = ops.LnFwdReq(h, outm.dense.bias.data, xq, outm.LayerNorm.weight.data, outm.LayerNorm.bias.data, 1e-12,
                       p_pre=p_hid, rng=rt.rng, sid_pre=outm._sid + salt, emit8=e_ln[0])
+    ln.prefetch = (a.after(outm.dense.weight, 3 * H * H // 2, use8, skip=8 * H * H),)  # behind W_1, W_2: the next layer's W_q and half of W_k
     yield ln
     if emit:
         f8.put(ln.out, ln.out8, e_ln[1])
@@ -347,6 +353,8 @@ def g_attn_bwd(rt, saved, dy, defer_wgrad=False, link=None):
     lb = ops.LnBwdReq(dy.contiguous(), z, stats, outm.LayerNorm.weight.data, a.atomic_target(outm.LayerNorm.weight),
                       a.atomic_target(outm.LayerNorm.bias), a.atomic_target(outm.dense.bias), p_pre=p_hid, rng=rt.rng,
                       sid_pre=outm._sid + salt, defer=rt.defer_list())
+    if a.shadow is not None:
+        lb.prefetch = (a.w(outm.dense.weight).view(-1),)  # the dgrad right behind this launch reads W_o
     yield lb
     d_h, d_res = lb.d_in, lb.d_res
     pd, d_c = ops.p_dgrad(d_h, a.w(outm.dense.weight))
@@ -359,9 +367,14 @@ def g_attn_bwd(rt, saved, dy, defer_wgrad=False, link=None):
     if self_att:
         dqkv = torch.empty_like(qkv)
         gb = a.atomic_target([bq, bk, bv])  # q/k/v bias gradients come out of the attention backward
-        yield ops.AttnBwdReq(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], mask, d_c, dqkv[:, :H], dqkv[:, H:2 * H],
-                             dqkv[:, 2 * H:], B, heads, Sq, Sk, p_att, rt.rng, att._sid + salt, gb[:H], gb[H:2 * H],
-                             gb[2 * H:], defer=rt.defer_list())
+        ab = ops.AttnBwdReq(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], mask, d_c, dqkv[:, :H], dqkv[:, H:2 * H],
+                            dqkv[:, 2 * H:], B, heads, Sq, Sk, p_att, rt.rng, att._sid + salt, gb[:H], gb[H:2 * H],
+                            gb[2 * H:], defer=rt.defer_list())
+        if a.shadow is not None:
+            # the dgrad behind this launch reads W_q, W_k, W_v; in front of them in the arena lie the FFN weights of the
+            # layer below (8 H^2 elements), which the backward reaches two launches later
+            ab.prefetch = (a.fused([wq, wk, wv]).view(-1), a.before(wq, 8 * H * H))
+        yield ab
         pdx, dxq = ops.p_dgrad(dqkv, a.fused([wq, wk, wv]), residual=d_res)
         dxkv = None
         if defer_wgrad:
@@ -435,6 +448,7 @@ def g_ffn_fwd(rt, inter, outm, x):
     e_ln = f8.emit(("ln", id(outm), 0)) if emit else (None, None)
     ln = ops.LnFwdReq(h, outm.dense.bias.data, x, outm.LayerNorm.weight.data, outm.LayerNorm.bias.data, 1e-12,
                       p_pre=p_hid, rng=rt.rng, sid_pre=outm._sid, dtype=x.dtype, emit8=e_ln[0])
+    ln.prefetch = (a.after(outm.dense.weight, 3 * x.shape[1] * x.shape[1] // 2, use8, skip=3 * x.shape[1] * x.shape[1] // 2),)  # the other half of the next layer's W_k, and W_v
     yield ln
     if emit:
         f8.put(ln.out, ln.out8, e_ln[1])
@@ -444,6 +458,7 @@ def g_ffn_fwd(rt, inter, outm, x):
 def g_ffn_bwd(rt, saved, dy):
     inter, outm, p_hid, (x, u, act, z, stats) = saved
     a = rt.arena
+
     lb = ops.LnBwdReq(dy.contiguous(), z, stats, outm.LayerNorm.weight.data, a.atomic_target(outm.LayerNorm.weight),
                       a.atomic_target(outm.LayerNorm.bias), a.atomic_target(outm.dense.bias), p_pre=p_hid, rng=rt.rng,
                       sid_pre=outm._sid, defer=rt.defer_list())

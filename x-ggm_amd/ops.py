@@ -155,6 +155,7 @@ def _ws(nbytes, device):
 
 # ---- grouped launches: several independent products in one grid -------------------------------
 import ctypes as _ct
+import os
 
 
 class GemmProblem(_ct.Structure):
@@ -632,12 +633,26 @@ class LnBwdReq:
                                  ptr(now[1]), ptr(now[2]), None, ptr(ws), nb, M, sid_pre, 0, 0)
 
 
+def prefetch_next(t):
+    """queue the bytes of tensor ``t`` (a contiguous slice of a weight buffer) for the next LayerNorm / attention launch to
+    read beside its own work and discard (xggm_prefetch_next): the products behind that launch then find their weights
+    in the Infinity Cache"""
+    if t is not None and t.numel():
+        a, n = t.data_ptr(), t.numel() * t.element_size()
+        pad = (-a) % 16
+        if n > pad + 16:
+            call("xggm_prefetch_next", a + pad, n - pad)
+
+
 def launch_row_requests(reqs):
     """launch LnFwdReq / LnBwdReq objects, grouping those with equal key (same kind, dtype, H, eps, p)."""
     groups = {}
     for r in reqs:
         groups.setdefault(r.key, []).append(r)
     for key, rs in groups.items():
+        for r in rs:
+            for t in getattr(r, "prefetch", ()):
+                prefetch_next(t)
         if key[0] in ("attn_fwd", "attn_bwd"):
             arr = (AttnProblem * len(rs))(*[r.prob for r in rs])
             call("xggm_%s_grouped_%s" % (key[0], sfx(key[1])), _ct.cast(arr, _ct.c_void_p), len(rs), 64, ptr(rs[0].rng),
