@@ -458,7 +458,6 @@ def g_ffn_fwd(rt, inter, outm, x):
 def g_ffn_bwd(rt, saved, dy):
     inter, outm, p_hid, (x, u, act, z, stats) = saved
     a = rt.arena
-
     lb = ops.LnBwdReq(dy.contiguous(), z, stats, outm.LayerNorm.weight.data, a.atomic_target(outm.LayerNorm.weight),
                       a.atomic_target(outm.LayerNorm.bias), a.atomic_target(outm.dense.bias), p_pre=p_hid, rng=rt.rng,
                       sid_pre=outm._sid, defer=rt.defer_list())
