@@ -121,7 +121,7 @@ def test_linear_backward_padded_odd_width(ops, M, N, K):
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("group_tile", [0, 1, 2, 3, 4, 7, 8])
+@pytest.mark.parametrize("group_tile", [0, 1, 2, 3, 4, 7, 8, 9])
 def test_grouped_gemm(ops, dt, group_tile):
     """forward (two modalities) + dgrad + wgrad in ONE launch == the four products done alone"""
     from xggm_amd import _lib
@@ -790,7 +790,7 @@ def test_layernorm_forward_sums_split_k_partials(ops):
         ops.p_fwd_splitk(x, w, 5)
 
 
-@pytest.mark.parametrize("group_tile", [0, 1, 2, 3, 4, 7, 8])
+@pytest.mark.parametrize("group_tile", [0, 1, 2, 3, 4, 7, 8, 9])
 def test_wgrad_norm_slots(ops, group_tile):
     """xggm_gemm_problem.sqsum: every 64 x 64 block of the stored fp32 weight gradient leaves its sum of squares in
     its slot -- for every tile size of the grouped kernels (a 128-wide tile writes 2 or 4 slots), with ``accumulate``
@@ -1387,7 +1387,7 @@ def test_tile_choice_changes_speed_only(ops):
             _lib.lib.xggm_gemm_set_group_tile(0)
 
     ref = run(1)
-    for pin in (0, 2, 3, 4, 7, 8):
+    for pin in (0, 2, 3, 4, 7, 8, 9):
         got = run(pin)
         for a, b in zip(ref[:3], got[:3]):  # dx, column sums, weight gradient
             assert torch.equal(a, b), pin

@@ -23,7 +23,7 @@ import bench  # noqa: E402
 from xggm_amd import ops, _lib  # noqa: E402
 import ctypes as ct  # noqa: E402
 
-PINS = (0, 1, 2, 3, 4, 7, 8)  # 7 / 8: the role k-loop (four loader + four compute waves) on 128 x 128 / 128 x 64
+PINS = (0, 1, 2, 3, 4, 7, 8, 9)  # 7 / 8 / 9: the role k-loop (four loader + four compute waves) on 128 x 128 / 128 x 64 / 64 x 64
 REPS = 3
 
 

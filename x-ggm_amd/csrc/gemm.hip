@@ -2013,11 +2013,13 @@ template <typename T> int grouped(const xggm_gemm_problem* probs, int n, hipStre
     if (v == 5) return launch_grouped_tile<128, 256, 8>(ga, stream);
     if (v == 6) return launch_grouped_tile<256, 128, 8>(ga, stream);
 #endif
-    if (v == 7 || v == 8) {  // role k-loop: whole k-tiles in every problem, otherwise the four-wave tile of the same shape
+    if (v >= 7 && v <= 9) {  // role k-loop: whole k-tiles in every problem, otherwise the four-wave tile of the same shape
         bool ok = true;
         for (int i = 0; i < n; ++i) ok = ok && glds_ok<false>(ga.p[i]);
-        if (ok) return v == 7 ? launch_grouped_role<128, 128>(ga, stream) : launch_grouped_role<128, 64>(ga, stream);
-        v = v == 7 ? 3 : 2;
+        if (ok)
+            return v == 7 ? launch_grouped_role<128, 128>(ga, stream)
+                          : v == 8 ? launch_grouped_role<128, 64>(ga, stream) : launch_grouped_role<64, 64>(ga, stream);
+        v = v == 7 ? 3 : v == 8 ? 2 : 1;
     }
     if (v == 4) return launch_grouped_tile<128, 128, 8>(ga, stream);
     if (v == 3) return launch_grouped_tile<128, 128>(ga, stream);
