@@ -29,8 +29,13 @@ def main():
     for ev in prof.events():
         if not ev.name.startswith("aten::"):
             continue
-        if not any(k.name and ("at::native" in k.name or "elementwise" in k.name or "emcpy" in k.name or "copyBuffer" in k.name
-                               or "fillBuffer" in k.name) for k in ev.kernels):
+        dev_us = getattr(ev, "device_time_total", 0) or getattr(ev, "cuda_time_total", 0)
+        hit = any(k.name and ("at::native" in k.name or "elementwise" in k.name or "emcpy" in k.name or "copyBuffer" in k.name
+                              or "fillBuffer" in k.name) for k in ev.kernels)
+        # device-to-device copies are memcpy activities, not kernels: an aten::copy_ with device time but no kernel of the
+        # package is one (clone / contiguous / copy_ of a tensor that was not contiguous)
+        if not hit and not (ev.name in ("aten::copy_", "aten::clone", "aten::contiguous", "aten::_to_copy", "aten::fill_", "aten::zero_")
+                            and dev_us > 0):
             continue
         st = [s for s in (ev.stack or []) if "ggm" in s or "bench.py" in s][:4]
         if not st:
