@@ -316,6 +316,23 @@ int xggm_ln_bwd_grouped_f32(const xggm_ln_bwd_problem* probs, int n, int H, floa
                             const uint64_t* rng, float out_scale, xggm_stream_t stream);
 int xggm_ln_bwd_grouped_bf16(const xggm_ln_bwd_problem* probs, int n, int H, float p_pre, float p_post,
                              const uint64_t* rng, float out_scale, xggm_stream_t stream);
+/* out = sum over n <= 4 terms of dropout_p_post(LayerNorm(in[k]; gamma[k], beta[k], eps)) in ONE launch: the
+ * jump-knowledge read-out of the graph blocks (src/module/gcn.py:70-77, src/module/gin.py:80-87).  The sum is held in
+ * fp32 and rounded once.  stats[k] (or NULL): [M][2] (mean, rstd) of term k for xggm_ln_bwd_* (whose `z` is in[k] itself:
+ * the terms have no bias, residual or input dropout).  `out` may not alias a term. */
+typedef struct xggm_ln_sum_args {
+    const void* in[4];
+    const float* gamma[4];
+    const float* beta[4];
+    float* stats[4];
+    uint32_t sid_post[4];
+    void* out;
+    int n, M, H;
+    float eps, p_post;
+    const uint64_t* rng;
+} xggm_ln_sum_args;
+int xggm_ln_sum_fwd_f32(const xggm_ln_sum_args* args, xggm_stream_t stream);
+int xggm_ln_sum_fwd_bf16(const xggm_ln_sum_args* args, xggm_stream_t stream);
 /* workspaces (bytes) of the backward row kernels: they hold one partial row per workgroup and
  * reduced vector, summed by a second kernel instead of contended atomics */
 size_t xggm_ln_bwd_workspace_bytes(int M, int H);
@@ -538,6 +555,27 @@ int xggm_sched_step(int64_t* step, float* lr_scale, int64_t t_total, float warmu
  * parameter groups of one optimiser step); index, t_total, warmup: HOST arrays of n entries */
 int xggm_sched_step_multi(int64_t* steps, float* lr_scale, const int* index, const int64_t* t_total, const float* warmup,
                           int n, xggm_stream_t stream);
+
+/* The tail of a pass in two launches instead of seven: nn.utils.clip_grad_norm_'s norm (src/vqa/vqacpv2.py:175) over up
+ * to 24 ranges in all -- `n` ranges of the gradient buffer `g` (squared) and `n_slots` ranges of the slot table the
+ * weight-gradient products filled (xggm_gemm_problem.sqsum: summed as they are) -- with partials added in (range, slice)
+ * order (fixed: replicas stay bit-identical); *out = sum * mul, *norm (or NULL) = sqrt(*out).  With `tail` the finishing
+ * workgroup also performs xggm_sched_step_multi's schedule step for tail->n counters (BertAdam.step's bookkeeping,
+ * src/lxrt/optimization.py:170-180) and, with tail->rng, xggm_rng_advance(rng, rng_by).  offsets / lengths / tail's
+ * arrays: HOST arrays; offsets multiples of 4; ws: XGGM_SQNORM_WS_FLOATS floats. */
+typedef struct {
+    int64_t* steps;
+    float* lr_scale;
+    const int* index;
+    const int64_t* t_total;
+    const float* warmup;
+    int n;
+    uint64_t* rng; /* or NULL */
+    uint64_t rng_by;
+} xggm_pass_tail;
+int xggm_clip_norm_f32(const float* g, const int64_t* offsets, const int64_t* lengths, int n, const float* slots,
+                       const int64_t* slot_offsets, const int64_t* slot_lengths, int n_slots, float* out, float* norm, float* ws,
+                       float mul, const xggm_pass_tail* tail, xggm_stream_t stream);
 
 /* out = in with the diagonal of every [N, N] matrix zeroed: adj_true.triu(1) + adj_true.tril(-1), src/vqa/vqacpv2.py:188 */
 int xggm_zero_diag_f32(const float* in, float* out, int B, int N, xggm_stream_t stream);

@@ -295,6 +295,51 @@ def test_layernorm_fwd_bwd(ops, dt, M, H):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("M,H,n", [(1152, 768, 3), (4096, 768, 2), (7, 128, 1), (100, 256, 4)])
+def test_sum_of_layernorms_in_one_launch(ops, dt, M, H, n):
+    """xggm_ln_sum_fwd: sum_k dropout(LayerNorm_k(x_k)), the read-out of src/module/gcn.py:70-77 / gin.py:80-87, against
+    float64 without dropout and against the chain of accumulating ln_fwd launches it replaces with dropout (same masks,
+    same statistics; the chain rounds the running sum to the storage type between the terms, this one once); and the
+    grouped backward of the terms against separate ln_bwd calls, bit for bit."""
+    gen = torch.Generator().manual_seed(11)
+    xs, xrs = zip(*[rnd((M, H), dt, 40 + k) for k in range(n)])
+    gam = [(1 + 0.1 * torch.randn(H, generator=gen)) for _ in range(n)]
+    bet = [(0.1 * torch.randn(H, generator=gen)) for _ in range(n)]
+    gd, bd = [g.to(DEV) for g in gam], [b.to(DEV) for b in bet]
+    out, stats = ops.ln_sum_fwd(list(xs), gd, bd, 1e-5)
+    ref = sum(torch.nn.functional.layer_norm(xr, (H,), g.double(), b.double(), 1e-5) for xr, g, b in zip(xrs, gam, bet))
+    assert rel_err(out, ref) < tol(dt)
+    rng = ops.make_rng(99, DEV)
+    out_d, stats_d = ops.ln_sum_fwd(list(xs), gd, bd, 1e-5, p_post=0.5, rng=rng, sids=[300 + k for k in range(n)])
+    chain = torch.empty_like(xs[0])
+    for k in range(n):
+        _, z, st = ops.ln_fwd(xs[k].clone(), None, None, gd[k], bd[k], 1e-5, p_post=0.5, rng=rng, sid_post=300 + k, out=chain,
+                              accumulate=k > 0)
+        assert torch.equal(z, xs[k]) and torch.equal(st, stats_d[k]) and torch.equal(st, stats[k])
+    assert rel_err(out_d, chain.double().cpu()) < tol(dt, 1e-6, 8e-3)
+    if dt == torch.float32 or n == 1:
+        assert float((out_d.double() - chain.double()).abs().max()) < 1e-5
+    # backward of the terms: one grouped launch == separate launches
+    dy = rnd((M, H), dt, 60)[0]
+    us = [rnd((M, H), dt, 70 + k)[0] for k in range(n)]
+    sep_g = [[torch.zeros(H, device=DEV) for _ in range(3)] for _ in range(n)]
+    sep = [ops.ln_bwd(dy, xs[k], stats_d[k], gd[k], *sep_g[k], p_post=0.5, rng=rng, sid_post=300 + k, gelu_aux=us[k])[0]
+           for k in range(n)]
+    grp_g = [[torch.zeros(H, device=DEV) for _ in range(3)] for _ in range(n)]
+    grp = ops.ln_bwd_group([dict(dy=dy, z=xs[k], stats=stats_d[k], gamma=gd[k], dgamma=grp_g[k][0], dbeta=grp_g[k][1],
+                                 dbias=grp_g[k][2], sid_post=300 + k, gelu_aux=us[k]) for k in range(n)], p_post=0.5, rng=rng)
+    for k in range(n):
+        assert torch.equal(grp[k][0], sep[k]) and grp[k][1] is None
+        for a, b in zip(grp_g[k], sep_g[k]):
+            assert torch.equal(a, b)
+    with pytest.raises(RuntimeError, match="may not be one of the terms"):
+        a = ops.LnSumArgs()
+        a.inp[0], a.gamma[0], a.beta[0], a.out = xs[0].data_ptr(), gd[0].data_ptr(), bd[0].data_ptr(), xs[0].data_ptr()
+        a.n, a.M, a.H, a.eps = 1, M, H, 1e-5
+        ops.call("xggm_ln_sum_fwd_" + ops.sfx(dt), ops._ct.byref(a), ops.stream())
+
+
+@pytest.mark.parametrize("dt", DTS)
 def test_grouped_row_requests_equal_separate_launches(ops, dt):
     """the language (640 rows, 20 tokens) and vision (1152 rows, 36 objects) LayerNorms / attention cores
     launched as ONE group give bit-identical activations and input gradients to separate launches; the deferred second stage of
@@ -848,6 +893,45 @@ def test_sched_step_multi_matches_reference_schedule(ops):
     assert np.allclose(scale.cpu().numpy(), want, rtol=1e-6, atol=1e-7)
     with pytest.raises(RuntimeError, match="listed twice"):
         ops.sched_step_multi(steps, scale, [(1, 20, 0.1), (1, 20, 0.1)])
+
+
+def test_clip_norm_pair_with_the_pass_tail(ops):
+    """xggm_clip_norm_f32: the norm nn.utils.clip_grad_norm_ returns (src/vqa/vqacpv2.py:175) over ranges of the gradient
+    buffer (squared) and of the slot table (summed as they are) in one pair of launches, against float64; the finishing
+    launch takes BertAdam.step's schedule step (src/lxrt/optimization.py:42-48, 170-180) and the RNG advance along;
+    repeated calls give the same bits (fixed summation order)."""
+    from oracle import xggm_oracle as O
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    g = torch.randn(3_000_011, generator=gen).to(DEV)
+    slots = torch.rand(5000, generator=gen).to(DEV)
+    spans = [(0, 1_000_000), (1_000_004, 1_000_004 + 37), (1_200_000, 3_000_011), (8, 8)]
+    slot_spans = [(0, 1024), (2048, 5000)]
+    want = sum(float((g[a:b].double() ** 2).sum()) for a, b in spans) + sum(float(slots[a:b].double().sum()) for a, b in slot_spans)
+    out, norm = torch.full((1,), -3.0, device=DEV), torch.zeros(1, device=DEV)
+    steps = torch.tensor([0, 3, 7], dtype=torch.int64, device=DEV)
+    scale = torch.full((3,), -1.0, device=DEV)
+    rng = torch.tensor([11, 40], dtype=torch.int64, device=DEV)
+    ops.clip_norm(g, spans, slots, slot_spans, out, norm, mul=0.25, sched=(steps, scale, [(0, 20, 0.1), (2, 20, 0.1)]), rng=(rng, 3))
+    assert abs(float(out) - 0.25 * want) < 2e-6 * want
+    assert abs(float(norm) - (0.25 * want) ** 0.5) < 2e-6 * want ** 0.5
+    assert steps.tolist() == [1, 3, 8] and rng.tolist() == [11, 43]
+    assert np.allclose(scale.cpu().numpy(), [O.warmup_linear(0 / 20, 0.1), -1.0, O.warmup_linear(7 / 20, 0.1)], rtol=1e-6, atol=1e-7)
+    first = float(out)
+    for _ in range(3):  # no tail: only the norm; same bits every time
+        o2 = torch.zeros(1, device=DEV)
+        ops.clip_norm(g, spans, slots, slot_spans, o2, None, mul=0.25)
+        assert float(o2) == first
+    assert steps.tolist() == [1, 3, 8] and rng.tolist() == [11, 43]
+    # ranges only / slots only / nothing at all (the finish then writes 0)
+    o3 = torch.ones(1, device=DEV)
+    ops.clip_norm(g, spans[:1], None, [], o3)
+    assert abs(float(o3) - float((g[:1_000_000].double() ** 2).sum())) < 2e-6 * want
+    ops.clip_norm(g, [], slots, slot_spans[:1], o3)
+    assert abs(float(o3) - float(slots[:1024].double().sum())) < 1e-3
+    ops.clip_norm(g, [], None, [], o3)
+    assert float(o3) == 0.0
+    with pytest.raises(RuntimeError, match="listed twice"):
+        ops.clip_norm(g, spans[:1], None, [], o3, sched=(steps, scale, [(1, 20, 0.1), (1, 20, 0.1)]))
 
 
 # ------------------------------------------------------------------------------------------------ fp8 forward (C5)

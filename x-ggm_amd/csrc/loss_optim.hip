@@ -199,15 +199,10 @@ struct Spans {
     int blk0[MAX_SPANS + 1];  // first workgroup of each range
     int n;
 };
+// one workgroup's share of one range: slice b of nb, four 16-byte loads in flight per thread
 template <bool SQ>
-__global__ __launch_bounds__(NT) void sqnorm_multi_kernel(const float* __restrict__ base, Spans sp, float* ws) {
-    int k = 0;
-#pragma unroll
-    for (int j = 1; j < MAX_SPANS; ++j)
-        if (j < sp.n && (int)blockIdx.x >= sp.blk0[j]) k = j;
-    const int nb = sp.blk0[k + 1] - sp.blk0[k], b = blockIdx.x - sp.blk0[k];
-    const float* g = base + sp.off[k];
-    const int64_t n = sp.len[k], n4 = n >> 2;
+__device__ __forceinline__ float span_partial(const float* __restrict__ g, int64_t n, int b, int nb) {
+    const int64_t n4 = n >> 2;
     typedef float __attribute__((ext_vector_type(4))) f4;
     const f4* g4 = reinterpret_cast<const f4*>(g);
     const int64_t stride = (int64_t)nb * NT;
@@ -231,7 +226,37 @@ __global__ __launch_bounds__(NT) void sqnorm_multi_kernel(const float* __restric
         const float v = g[(n4 << 2) + threadIdx.x];
         acc += SQ ? v * v : v;
     }
-    acc = block_sum(acc);
+    return block_sum(acc);
+}
+
+template <bool SQ>
+__global__ __launch_bounds__(NT) void sqnorm_multi_kernel(const float* __restrict__ base, Spans sp, float* ws) {
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < MAX_SPANS; ++j)
+        if (j < sp.n && (int)blockIdx.x >= sp.blk0[j]) k = j;
+    const float acc = span_partial<SQ>(base + sp.off[k], sp.len[k], blockIdx.x - sp.blk0[k], sp.blk0[k + 1] - sp.blk0[k]);
+    if (threadIdx.x == 0) ws[blockIdx.x] = acc;
+}
+
+// The norm of a whole pass in ONE pair of launches (xggm_clip_norm_f32): ranges of the gradient buffer (squared) and
+// ranges of the slot table the weight-gradient products filled (already sums of squares: added as they are) side by
+// side in one grid, partials in (range, slice) order; the finishing workgroup also takes the schedule step and the
+// RNG advance of the pass along (three one-workgroup launches of their own before).
+constexpr int MAX_NORM_SPANS = 24;
+struct NormSpans {
+    const float* ptr[MAX_NORM_SPANS];
+    int64_t len[MAX_NORM_SPANS];
+    int blk0[MAX_NORM_SPANS + 1];
+    int n, n_sq;  // ranges [0, n_sq) are squared, [n_sq, n) summed as they are
+};
+__global__ __launch_bounds__(NT) void clip_norm_kernel(NormSpans sp, float* ws) {
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < MAX_NORM_SPANS; ++j)
+        if (j < sp.n && (int)blockIdx.x >= sp.blk0[j]) k = j;
+    const int b = blockIdx.x - sp.blk0[k], nb = sp.blk0[k + 1] - sp.blk0[k];
+    const float acc = k < sp.n_sq ? span_partial<true>(sp.ptr[k], sp.len[k], b, nb) : span_partial<false>(sp.ptr[k], sp.len[k], b, nb);
     if (threadIdx.x == 0) ws[blockIdx.x] = acc;
 }
 __global__ __launch_bounds__(NT) void sqnorm_multi_finish_kernel(const float* __restrict__ ws, int nblk, float* out, float* norm,
@@ -769,6 +794,90 @@ extern "C" int xggm_sched_step_multi(int64_t* steps, float* lr_scale, const int*
     }
     hipLaunchKernelGGL(sched_multi_kernel, dim3(1), dim3(64), 0, st, steps, lr_scale, a);
     return xggm_check_launch("xggm_sched_step_multi");
+}
+
+namespace {
+__global__ __launch_bounds__(NT) void clip_norm_finish_kernel(const float* __restrict__ ws, int nblk, float* out, float* norm, float mul,
+                                                              int64_t* steps, float* lr_scale, SchedArgs sa, uint64_t* rng,
+                                                              uint64_t rng_by) {
+    float t = 0.f;
+    for (int b = threadIdx.x; b < nblk; b += NT) t += ws[b];
+    t = block_sum(t);
+    if (threadIdx.x == 0) {
+        const float s = t * mul;
+        *out = s;
+        if (norm) *norm = sqrtf(s);
+        if (rng) rng[1] += rng_by;
+    }
+    const int i = threadIdx.x;
+    if (i < sa.n) {  // sched_multi_kernel's step
+        const int k = sa.index[i];
+        const int64_t s = steps[k];
+        float sc = 1.f;
+        if (sa.t_total[i] > 0) {
+            const float x = (float)((double)s / (double)sa.t_total[i]);
+            sc = x < sa.warmup[i] ? x / sa.warmup[i] : fmaxf((x - 1.f) / (sa.warmup[i] - 1.f), 0.f);
+        }
+        lr_scale[k] = sc;
+        steps[k] = s + 1;
+    }
+}
+}  // namespace
+
+extern "C" int xggm_clip_norm_f32(const float* g, const int64_t* offsets, const int64_t* lengths, int n, const float* slots,
+                                  const int64_t* slot_offsets, const int64_t* slot_lengths, int n_slots, float* out, float* norm,
+                                  float* ws, float mul, const xggm_pass_tail* tail, hipStream_t st) {
+    XGGM_REQUIRE(out && ws && n >= 0 && n_slots >= 0 && n + n_slots <= MAX_NORM_SPANS && (n == 0 || (g && offsets && lengths)) &&
+                     (n_slots == 0 || (slots && slot_offsets && slot_lengths)),
+                 "xggm_clip_norm_f32: bad arguments (%d + %d ranges, at most %d in all)", n, n_slots, MAX_NORM_SPANS);
+    XGGM_REQUIRE((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(slots)) % 16 == 0,
+                 "xggm_clip_norm_f32: buffers must be 16-byte aligned");
+    NormSpans sp;
+    sp.n = n + n_slots;
+    sp.n_sq = n;
+    int64_t total = 0;
+    for (int i = 0; i < sp.n; ++i) {
+        const int64_t o = i < n ? offsets[i] : slot_offsets[i - n], l = i < n ? lengths[i] : slot_lengths[i - n];
+        XGGM_REQUIRE(o >= 0 && l > 0 && o % 4 == 0, "xggm_clip_norm_f32: range %d (offset %lld, length %lld) must be non-empty and "
+                     "start on a multiple of 4", i, (long long)o, (long long)l);
+        sp.ptr[i] = (i < n ? g : slots) + o;
+        sp.len[i] = l;
+        total += l;
+    }
+    int nblk = 0;  // as xggm_sqnorm_multi_f32: <= 4096 + n partials, at least 8 float4 per thread where a range is long enough
+    for (int i = 0; i < sp.n; ++i) {
+        sp.blk0[i] = nblk;
+        nblk += (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div64(sp.len[i], (int64_t)NT * 32), (4096 - sp.n) * sp.len[i] / total + 1));
+    }
+    sp.blk0[sp.n] = nblk;
+    XGGM_REQUIRE(nblk <= 4100, "xggm_clip_norm_f32: internal: %d partials", nblk);
+    SchedArgs sa;
+    sa.n = 0;
+    int64_t* steps = nullptr;
+    float* lr_scale = nullptr;
+    uint64_t* rng = nullptr;
+    uint64_t rng_by = 0;
+    if (tail) {
+        XGGM_REQUIRE(tail->n >= 0 && tail->n <= MAX_SCHED && (tail->n == 0 || (tail->steps && tail->lr_scale && tail->index &&
+                                                                             tail->t_total && tail->warmup)),
+                     "xggm_clip_norm_f32: bad schedule entries (n = %d, at most %d)", tail->n, MAX_SCHED);
+        sa.n = tail->n;
+        for (int i = 0; i < sa.n; ++i) {
+            XGGM_REQUIRE(tail->index[i] >= 0, "xggm_clip_norm_f32: negative schedule index");
+            for (int j = 0; j < i; ++j)
+                XGGM_REQUIRE(tail->index[j] != tail->index[i], "xggm_clip_norm_f32: counter %d listed twice", tail->index[i]);
+            sa.index[i] = tail->index[i];
+            sa.t_total[i] = tail->t_total[i];
+            sa.warmup[i] = tail->warmup[i];
+        }
+        steps = tail->steps;
+        lr_scale = tail->lr_scale;
+        rng = tail->rng;
+        rng_by = tail->rng_by;
+    }
+    if (nblk > 0) hipLaunchKernelGGL(clip_norm_kernel, dim3(nblk), dim3(NT), 0, st, sp, ws);
+    hipLaunchKernelGGL(clip_norm_finish_kernel, dim3(1), dim3(NT), 0, st, ws, nblk, out, norm, mul, steps, lr_scale, sa, rng, rng_by);
+    return xggm_check_launch("xggm_clip_norm_f32");
 }
 
 extern "C" int xggm_rng_advance(uint64_t* rng, uint64_t by, hipStream_t st) {

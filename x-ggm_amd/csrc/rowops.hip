@@ -404,6 +404,102 @@ __global__ __launch_bounds__(LN_FWD_W * 64) void ln_fwd_kernel(LnFwdGroup G, int
     }
 }
 
+// ------------------------------------------------------------------------------- sum of LayerNorms
+// The jump-knowledge read-out of the graph blocks (src/module/gcn.py:70-77, src/module/gin.py:80-87) adds up to four
+// dropout(LayerNorm_k(x_k)): launched as a chain of accumulating ln_fwd calls it was k launches that each re-read and
+// re-wrote the sum (rounded to the storage type in between); here a wave holds the row's sum in fp32 registers while it
+// walks the terms, and the sum is rounded once.  The terms have no bias / residual / input dropout, so the saved
+// pre-normalisation row IS the input: only (mean, rstd) are written per term.
+struct LnSumArgs {
+    const void* in[4];
+    const float* gamma[4];
+    const float* beta[4];
+    float* stats[4];
+    uint32_t sid_post[4];
+    void* out;
+    int n, M;
+};
+template <typename T, int NV>
+__global__ __launch_bounds__(LN_FWD_W * 64) void ln_sum_fwd_kernel(LnSumArgs a, int H, float eps, float p_post, const uint64_t* rng) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint64_t seed, off;
+    rng_load(rng, seed, off);
+    const float ik_post = p_post > 0.f ? 1.f / (1.f - p_post) : 1.f;
+    int cc[NV];
+    bool ok[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int c = (v * 64 + lane) * 4;
+        ok[v] = c < H;
+        cc[v] = ok[v] ? c : H - 4;
+    }
+    T* out = reinterpret_cast<T*>(a.out);
+    for (int row = blockIdx.x * LN_FWD_W + wid; row < a.M; row += gridDim.x * LN_FWD_W) {
+        const int64_t rb = (int64_t)row * H;
+        typename Raw4<T>::type rin[4][NV];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < a.n) {  // uniform: every term's row is on its way before the first one is used
+#pragma unroll
+                for (int v = 0; v < NV; ++v) rin[k][v] = load_raw4<T>(reinterpret_cast<const T*>(a.in[k]) + rb + cc[v]);
+            }
+        float acc[NV][4];
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[v][i] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < a.n) {
+                float z[NV][4];
+                float sum = 0.f;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    cvt4(rin[k][v], z[v]);
+                    if (ok[v]) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) sum += z[v][i];
+                    }
+                }
+                const float mean = wave_sum(sum) / (float)H;
+                float var = 0.f;
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+                    if (ok[v]) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float t = z[v][i] - mean;
+                            var += t * t;
+                        }
+                    }
+                const float rstd = rsqrtf(wave_sum(var) / (float)H + eps);
+                if (a.stats[k] && lane == 0) {
+                    a.stats[k][2 * row] = mean;
+                    a.stats[k][2 * row + 1] = rstd;
+                }
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    float g4[4], be4[4], y[4];
+                    load4(a.gamma[k] + cc[v], g4);
+                    load4(a.beta[k] + cc[v], be4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) y[i] = (z[v][i] - mean) * rstd * g4[i] + be4[i];
+                    if (p_post > 0.f) {
+                        float s4[4];
+                        dropout_scale4(p_post, ik_post, seed, off, a.sid_post[k], (uint64_t)(rb + cc[v]), s4);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) y[i] *= s4[i];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[v][i] += y[i];
+                }
+            }
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            if (ok[v]) store4(out + rb + cc[v], acc[v]);
+    }
+}
+
 // ------------------------------------------------------------------------------- LN bwd
 // dy: gradient w.r.t. `out`.  Produces d_in (grad of `in`, i.e. through drop_pre), d_res
 // (grad of `residual`), and accumulates dgamma / dbeta / dbias (bias of `in`) with one fp32
@@ -1052,6 +1148,31 @@ int ln_fwd_grouped(const xggm_ln_fwd_problem* probs, int n, int H, float eps, fl
 }
 
 template <typename T>
+int ln_sum_fwd(const xggm_ln_sum_args* x, hipStream_t st) {
+    XGGM_REQUIRE(x && x->n >= 1 && x->n <= 4 && x->out, "xggm_ln_sum_fwd: 1..4 terms and an output");
+    if (int e = check_row_shape("xggm_ln_sum_fwd", x->M, x->H)) return e;
+    XGGM_REQUIRE(x->p_post >= 0.f && x->p_post < 1.f && (x->p_post == 0.f || x->rng), "xggm_ln_sum_fwd: bad dropout p / no rng state");
+    LnSumArgs a;
+    a.n = x->n;
+    a.M = x->M;
+    a.out = x->out;
+    for (int k = 0; k < 4; ++k) {
+        const bool on = k < x->n;
+        XGGM_REQUIRE(!on || (x->in[k] && x->gamma[k] && x->beta[k]), "xggm_ln_sum_fwd: term %d has a null pointer", k);
+        XGGM_REQUIRE(!on || x->in[k] != x->out, "xggm_ln_sum_fwd: the output may not be one of the terms");
+        a.in[k] = on ? x->in[k] : nullptr;
+        a.gamma[k] = on ? x->gamma[k] : nullptr;
+        a.beta[k] = on ? x->beta[k] : nullptr;
+        a.stats[k] = on ? x->stats[k] : nullptr;
+        a.sid_post[k] = on ? x->sid_post[k] : 0u;
+    }
+    const int H = x->H;
+    const int grid = std::min(ceil_div(x->M, LN_FWD_W), 4096);
+    DISPATCH_NV(H, hipLaunchKernelGGL((ln_sum_fwd_kernel<T, NV>), dim3(grid), dim3(LN_FWD_W * 64), 0, st, a, H, x->eps, x->p_post, x->rng));
+    return xggm_check_launch("xggm_ln_sum_fwd");
+}
+
+template <typename T>
 int ln_fwd(const void* in, const float* bias, const void* residual, const float* gamma, const float* beta, void* out,
            void* z_out, float* stats, int M, int H, float eps, float p_pre, float p_post, const uint64_t* rng,
            uint32_t s_pre, uint32_t s_post, int accumulate, float out_scale, hipStream_t st) {
@@ -1258,6 +1379,7 @@ size_t ws_colsum(int M, int N) { return sizeof(float) * (size_t)ceil_div(M, CS_R
                                              const uint64_t* rng, float out_scale, hipStream_t st) {                      \
         return ln_bwd_grouped<T>(probs, n, H, p_pre, p_post, rng, out_scale, st);                                          \
     }                                                                                                                       \
+    extern "C" int xggm_ln_sum_fwd_##SUF(const xggm_ln_sum_args* args, hipStream_t st) { return ln_sum_fwd<T>(args, st); }  \
     extern "C" int xggm_embed_fwd_##SUF(const int64_t* ids, const int64_t* seg, const void* word, const void* pos,         \
                                         const void* type, const float* gamma, const float* beta, void* out, void* z_out,   \
                                         float* stats, int M, int Tlen, int H, float eps, float p, const uint64_t* rng,    \

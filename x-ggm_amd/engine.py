@@ -96,9 +96,7 @@ class CapturedTrainer:
         return loss, logit
 
     def _update(self):
-        total = clip_and_step(self.model, self.optim, self.clip)
-        self.rt.advance()
-        return total
+        return clip_and_step(self.model, self.optim, self.clip, advance=True)
 
     # the update as graphs: one, or -- sharded update -- two with the norm's scalar all-reduce between them and the
     # all-gather of the weights behind them (collectives run on the live communicator, never inside a capture)

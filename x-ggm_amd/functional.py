@@ -151,7 +151,10 @@ class Runtime:
 
     def advance(self):
         """new dropout masks / noise for the next pass (graph-capturable)."""
-        ops.rng_advance(self.rng, 1)
+        if getattr(self, "rng_advanced", False):
+            self.rng_advanced = False  # the norm's finishing launch of this pass has advanced the state (clip_grad_norm_)
+        else:
+            ops.rng_advance(self.rng, 1)
         if self.arena.fp8 is not None:
             self.arena.fp8.step()  # delayed scaling: the activation maxima of this pass set the next pass's scales
 
@@ -745,16 +748,14 @@ class GCNFn(Function):
             convs.append((agg, z, stats))
             hs.append(h.view(B, N, H))
         p_ro = rt.p(gcn.dropout_p)
-        ret = torch.empty((B * N, H), device=x.device, dtype=x.dtype)
-        reads = []
         pf = [ops.p_fwd(h.view(B * N, H), a.w(mlp[0].weight), mlp[0].bias.data, act=ops.ACT_GELU, want_preact=True)
               for mlp, h in zip(gcn.linear_prediction, hs)]
         ops.gemm_group(x.dtype, [t[0] for t in pf])  # the three read-out projections in one launch
-        for k, mlp in enumerate(gcn.linear_prediction):
-            _, act, u = pf[k]
-            _, z, stats = ops.ln_fwd(act, None, None, mlp[2].weight.data, mlp[2].bias.data, 1e-5, p_post=p_ro,
-                                     rng=rt.rng, sid_post=gcn._sid + k, out=ret, accumulate=k > 0)
-            reads.append((u, z, stats))
+        # the three dropout(LayerNorm(.)) terms and their sum: one launch, the sum held in fp32
+        ret, stats = ops.ln_sum_fwd([t[1] for t in pf], [mlp[2].weight.data for mlp in gcn.linear_prediction],
+                                    [mlp[2].bias.data for mlp in gcn.linear_prediction], 1e-5, p_post=p_ro, rng=rt.rng,
+                                    sids=[gcn._sid + k for k in range(len(pf))])
+        reads = [(u, act, st) for (_, act, u), st in zip(pf, stats)]
         ctx.rt, ctx.gcn, ctx.p = rt, gcn, p_ro
         ctx.saved = (adj, hs, convs, reads)
         return ret.view(B, N, H)
@@ -767,11 +768,14 @@ class GCNFn(Function):
         B, N, H = hs[0].shape
         d_ret = d_ret.contiguous().view(B * N, H)
         dh, probs = [], []
+        # the three read-out LayerNorm backwards read the same d_ret: one launch
+        d_us = ops.ln_bwd_group([dict(dy=d_ret, z=z, stats=stats, gamma=mlp[2].weight.data, dgamma=a.atomic_target(mlp[2].weight),
+                                      dbeta=a.atomic_target(mlp[2].bias), dbias=a.atomic_target(mlp[0].bias),
+                                      sid_post=gcn._sid + k, gelu_aux=u, defer=rt.defer_list())
+                                 for k, (mlp, (u, z, stats)) in enumerate(zip(gcn.linear_prediction, reads))],
+                                p_post=ctx.p, rng=rt.rng)
         for k, (mlp, h) in enumerate(zip(gcn.linear_prediction, hs)):
-            u, z, stats = reads[k]
-            d_u, _ = ops.ln_bwd(d_ret, z, stats, mlp[2].weight.data, a.atomic_target(mlp[2].weight),
-                                a.atomic_target(mlp[2].bias), a.atomic_target(mlp[0].bias), p_post=ctx.p, rng=rt.rng,
-                                sid_post=gcn._sid + k, gelu_aux=u, defer=rt.defer_list())
+            d_u = d_us[k][0]
             pd, dhk = ops.p_dgrad(d_u, a.w(mlp[0].weight))
             probs += [_p_wgrad(rt, d_u, h.view(B * N, H), mlp[0].weight), pd]
             dh.append(dhk)
@@ -813,14 +817,13 @@ class GINFn(Function):
         h1, z1, st1 = ops.ln_fwd(act, None, None, conv.linear[2].weight.data, conv.linear[2].bias.data, 1e-5)
         hs = [x, h1.view(B, N, H)]
         p_ro = rt.p(gin.dropout_p)
-        ret = torch.empty((B * N, H), device=x.device, dtype=x.dtype)
-        reads = []
-        for k, (mlp, h) in enumerate(zip(gin.linear_prediction, hs)):
-            ak, uk = ops.linear_fwd(h.view(B * N, H), a.w(mlp[0].weight), mlp[0].bias.data, act=ops.ACT_GELU,
-                                    want_preact=True)
-            _, zk, sk = ops.ln_fwd(ak, None, None, mlp[2].weight.data, mlp[2].bias.data, 1e-5, p_post=p_ro,
-                                   rng=rt.rng, sid_post=gin._sid + k, out=ret, accumulate=k > 0)
-            reads.append((uk, zk, sk))
+        pf = [ops.p_fwd(h.view(B * N, H), a.w(mlp[0].weight), mlp[0].bias.data, act=ops.ACT_GELU, want_preact=True)
+              for mlp, h in zip(gin.linear_prediction, hs)]
+        ops.gemm_group(x.dtype, [t[0] for t in pf])  # the read-out projections in one launch
+        ret, stats = ops.ln_sum_fwd([t[1] for t in pf], [mlp[2].weight.data for mlp in gin.linear_prediction],
+                                    [mlp[2].bias.data for mlp in gin.linear_prediction], 1e-5, p_post=p_ro, rng=rt.rng,
+                                    sids=[gin._sid + k for k in range(len(pf))])
+        reads = [(u, act, st) for (_, act, u), st in zip(pf, stats)]
         ctx.rt, ctx.gin, ctx.p = rt, gin, p_ro
         ctx.saved = (adj, hs, hin, u, z1, st1, reads)
         return ret.view(B, N, H)
@@ -833,14 +836,17 @@ class GINFn(Function):
         B, N, H = hs[0].shape
         conv = gin.gnn_convs[0]
         d_ret = d_ret.contiguous().view(B * N, H)
-        dh = []
+        dh, probs = [], []
+        d_us = ops.ln_bwd_group([dict(dy=d_ret, z=zk, stats=sk, gamma=mlp[2].weight.data, dgamma=a.atomic_target(mlp[2].weight),
+                                      dbeta=a.atomic_target(mlp[2].bias), dbias=a.atomic_target(mlp[0].bias),
+                                      sid_post=gin._sid + k, gelu_aux=uk, defer=rt.defer_list())
+                                 for k, (mlp, (uk, zk, sk)) in enumerate(zip(gin.linear_prediction, reads))],
+                                p_post=ctx.p, rng=rt.rng)
         for k, (mlp, h) in enumerate(zip(gin.linear_prediction, hs)):
-            uk, zk, sk = reads[k]
-            d_u, _ = ops.ln_bwd(d_ret, zk, sk, mlp[2].weight.data, a.atomic_target(mlp[2].weight),
-                                a.atomic_target(mlp[2].bias), a.atomic_target(mlp[0].bias), p_post=ctx.p, rng=rt.rng,
-                                sid_post=gin._sid + k, gelu_aux=uk, defer=rt.defer_list())
-            _wgrad(rt, d_u, h.view(B * N, H), mlp[0].weight)
-            dh.append(ops.linear_dgrad(d_u, a.w(mlp[0].weight)))
+            pd, dhk = ops.p_dgrad(d_us[k][0], a.w(mlp[0].weight))
+            probs += [_p_wgrad(rt, d_us[k][0], h.view(B * N, H), mlp[0].weight), pd]
+            dh.append(dhk)
+        ops.gemm_group(d_ret.dtype, probs)  # weight and input gradients of the read-outs in one launch
         d_u, _ = ops.ln_bwd(dh[1], z1, st1, conv.linear[2].weight.data, a.atomic_target(conv.linear[2].weight),
                             a.atomic_target(conv.linear[2].bias), a.atomic_target(conv.linear[0].bias), gelu_aux=u,
                             defer=rt.defer_list())

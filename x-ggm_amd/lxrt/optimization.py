@@ -44,11 +44,14 @@ def _arena_of_params(params):
     return None
 
 
-def clip_grad_norm_(parameters, max_norm):
+def clip_grad_norm_(parameters, max_norm, tail=None):
     """fused replacement of ``nn.utils.clip_grad_norm_(model.parameters(), 5.)``
     (src/vqa/vqacpv2.py:175): one sum-of-squares reduction per active arena range; the scale
     min(1, max_norm/(norm+1e-6)) is applied INSIDE the following BertAdam.step (the gradients
-    in memory stay unscaled).  Returns the total norm as a device scalar."""
+    in memory stay unscaled).  Returns the total norm as a device scalar.
+    ``tail`` = (optimiser, runtime or None), given by ``vqa.vqacpv2.clip_and_step``: the launch that finishes the norm
+    also takes the schedule step of the ``optimiser.step()`` that follows and -- with a runtime -- the RNG advance that
+    ends the pass (``arena.sched_done`` / ``runtime.rng_advanced`` tell the two that their launch has been made)."""
     params = [p for p in parameters]
     arena = _arena_of_params(params)
     if arena is None:
@@ -85,9 +88,24 @@ def clip_grad_norm_(parameters, max_norm):
     # two launches for all ranges, two more for the slot table; sums in a fixed order (deterministic replicas); the
     # finish kernels seed the running sum and write the norm: no framework fill / add / sqrt kernels in the pass
     total = torch.empty(1, device=arena.grads.device, dtype=torch.float32)
-    ops.sqnorm_multi(arena.grads, spans, arena.sqnorm, None if slot_spans else total, overwrite=True)
-    if slot_spans:
-        ops.sqnorm_multi(arena.sq_slots, slot_spans, arena.sqnorm, total, overwrite=False, square=False)
+    if len(spans) + len(slot_spans) <= ops.CLIP_NORM_MAX_SPANS:
+        # one pair of launches for the ranges AND the slot table; the finishing one carries the pass's scalar bookkeeping
+        sched = rng = None
+        if tail is not None:
+            optim, rt = tail
+            entries = [(gi, pg['t_total'], pg['warmup']) for _, pg, gi in optim._todo(arena)]
+            if entries and len(entries) <= ops.CLIP_NORM_MAX_SCHED:
+                sched = (arena.steps, arena.lr_scale, entries)
+                arena.sched_done = True
+            if rt is not None:
+                rng = (rt.rng, 1)
+                rt.rng_advanced = True
+        ops.clip_norm(arena.grads, spans, arena.sq_slots if slot_spans else None, slot_spans, arena.sqnorm, total, sched=sched,
+                      rng=rng)
+    else:
+        ops.sqnorm_multi(arena.grads, spans, arena.sqnorm, None if slot_spans else total, overwrite=True)
+        if slot_spans:
+            ops.sqnorm_multi(arena.sq_slots, slot_spans, arena.sqnorm, total, overwrite=False, square=False)
     arena.pending_clip = float(max_norm)
     return total.view(())
 
@@ -270,14 +288,8 @@ class BertAdam(Optimizer):
         if arena is not None:
             arena.begin_pass()
 
-    @torch.no_grad()
-    def step(self, closure=None):
-        loss = closure() if closure is not None else None
-        arena = self._arena()
-        if arena is None:
-            raise RuntimeError("BertAdam.step: parameters are not arena-managed; run a forward/backward first")
-        sq = arena.sqnorm if arena.pending_clip is not None else None
-        max_norm = arena.pending_clip if arena.pending_clip is not None else 0.0
+    def _todo(self, arena):
+        """(group, its param_group, its index) for every arena group that received gradients in this pass"""
         todo = []
         for g in arena.active_groups():
             G = arena.groups[g]
@@ -287,8 +299,20 @@ class BertAdam(Optimizer):
             if any(p.grad is None for p in G.params):
                 raise RuntimeError("arena group '%s' received gradients for only part of its parameters" % g)
             todo.append((G, pg, arena.group_index[g]))
-        if todo:  # schedule values and step counters of all groups: one launch
+        return todo
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        arena = self._arena()
+        if arena is None:
+            raise RuntimeError("BertAdam.step: parameters are not arena-managed; run a forward/backward first")
+        sq = arena.sqnorm if arena.pending_clip is not None else None
+        max_norm = arena.pending_clip if arena.pending_clip is not None else 0.0
+        todo = self._todo(arena)
+        if todo and not getattr(arena, "sched_done", False):  # schedule values and step counters of all groups: one launch
             ops.sched_step_multi(arena.steps, arena.lr_scale, [(gi, pg['t_total'], pg['warmup']) for _, pg, gi in todo])
+        arena.sched_done = False  # (True: clip_grad_norm_'s finishing launch has taken the step along)
         if not torch.cuda.is_current_stream_capturing():
             self.sync_hyper()  # the kernels read lr from a device table: edits of param_groups survive graph replay
         elif any(arena.lr_host[gi] is None for _, _, gi in todo):

@@ -633,6 +633,73 @@ class LnBwdReq:
                                  ptr(now[1]), ptr(now[2]), None, ptr(ws), nb, M, sid_pre, 0, 0)
 
 
+class LnSumArgs(_ct.Structure):
+    """mirror of ``xggm_ln_sum_args`` (include/xggm.h)"""
+    _fields_ = [("inp", _ct.c_void_p * 4), ("gamma", _ct.c_void_p * 4), ("beta", _ct.c_void_p * 4), ("stats", _ct.c_void_p * 4),
+                ("sid_post", _ct.c_uint32 * 4), ("out", _ct.c_void_p), ("n", _ct.c_int), ("M", _ct.c_int), ("H", _ct.c_int),
+                ("eps", _ct.c_float), ("p_post", _ct.c_float), ("rng", _ct.c_void_p)]
+
+
+def ln_sum_fwd(xs, gammas, betas, eps, p_post=0.0, rng=None, sids=None):
+    """sum_k dropout(LayerNorm(xs[k])) for up to four [M, H] terms in ONE launch (the read-out of the graph blocks).
+    Returns (out, [stats_k]); the saved pre-normalisation rows are ``xs`` themselves."""
+    n = len(xs)
+    assert 1 <= n <= 4 and len(gammas) == n and len(betas) == n
+    M, H = xs[0].shape
+    a = LnSumArgs()
+    stats = []
+    for k, (x, g, b) in enumerate(zip(xs, gammas, betas)):
+        _c(x, xs[0].dtype), _c(g, F32, "gamma"), _c(b, F32, "beta")
+        assert tuple(x.shape) == (M, H) and g.numel() == H and b.numel() == H
+        st = torch.empty((M, 2), device=x.device, dtype=F32)
+        stats.append(st)
+        a.inp[k], a.gamma[k], a.beta[k], a.stats[k] = ptr(x), ptr(g), ptr(b), ptr(st)
+        a.sid_post[k] = int(sids[k]) if sids is not None else 0
+    out = torch.empty_like(xs[0])
+    a.out, a.n, a.M, a.H, a.eps, a.p_post, a.rng = ptr(out), n, M, H, float(eps), float(p_post), ptr(rng)
+    call("xggm_ln_sum_fwd_" + sfx(xs[0].dtype), _ct.byref(a), stream())
+    return out, stats
+
+
+def ln_bwd_group(items, p_pre=0.0, p_post=0.0, rng=None, out_scale=1.0):
+    """several LayerNorm backwards with one H and one pair of dropout rates in ONE launch (xggm_ln_bwd_grouped_*, four
+    problems per launch).  ``items``: dicts of the per-problem arguments of ``ln_bwd`` (dy, z, stats, gamma, dgamma, dbeta,
+    dbias, and optionally want_din, want_dres, d_res, sid_pre, sid_post, gelu_aux, defer).  Returns [(d_in, d_res)]."""
+    probs, outs, keep = [], [], []
+    dt, H = items[0]["dy"].dtype, items[0]["dy"].shape[1]
+    for it in items:
+        dy, z, stats = it["dy"], it["z"], it["stats"]
+        _c(dy, dt), _c(z, dt)
+        M = dy.shape[0]
+        assert dy.shape[1] == H and z.shape == dy.shape and tuple(stats.shape) == (M, 2)
+        now = (it.get("dgamma"), it.get("dbeta"), it.get("dbias"))
+        for t in now:
+            if t is not None:
+                _c(t, F32, "param grad")
+                assert t.numel() == H
+        d_in = torch.empty_like(dy) if it.get("want_din", True) else None
+        d_res = it.get("d_res")
+        acc = d_res is not None
+        if it.get("want_dres", False) and d_res is None:
+            d_res = torch.empty_like(dy)
+        if d_res is not None:
+            assert d_res.shape == dy.shape and d_res.dtype == dt and d_res.is_contiguous()
+        ws, nb = _ws(_lib.lib.xggm_ln_bwd_workspace_bytes(M, H), dy.device)
+        defer = it.get("defer")
+        if defer is not None and any(t is not None for t in now):
+            defer.append((ws, nb // (12 * H), 3, H, now))
+            now = (None, None, None)
+        probs.append(LnBwdProblem(ptr(dy), ptr(z), ptr(stats), ptr(it["gamma"]), ptr(d_in), ptr(d_res), ptr(now[0]), ptr(now[1]),
+                                  ptr(now[2]), ptr(it.get("gelu_aux")), ptr(ws), nb, M, it.get("sid_pre", 0),
+                                  it.get("sid_post", 0), int(acc)))
+        outs.append((d_in, d_res))
+        keep.append(ws)
+    arr = (LnBwdProblem * len(probs))(*probs)
+    call("xggm_ln_bwd_grouped_" + sfx(dt), _ct.cast(arr, _ct.c_void_p), len(probs), H, float(p_pre), float(p_post), ptr(rng),
+         float(out_scale), stream())
+    return outs
+
+
 def prefetch_next(t):
     """queue the bytes of tensor ``t`` (a contiguous slice of a weight buffer) for the next LayerNorm / attention launch to
     read beside its own work and discard (xggm_prefetch_next): the products behind that launch then find their weights
@@ -1046,6 +1113,57 @@ def sqnorm_multi(buf, spans, out, norm=None, overwrite=True, square=True, mul=1.
         last = ci == len(chunks) - 1
         call("xggm_sqnorm_multi_f32", ptr(buf), _ct.cast(offs, _ct.c_void_p), _ct.cast(lens, _ct.c_void_p), len(ch), ptr(out),
              ptr(norm) if last else None, ptr(ws), int(overwrite and ci == 0), int(square), float(mul) if last else 1.0, stream())
+
+
+class _PassTail(_ct.Structure):
+    _fields_ = [("steps", _ct.c_void_p), ("lr_scale", _ct.c_void_p), ("index", _ct.c_void_p), ("t_total", _ct.c_void_p),
+                ("warmup", _ct.c_void_p), ("n", _ct.c_int), ("rng", _ct.c_void_p), ("rng_by", _ct.c_uint64)]
+
+
+CLIP_NORM_MAX_SPANS = 24
+CLIP_NORM_MAX_SCHED = 16
+
+
+def clip_norm(g, spans, slots, slot_spans, out, norm=None, mul=1.0, sched=None, rng=None):
+    """out (1 fp32) = mul * (sum over the (start, end) ranges ``spans`` of g^2 + sum over ``slot_spans`` of slots), fixed
+    summation order, ``norm`` (1 fp32 or None) = sqrt(out): the whole norm of a pass in two launches.  The finishing
+    launch also takes ``sched`` = (steps, lr_scale, [(index, t_total, warmup)]) (sched_step_multi) and ``rng`` =
+    (state, by) (rng_advance) along.  At most 24 ranges and 16 schedule entries."""
+    _c(g, F32), _c(out, F32)
+    rs = [(s, e) for s, e in spans if e > s]
+    ss = [(s, e) for s, e in slot_spans if e > s]
+    assert len(rs) + len(ss) <= CLIP_NORM_MAX_SPANS
+    if ss:
+        _c(slots, F32)
+    ws = _SQNORM_WS.get(g.device)
+    if ws is None:
+        ws = _SQNORM_WS[g.device] = torch.zeros(4100, device=g.device, dtype=F32)
+
+    def arrs(r):
+        return ((_ct.c_int64 * max(len(r), 1))(*[s for s, _ in r]), (_ct.c_int64 * max(len(r), 1))(*[e - s for s, e in r]))
+
+    o1, l1 = arrs(rs)
+    o2, l2 = arrs(ss)
+    tail = None
+    if sched is not None or rng is not None:
+        tail = _PassTail()
+        keep = []
+        if sched is not None:
+            steps, lr_scale, entries = sched
+            _c(steps, torch.int64), _c(lr_scale, F32)
+            n = len(entries)
+            assert n <= CLIP_NORM_MAX_SCHED
+            idx = (_ct.c_int * max(n, 1))(*[int(e[0]) for e in entries])
+            tt = (_ct.c_int64 * max(n, 1))(*[int(e[1]) for e in entries])
+            wu = (_ct.c_float * max(n, 1))(*[float(e[2]) for e in entries])
+            keep += [idx, tt, wu]
+            tail.steps, tail.lr_scale, tail.n = ptr(steps), ptr(lr_scale), n
+            tail.index, tail.t_total, tail.warmup = (_ct.cast(a, _ct.c_void_p) for a in (idx, tt, wu))
+        if rng is not None:
+            tail.rng, tail.rng_by = ptr(rng[0]), int(rng[1])
+    call("xggm_clip_norm_f32", ptr(g), _ct.cast(o1, _ct.c_void_p), _ct.cast(l1, _ct.c_void_p), len(rs),
+         ptr(slots) if ss else None, _ct.cast(o2, _ct.c_void_p), _ct.cast(l2, _ct.c_void_p), len(ss), ptr(out),
+         ptr(norm) if norm is not None else None, ptr(ws), float(mul), _ct.byref(tail) if tail is not None else None, stream())
 
 
 def additive_mask(mask):

@@ -170,30 +170,34 @@ def forward_backward_ggm(model, bce_loss, feats, boxes, sent, target, adj_true, 
     return loss.detach(), logit.detach(), dict(d_loss=_Scaled(d_loss, w_kl / A), loss_grad=_Scaled(loss_grad, w_dsm))
 
 
-def clip_and_step(model, optim, clip=5.0):
+def clip_and_step(model, optim, clip=5.0, advance=False):
     """nn.utils.clip_grad_norm_(params, 5.) + optim.step() + optim.zero_grad()
-    (src/vqa/vqacpv2.py:175-177), fused: one norm reduction, one update pass."""
-    total = clip_grad_norm_(model.parameters(), clip)
+    (src/vqa/vqacpv2.py:175-177), fused: one norm reduction, one update pass.  ``advance``: also end the pass
+    (Runtime.advance: new dropout masks / noise for the next one) -- the RNG step then rides on the norm's last launch."""
+    rt = runtime_of(model)
+    total = clip_grad_norm_(model.parameters(), clip, tail=(optim, rt if advance else None))
     optim.step()
-    z = runtime_of(model).arena.zero1
+    z = rt.arena.zero1
     if z is not None:
         z.gather()  # sharded update: the other ranks' slices of the bf16 weights
     optim.zero_grad()
+    if advance:
+        rt.advance()
     return total
 
 
-def plain_pass(model, optim, bce_loss, feats, boxes, sent, target, clip=5.0):
+def plain_pass(model, optim, bce_loss, feats, boxes, sent, target, clip=5.0, advance=False):
     out = forward_backward_plain(model, bce_loss, feats, boxes, sent, target)
     _sync_grads(model)
-    clip_and_step(model, optim, clip)
+    clip_and_step(model, optim, clip, advance)
     return out
 
 
 def ggm_pass(model, optim, bce_loss, feats, boxes, sent, target, adj_true, branch, sigma=1.0, kl_weight=8.0,
-             randn=None, clip=5.0):
+             randn=None, clip=5.0, advance=False):
     out = forward_backward_ggm(model, bce_loss, feats, boxes, sent, target, adj_true, branch, sigma, kl_weight, randn)
     _sync_grads(model)
-    clip_and_step(model, optim, clip)
+    clip_and_step(model, optim, clip, advance)
     return out
 
 
@@ -220,17 +224,13 @@ def train_iteration(model, optim, bce_loss, batch, delta=5, sigma=1.0, order="vq
     args = (batch["feats"], batch["boxes"], batch["sent"], batch["target"])
     out = {}
     if order == "vqa":
-        out["loss_plain"], out["logit"] = plain_pass(model, optim, bce_loss, *args, clip=clip)
-        rt.advance()
+        out["loss_plain"], out["logit"] = plain_pass(model, optim, bce_loss, *args, clip=clip, advance=True)
         out["loss_ggm"], _, ex = ggm_pass(model, optim, bce_loss, *args, batch["adj_true"], branch, sigma, 8.0,
-                                          clip=clip)
-        rt.advance()
+                                          clip=clip, advance=True)
     else:
         out["loss_ggm"], _, ex = ggm_pass(model, optim, bce_loss, *args, batch["adj_true"], branch, sigma, 12.0,
-                                          clip=clip)
-        rt.advance()
-        out["loss_plain"], out["logit"] = plain_pass(model, optim, bce_loss, *args, clip=clip)
-        rt.advance()
+                                          clip=clip, advance=True)
+        out["loss_plain"], out["logit"] = plain_pass(model, optim, bce_loss, *args, clip=clip, advance=True)
     out.update(ex)
     out["branch"] = branch
     return out
