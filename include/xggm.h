@@ -368,6 +368,19 @@ int xggm_embed_bwd_bf16(const int64_t* ids, const int64_t* seg, const void* dy, 
                         const float* gamma, void* dz_ws, float* dword, float* dpos, float* dtype, float* dgamma,
                         float* dbeta, int M, int Tlen, int H, float p, const uint64_t* rng, uint32_t sid, float* ws,
                         size_t ws_bytes, xggm_stream_t stream);
+/* xggm_embed_bwd_* that also LISTS what it did to the word table's gradient (M <= the capacity of the three buffers):
+ * row_ids[r] = ids[r]; row_sq[r] = |dword[ids[r]]|^2 after the add where batch row r is the owner of that table row, 0
+ * elsewhere (so sum(row_sq[0 .. M)) is the table's contribution to clip_grad_norm_ when the table was zero before);
+ * *row_n = M.  A caller that keeps the invariant "every non-zero row of dword is listed" clears the table with
+ * xggm_zero_ranges_rows_f32 and never reads its 94 MB for the norm. */
+int xggm_embed_bwd_listed_f32(const int64_t* ids, const int64_t* seg, const void* dy, const void* z, const float* stats,
+                              const float* gamma, void* dz_ws, float* dword, float* dpos, float* dtype, float* dgamma,
+                              float* dbeta, int M, int Tlen, int H, float p, const uint64_t* rng, uint32_t sid, float* ws,
+                              size_t ws_bytes, int64_t* row_ids, float* row_sq, int* row_n, xggm_stream_t stream);
+int xggm_embed_bwd_listed_bf16(const int64_t* ids, const int64_t* seg, const void* dy, const void* z, const float* stats,
+                               const float* gamma, void* dz_ws, float* dword, float* dpos, float* dtype, float* dgamma,
+                               float* dbeta, int M, int Tlen, int H, float p, const uint64_t* rng, uint32_t sid, float* ws,
+                               size_t ws_bytes, int64_t* row_ids, float* row_sq, int* row_n, xggm_stream_t stream);
 /* VisualFeatEncoder tail: src/lxrt/modeling.py:546-556.  u = feat @ W_f^T (T, from
  * xggm_gemm); boxes T [M,4]; W_b fp32 [H,4].  z1 may alias u.  stats [M,4]. */
 int xggm_visn_embed_fwd_f32(const void* u, const float* bf, const void* boxes, const float* Wb, const float* bb,
@@ -600,6 +613,10 @@ int xggm_pad_rows_bf16(const void* src, int src_f32, void* dst, int rows, int n,
  * atomically accumulated gradient ranges of all parameter groups at the start of a backward pass.
  * offsets / lengths are HOST arrays (copied into the kernel arguments); both multiples of 4. */
 int xggm_zero_ranges_f32(float* base, const int64_t* offsets, const int64_t* lengths, int n, xggm_stream_t stream);
+/* the same fill (n may be 0) and, in the same launch, rows row_ids[0 .. min(*row_n, row_cap)) of the fp32 table
+ * [R, H] zeroed (row_ids / row_n: DEVICE buffers, as xggm_embed_bwd_listed_* left them; H a multiple of 4) */
+int xggm_zero_ranges_rows_f32(float* base, const int64_t* offsets, const int64_t* lengths, int n, float* table,
+                              const int64_t* row_ids, const int* row_n, int row_cap, int64_t R, int H, xggm_stream_t stream);
 
 /* ---- small element-wise kernels ---------------------------------------------------------
  * out = scale * (1 + *scale_ptr) * x   (GIN's (1+eps), src/module/gin.py:32) */

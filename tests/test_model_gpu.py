@@ -987,6 +987,73 @@ def test_trainer_written_with_plain_torch_statements_equals_the_fused_pass(branc
         assert cos > 0.9 and bool(torch.isfinite(db).all()), cos
 
 
+@pytest.mark.parametrize("dt", [F32, BF16])
+def test_word_table_gradient_kept_row_sparse_between_passes(dt):
+    """arena.RowList: from the second pass on the start of the backward clears only the rows of the word table's gradient
+    the previous pass listed, and clip_grad_norm_ adds the listed per-row sums of squares instead of reading the table
+    (src/lxrt/modeling.py:298-313, src/vqa/vqacpv2.py:175).  Against the same passes with the bookkeeping switched off:
+    the same parameters bit for bit after five passes over five different batches (the clip not binding, so the two
+    norms' different summation order cannot matter), the same norm to 2e-6, a dense gradient view whose rows outside the
+    current batch are exactly zero, and the sparse path really taken."""
+    from oracle import shapes
+    from xggm_amd.runtime import runtime_of
+    from xggm_amd.lxrt.optimization import clip_grad_norm_
+    from xggm_amd.vqa.vqacpv2 import forward_backward_plain, clip_and_step, BCEWithLogitsLoss, make_optimizer
+    cfg, A, B = shapes.TINY, 17, 4
+    bce = BCEWithLogitsLoss()
+    batches = [batch_tensors(synth.vqa_batch(B, A=A, F=cfg["feat_dim"], vocab=cfg["vocab"], seed=30 + i), DEV) for i in range(5)]
+    models, norms = [], []
+    for sparse in (True, False):
+        m = build_model(cfg, A, seed=8, dt=dt).train()
+        opt = make_optimizer(m, 1e-3, 20)
+        arena = runtime_of(m).arena
+        arena.row_list_enabled = sparse
+        ns = []
+        for i, b in enumerate(batches):
+            sent = (b["input_ids"], b["input_mask"], b["segment_ids"])
+            forward_backward_plain(m, bce, b["feats"], b["boxes"], sent, b["target"])
+            wt = m.lxrt_encoder.model.bert.embeddings.word_embeddings.weight
+            used = torch.zeros(wt.shape[0], dtype=torch.bool, device=DEV)
+            used[b["input_ids"].view(-1)] = True
+            assert float(wt.grad[~used].abs().max()) == 0.0 and float(wt.grad[used].abs().max()) > 0.0
+            ns.append(float(clip_grad_norm_(m.parameters(), 1e9)))
+            want = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters() if p.grad is not None)))
+            assert abs(ns[-1] - want) < 2e-6 * want
+            rl = arena.row_list
+            if sparse:
+                assert rl is not None and rl.clean and rl.listed == b["input_ids"].numel() and int(rl.n) == rl.listed
+                assert sorted(set(rl.ids[:rl.listed].tolist())) == sorted(set(b["input_ids"].view(-1).tolist()))
+            else:
+                assert rl is None
+            clip_and_step(m, opt, 1e9, advance=True)
+        models.append(m)
+        norms.append(ns)
+    for a, b_ in zip(norms[0], norms[1]):
+        assert abs(a - b_) < 2e-6 * b_
+    sa, sb = models[0].state_dict(), models[1].state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    # what the list cannot vouch for drops it: a second backward without zero_grad() accumulates over other rows
+    m = models[0]
+    arena = runtime_of(m).arena
+    b0, b1 = batches[0], batches[1]
+    forward_backward_plain(m, bce, b0["feats"], b0["boxes"], (b0["input_ids"], b0["input_mask"], b0["segment_ids"]), b0["target"])
+    assert arena.row_list.clean and arena.row_list.listed
+    _, _, x = m(b1["feats"], b1["boxes"], (b1["input_ids"], b1["input_mask"], b1["segment_ids"]))
+    runtime_of(m).backward(bce(m.logit_fc(x), b1["target"], scale=A))
+    assert not arena.row_list.clean and not arena.row_list.listed
+    total = float(clip_grad_norm_(m.parameters(), 1e9))
+    want = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters() if p.grad is not None)))
+    assert abs(total - want) < 2e-6 * want
+    m.zero_grad()
+    forward_backward_plain(m, bce, b0["feats"], b0["boxes"], (b0["input_ids"], b0["input_mask"], b0["segment_ids"]), b0["target"])
+    wt = m.lxrt_encoder.model.bert.embeddings.word_embeddings.weight
+    used = torch.zeros(wt.shape[0], dtype=torch.bool, device=DEV)
+    used[b0["input_ids"].view(-1)] = True
+    assert float(wt.grad[~used].abs().max()) == 0.0  # the dense clear has caught the rows of BOTH batches
+    assert arena.row_list.clean and arena.row_list.listed
+
+
 def test_switching_the_compute_dtype_rebuilds_the_arena():
     """runtime.set_compute_dtype: one model object, bf16 execution, then exact-fp32 execution, then bf16 again; every
     switch rebuilds the arena around the SAME parameters (the optimiser keeps working on them), and each mode gives

@@ -178,7 +178,11 @@ class ParamArena:
                     self.sq_base[n] = n_slots
                     n_slots += k // 4096
             self.sq_range[gname] = (first, n_slots)
-        self.sq_slots = torch.zeros(_align(max(n_slots, 1)), device=dev, dtype=torch.float32)
+        # ... and behind them ROW_LIST_CAP slots for the word table's gradient rows (RowList below)
+        self.row_sq0 = _align(max(n_slots, 1))
+        self.sq_slots = torch.zeros(self.row_sq0 + ROW_LIST_CAP, device=dev, dtype=torch.float32)
+        self.row_list = None       # RowList of the word-embedding table, made at its first backward
+        self.row_list_enabled = True  # off when gradients are exchanged between ranks (other ranks' rows arrive)
         self.sq_covered = set()  # names whose gradient of this pass is accounted for in the slots
         self.sq_clean = False    # slots zeroed since the last zero_grad()
         self.named = dict(named)
@@ -264,6 +268,7 @@ class ParamArena:
         if self.wire is None:
             self.wire = torch.zeros(self.total, device=self.device, dtype=torch.bfloat16)
         self.sq_enabled = False
+        self.row_list_enabled = False
         return self.wire
 
     def grad_view(self, ps, wire=False):
@@ -287,6 +292,8 @@ class ParamArena:
         ranges can be cleared with one fill per group at the next backward."""
         self.vec_zeroed = False
         self.emb_uses = 0  # look-ups of the word table since zero_grad() (dist.GradSync: the sparse exchange needs exactly one)
+        if self.row_list is not None:
+            self.row_list.listed = 0
         self.pending_clip = None
         self.sq_covered.clear()
         self.sq_clean = False
@@ -338,14 +345,42 @@ class ParamArena:
             # first atomic touch after zero_grad(): one fill per group, valid only while no
             # atomically accumulated gradient is live
             self.all_dirty = not all(q.grad is None for q in self._atomic_params)
+            rl = self.row_list
             if not self.all_dirty:
-                ops.zero_ranges(self.grads, [(G.vec_start, G.end) for G in self.groups.values()])  # one launch
+                ranges = [(G.vec_start, G.end) for G in self.groups.values()]
+                if rl is not None and rl.clean and self.row_list_enabled:
+                    # every non-zero row of the word table's gradient is on the device-side list the last pass left:
+                    # those rows are cleared instead of the table's 94 MB (same launch)
+                    ranges = _cut(ranges, rl.o, rl.o + rl.R * rl.H)
+                    ops.zero_ranges(self.grads, ranges, rows=(self.grads[rl.o:rl.o + rl.R * rl.H].view(rl.R, rl.H), rl.ids, rl.n))
+                else:
+                    ops.zero_ranges(self.grads, ranges)  # one launch
+                    if rl is not None:
+                        rl.clean = True  # the table is all zero: any list covers its non-zero rows
                 self.touched.clear()
+            elif rl is not None:
+                rl.clean = False  # gradients are being accumulated over several backwards: the list would miss rows
             self.vec_zeroed = True
         if self.all_dirty or not p._xg[4] or name in self.touched:
             o, k = p._xg[1], p._xg[2]
             ops.zero_ranges(self.grads, [(o, o + (k + 3) // 4 * 4)])  # offsets are 8-aligned: the padding is ours
         self.touched.add(name)
+
+    def row_list_for(self, p, M):
+        """the (ids, sq, n) buffers the embedding backward fills for table ``p`` when the row-sparse bookkeeping of its
+        gradient holds for this pass (RowList), else None (the table is then cleared and read as a whole)"""
+        if not self.row_list_enabled:
+            return None
+        rl = self.row_list
+        if rl is None or rl.name != p._xg[5]:
+            rl = self.row_list = RowList(self, p)
+            # first backward through this table: its gradient is all zero if this pass began with the groups' fill
+            rl.clean = bool(p._xg[4]) and self.vec_zeroed and not self.all_dirty
+        if not rl.clean or self.emb_uses != 1 or M > ROW_LIST_CAP:
+            rl.clean, rl.listed = False, 0
+            return None
+        rl.listed = int(M)
+        return rl.ids, self.sq_slots[self.row_sq0:self.row_sq0 + ROW_LIST_CAP], rl.n
 
     def atomic_target(self, ps):
         """fp32 grad view for gradients accumulated with atomics: cleared on first touch."""
@@ -366,6 +401,43 @@ class ParamArena:
             if any(p.grad is not None for p in G.params):
                 act.append(g)
         return act
+
+
+ROW_LIST_CAP = 8192  # look-ups of the word table per pass the row list holds (B * T: 5120 at 256 samples of 20 tokens)
+
+
+class RowList:
+    """Row-sparse bookkeeping of ONE embedding table's gradient (the word table: 30522 x 768 fp32 = 94 MB, of which a
+    pass touches at most B * T rows; src/lxrt/modeling.py:298-313).  Invariant while ``clean``: every non-zero row of the
+    table's gradient is among ``ids[:n]`` (device buffers the embedding backward rewrites, xggm_embed_bwd_listed_*).
+    Then the start of the next backward clears those rows instead of the table (ParamArena._clear_for_first_touch) and
+    clip_grad_norm_ adds the ``listed`` per-row sums of squares instead of reading it.  ``p.grad`` stays the dense view
+    and the update stays dense (moments and weight decay move every row, src/lxrt/optimization.py:159-193).  Anything the
+    list cannot vouch for -- two look-ups in one pass, gradients accumulated over several backwards, more look-ups than
+    the buffers hold, gradients exchanged between ranks -- drops ``clean``, and the next pass falls back to the dense
+    clear and read."""
+
+    def __init__(self, arena, p):
+        self.name, self.o = p._xg[5], p._xg[1]
+        self.R, self.H = p.shape
+        self.ids = torch.zeros(ROW_LIST_CAP, device=arena.device, dtype=torch.int64)
+        self.n = torch.zeros(1, device=arena.device, dtype=torch.int32)
+        self.clean = False
+        self.listed = 0  # rows the embedding backward of THIS pass has listed (0: the norm reads the table)
+
+
+def _cut(ranges, a, b):
+    """(start, end) ranges minus [a, b)"""
+    out = []
+    for s, e in ranges:
+        if e <= a or s >= b:
+            out.append((s, e))
+            continue
+        if s < a:
+            out.append((s, a))
+        if e > b:
+            out.append((b, e))
+    return out
 
 
 def arena_of(model, compute_dtype=None):

@@ -105,6 +105,60 @@ extern "C" int xggm_zero_ranges_f32(float* base, const int64_t* offsets, const i
     return xggm_check_launch("xggm_zero_ranges_f32");
 }
 
+namespace {
+// the same fill plus the LISTED rows of one [R, H] table (row ids and their count live on the device: the list the last
+// xggm_embed_bwd_listed_* left) -- the word table's gradient is 94 MB of which a pass makes <= B * T rows non-zero
+__global__ __launch_bounds__(NT) void zero_ranges_rows_kernel(float* base, Ranges r, int range_blocks, float* table,
+                                                              const int64_t* __restrict__ ids, const int* __restrict__ n_ptr, int cap,
+                                                              int64_t R, int H) {
+    typedef float __attribute__((ext_vector_type(4))) f4;
+    if ((int)blockIdx.x < range_blocks) {
+        const int64_t total = r.start[r.n];
+        for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)range_blocks * NT) {
+            int k = 0;
+#pragma unroll
+            for (int j = 1; j < MAX_RANGES; ++j)
+                if (j < r.n && i >= r.start[j]) k = j;
+            __builtin_nontemporal_store((f4){0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f4*>(base + r.off[k]) + (i - r.start[k]));
+        }
+        return;
+    }
+    const int n = min(*n_ptr, cap), nb = gridDim.x - range_blocks;
+    for (int i = blockIdx.x - range_blocks; i < n; i += nb) {
+        const int64_t id = ids[i];
+        if (id < 0 || id >= R) continue;  // (never: the forward has read this row)
+        f4* row = reinterpret_cast<f4*>(table + id * H);
+        for (int c = threadIdx.x; c < H / 4; c += NT) row[c] = (f4){0.f, 0.f, 0.f, 0.f};
+    }
+}
+}  // namespace
+
+extern "C" int xggm_zero_ranges_rows_f32(float* base, const int64_t* offsets, const int64_t* lengths, int n, float* table,
+                                         const int64_t* row_ids, const int* row_n, int row_cap, int64_t R, int H, hipStream_t st) {
+    XGGM_REQUIRE(base && n >= 0 && n <= MAX_RANGES && (n == 0 || (offsets && lengths)), "xggm_zero_ranges_rows_f32: bad ranges (n = %d)", n);
+    XGGM_REQUIRE(table && row_ids && row_n && row_cap > 0 && R > 0 && H > 0 && H % 4 == 0,
+                 "xggm_zero_ranges_rows_f32: bad row list (cap %d, table %lld x %d)", row_cap, (long long)R, H);
+    XGGM_REQUIRE((reinterpret_cast<uintptr_t>(base) | reinterpret_cast<uintptr_t>(table)) % 16 == 0,
+                 "xggm_zero_ranges_rows_f32: buffers must be 16-byte aligned");
+    Ranges r;
+    r.n = n;
+    int64_t tot = 0;
+    for (int i = 0; i < n; ++i) {
+        XGGM_REQUIRE(offsets[i] >= 0 && lengths[i] >= 0 && offsets[i] % 4 == 0 && lengths[i] % 4 == 0,
+                     "xggm_zero_ranges_rows_f32: range %d is not float4-aligned", i);
+        r.off[i] = offsets[i];
+        r.len4[i] = lengths[i] / 4;
+        r.start[i] = tot;
+        tot += r.len4[i];
+    }
+    r.start[n] = tot;
+    const int range_blocks = (int)std::min<int64_t>(ceil_div64(tot, NT), 4096);
+    const int row_blocks = std::min(row_cap, 1024);
+    hipLaunchKernelGGL(zero_ranges_rows_kernel, dim3(range_blocks + row_blocks), dim3(NT), 0, st, base, r, range_blocks, table,
+                       row_ids, row_n, row_cap, R, H);
+    return xggm_check_launch("xggm_zero_ranges_rows_f32");
+}
+
 EW_API(f32, float)
 EW_API(bf16, bf16)
 

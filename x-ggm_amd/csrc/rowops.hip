@@ -766,10 +766,18 @@ __global__ __launch_bounds__(NT) void embed_fwd_kernel(const int64_t* __restrict
 // a plain read-modify-write).  The sum's order is fixed by the data, not by the scheduling: same inputs, same bits.
 // ([CLS] / [SEP] occur once per sample: 32 serial atomics per address before, four rounds of eight loads now.)
 constexpr int ES_CAP = 512;  // list entries per wave; longer lists are summed in several rounds
+// Optional by-products for the caller that keeps the word table's gradient row-sparse between passes (the table is 94 MB
+// of which a pass touches <= B * T rows): ids[r] = the table row batch row r looked up, sq[r] = |gradient row|^2 after
+// the add where r is the row's owner and 0 elsewhere, *n = M.  All three null: nothing is written.
+struct RowList {
+    int64_t* ids;
+    float* sq;
+    int* n;
+};
 template <typename T, int NV>
 __global__ __launch_bounds__(NT) void embed_scatter_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ seg,
                                                            const T* __restrict__ dz, float* dword, float* dpos, float* dtype,
-                                                           int M, int Tlen, int H) {
+                                                           int M, int Tlen, int H, RowList rl) {
     __shared__ int list[WPB][ES_CAP];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int task = blockIdx.x * WPB + wid;  // wave-uniform
@@ -819,11 +827,18 @@ __global__ __launch_bounds__(NT) void embed_scatter_kernel(const int64_t* __rest
         }
     };
     float* target = nullptr;
+    bool listed = false;  // wave-uniform: this wave owns a listed row of the word table
+    int list_slot = 0;
     if (task < n_word + n_type) {
         const bool is_word = task < n_word;
         const int r = is_word ? task : task - n_word;
         const int64_t* key = is_word ? ids : seg;
         const int64_t k = key[r];
+        if (is_word && rl.ids && lane == 0) {  // the rows of the word table this pass leaves non-zero (xggm_embed_bwd_listed_*)
+            rl.ids[r] = k;
+            rl.sq[r] = 0.f;  // the owner of the row overwrites it below
+            if (r == 0) *rl.n = M;
+        }
         if (k == 0) return;  // padding_idx
         // owner = first row with this key
         bool seen = false;
@@ -832,6 +847,8 @@ __global__ __launch_bounds__(NT) void embed_scatter_kernel(const int64_t* __rest
             seen = __ballot(q < r && key[q] == k) != 0ull;
         }
         if (seen) return;
+        listed = is_word && rl.ids;
+        list_slot = r;
         int cnt = 0;
         for (int q0 = r & ~63; q0 < M; q0 += 64) {
             const int q = q0 + lane;
@@ -862,15 +879,23 @@ __global__ __launch_bounds__(NT) void embed_scatter_kernel(const int64_t* __rest
         }
         target = dpos + (int64_t)t * H;
     }
+    float sq = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v)
         if (ok[v]) {
             float o[4];
             load4(target + cc[v], o);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] += acc[v][i];
+            for (int i = 0; i < 4; ++i) {
+                o[i] += acc[v][i];
+                sq += o[i] * o[i];
+            }
             store4(target + cc[v], o);
         }
+    if (listed) {  // |row|^2 of the table gradient as it stands now: clip_grad_norm_ adds these instead of reading the table
+        sq = wave_sum(sq);
+        if (lane == 0) rl.sq[list_slot] = sq;
+    }
 }
 
 // ------------------------------------------------------------------------------- visual embedding
@@ -1267,8 +1292,10 @@ int embed_fwd(const int64_t* ids, const int64_t* seg, const void* word, const vo
 template <typename T>
 int embed_bwd(const int64_t* ids, const int64_t* seg, const void* dy, const void* z, const float* stats, const float* gamma,
               void* dz_ws, float* dword, float* dpos, float* dtype, float* dgamma, float* dbeta, int M, int Tlen, int H,
-              float p, const uint64_t* rng, uint32_t sid, float* ws, size_t ws_bytes, hipStream_t st) {
+              float p, const uint64_t* rng, uint32_t sid, float* ws, size_t ws_bytes, RowList rl, hipStream_t st) {
     if (int e = check_row_shape("xggm_embed_bwd", M, H)) return e;
+    XGGM_REQUIRE((rl.ids != nullptr) == (rl.sq != nullptr) && (rl.ids != nullptr) == (rl.n != nullptr),
+                 "xggm_embed_bwd_listed: the row list is ids + squares + count, or nothing");
     XGGM_REQUIRE(ids && dy && z && stats && gamma && dz_ws && dword && dpos && dtype, "xggm_embed_bwd: null pointer");
     if (int e = ln_bwd<T>(dy, z, stats, gamma, dz_ws, nullptr, dgamma, dbeta, nullptr, M, H, 0.f, p, rng, 0, sid, 1.0f, 0,
                           nullptr, ws, ws_bytes, st))
@@ -1276,7 +1303,7 @@ int embed_bwd(const int64_t* ids, const int64_t* seg, const void* dy, const void
     XGGM_REQUIRE(Tlen > 0 && M % Tlen == 0, "xggm_embed_bwd: M=%d is not a multiple of T=%d", M, Tlen);
     const int tasks = M + (seg ? M : 0) + Tlen;  // one wave per candidate owner, see embed_scatter_kernel
     DISPATCH_NV(H, hipLaunchKernelGGL((embed_scatter_kernel<T, NV>), dim3(ceil_div(tasks, WPB)), dim3(NT), 0, st, ids, seg,
-                                       (const T*)dz_ws, dword, dpos, dtype, M, Tlen, H));
+                                       (const T*)dz_ws, dword, dpos, dtype, M, Tlen, H, rl));
     return xggm_check_launch("xggm_embed_bwd(scatter)");
 }
 
@@ -1393,7 +1420,16 @@ size_t ws_colsum(int M, int N) { return sizeof(float) * (size_t)ceil_div(M, CS_R
                                         float* dtype, float* dgamma, float* dbeta, int M, int Tlen, int H, float p,        \
                                         const uint64_t* rng, uint32_t sid, float* ws, size_t ws_bytes, hipStream_t st) {  \
         return embed_bwd<T>(ids, seg, dy, z, stats, gamma, dz_ws, dword, dpos, dtype, dgamma, dbeta, M, Tlen, H, p, rng,   \
-                            sid, ws, ws_bytes, st);                                                                        \
+                            sid, ws, ws_bytes, RowList{nullptr, nullptr, nullptr}, st);                                    \
+    }                                                                                                                       \
+    extern "C" int xggm_embed_bwd_listed_##SUF(const int64_t* ids, const int64_t* seg, const void* dy, const void* z,      \
+                                               const float* stats, const float* gamma, void* dz_ws, float* dword,          \
+                                               float* dpos, float* dtype, float* dgamma, float* dbeta, int M, int Tlen,    \
+                                               int H, float p, const uint64_t* rng, uint32_t sid, float* ws,              \
+                                               size_t ws_bytes, int64_t* row_ids, float* row_sq, int* row_n,               \
+                                               hipStream_t st) {                                                           \
+        return embed_bwd<T>(ids, seg, dy, z, stats, gamma, dz_ws, dword, dpos, dtype, dgamma, dbeta, M, Tlen, H, p, rng,   \
+                            sid, ws, ws_bytes, RowList{row_ids, row_sq, row_n}, st);                                       \
     }                                                                                                                       \
     extern "C" int xggm_visn_embed_fwd_##SUF(const void* u, const float* bf, const void* boxes, const float* Wb,           \
                                              const float* bb, const float* g1, const float* b1, const float* g2,           \

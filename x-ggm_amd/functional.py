@@ -205,7 +205,8 @@ class EmbedFn(Function):
         ops.embed_bwd(ids, seg, dy.contiguous(), z, stats, mod.LayerNorm.weight.data,
                       a.atomic_target(mod.word_embeddings.weight), a.atomic_target(mod.position_embeddings.weight),
                       a.atomic_target(mod.token_type_embeddings.weight), a.atomic_target(mod.LayerNorm.weight),
-                      a.atomic_target(mod.LayerNorm.bias), ctx.p, rt.rng, mod._sid)
+                      a.atomic_target(mod.LayerNorm.bias), ctx.p, rt.rng, mod._sid,
+                      row_list=a.row_list_for(mod.word_embeddings.weight, dy.numel() // dy.shape[-1]))
         return (None,) * (4 + ctx.np)
 
 

@@ -87,6 +87,15 @@ def clip_grad_norm_(parameters, max_norm, tail=None):
         slot_spans.append(arena.sq_range[g])
     # two launches for all ranges, two more for the slot table; sums in a fixed order (deterministic replicas); the
     # finish kernels seed the running sum and write the norm: no framework fill / add / sqrt kernels in the pass
+    rl = arena.row_list
+    if rl is not None and rl.clean and rl.listed and arena.row_list_enabled:
+        # the word table's gradient: its non-zero rows are the ones the embedding backward of this pass listed, with
+        # their sums of squares in the slots behind the products' -- 94 MB the norm does not read (arena.RowList)
+        from ..arena import _cut
+        cut = _cut([tuple(sp) for sp in spans], rl.o, rl.o + rl.R * rl.H)
+        if cut != [tuple(sp) for sp in spans]:
+            spans = [list(sp) for sp in cut]
+            slot_spans.append((arena.row_sq0, arena.row_sq0 + rl.listed))
     total = torch.empty(1, device=arena.grads.device, dtype=torch.float32)
     if len(spans) + len(slot_spans) <= ops.CLIP_NORM_MAX_SPANS:
         # one pair of launches for the ranges AND the slot table; the finishing one carries the pass's scalar bookkeeping

@@ -834,7 +834,9 @@ def embed_fwd(ids, seg, word, pos, typ, gamma, beta, eps, p, rng, sid, emit8=Non
     return out, z, stats
 
 
-def embed_bwd(ids, seg, dy, z, stats, gamma, dword, dpos, dtyp, dgamma, dbeta, p, rng, sid):
+def embed_bwd(ids, seg, dy, z, stats, gamma, dword, dpos, dtyp, dgamma, dbeta, p, rng, sid, row_list=None):
+    """``row_list`` = (ids int64 [cap], sq fp32 [cap], n int32 [1]), cap >= M: the kernel also lists the word-table rows it
+    touched, |row|^2 of the gradient per owner and the count (xggm_embed_bwd_listed_*)"""
     B, T = ids.shape
     M, H = dy.shape
     _c(dy), _c(z, dy.dtype)
@@ -842,9 +844,17 @@ def embed_bwd(ids, seg, dy, z, stats, gamma, dword, dpos, dtyp, dgamma, dbeta, p
         _c(t, F32, "embedding grad")
     dz = torch.empty_like(dy)
     ws, nb = _ws(_lib.lib.xggm_ln_bwd_workspace_bytes(M, H), dy.device)
-    call("xggm_embed_bwd_" + sfx(dy.dtype), ptr(ids), ptr(seg), ptr(dy), ptr(z), ptr(stats), ptr(gamma),
+    if row_list is None:
+        call("xggm_embed_bwd_" + sfx(dy.dtype), ptr(ids), ptr(seg), ptr(dy), ptr(z), ptr(stats), ptr(gamma),
+             ptr(dz), ptr(dword), ptr(dpos), ptr(dtyp), ptr(dgamma), ptr(dbeta), M, T, H, float(p), ptr(rng), sid,
+             ptr(ws), nb, stream())
+        return
+    rid, rsq, rn = row_list
+    _c(rid, torch.int64), _c(rsq, F32), _c(rn, torch.int32)
+    assert rid.numel() >= M and rsq.numel() >= M
+    call("xggm_embed_bwd_listed_" + sfx(dy.dtype), ptr(ids), ptr(seg), ptr(dy), ptr(z), ptr(stats), ptr(gamma),
          ptr(dz), ptr(dword), ptr(dpos), ptr(dtyp), ptr(dgamma), ptr(dbeta), M, T, H, float(p), ptr(rng), sid,
-         ptr(ws), nb, stream())
+         ptr(ws), nb, ptr(rid), ptr(rsq), ptr(rn), stream())
 
 
 def visn_embed_fwd(u, bf, boxes, Wb, bb, g1, b1, g2, b2, eps, p, rng, sid, emit8=None):
@@ -1072,15 +1082,24 @@ def bce_bwd(logit, target, gout, coef, dt):
 
 
 # ----------------------------------------------------------------------------- optimiser / utils
-def zero_ranges(buf, ranges):
-    """zero buf[s:e] for up to 16 (s, e) element ranges per launch (all float4-aligned)."""
+def zero_ranges(buf, ranges, rows=None):
+    """zero buf[s:e] for up to 16 (s, e) element ranges per launch (all float4-aligned).  ``rows`` = (table [R, H] fp32,
+    ids int64 [cap], n int32 [1]): the first launch also zeroes rows ids[:n] of the table (device-side list, as
+    ``embed_bwd(..., row_list=...)`` left it)."""
     _c(buf, F32)
     rs = [(s, e) for s, e in ranges if e > s]
-    for i in range(0, len(rs), 16):
+    for i in range(0, max(len(rs), 1 if rows is not None else 0), 16):
         chunk = rs[i:i + 16]
-        offs = (_ct.c_int64 * len(chunk))(*[s for s, _ in chunk])
-        lens = (_ct.c_int64 * len(chunk))(*[e - s for s, e in chunk])
-        call("xggm_zero_ranges_f32", ptr(buf), _ct.cast(offs, _ct.c_void_p), _ct.cast(lens, _ct.c_void_p), len(chunk), stream())
+        offs = (_ct.c_int64 * max(len(chunk), 1))(*[s for s, _ in chunk])
+        lens = (_ct.c_int64 * max(len(chunk), 1))(*[e - s for s, e in chunk])
+        if rows is not None and i == 0:
+            table, ids, n = rows
+            _c(table, F32), _c(ids, torch.int64), _c(n, torch.int32)
+            assert table.dim() == 2
+            call("xggm_zero_ranges_rows_f32", ptr(buf), _ct.cast(offs, _ct.c_void_p), _ct.cast(lens, _ct.c_void_p), len(chunk),
+                 ptr(table), ptr(ids), ptr(n), ids.numel(), table.shape[0], table.shape[1], stream())
+        else:
+            call("xggm_zero_ranges_f32", ptr(buf), _ct.cast(offs, _ct.c_void_p), _ct.cast(lens, _ct.c_void_p), len(chunk), stream())
 
 
 _SQNORM_WS = {}

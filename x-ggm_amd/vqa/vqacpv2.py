@@ -101,6 +101,7 @@ def enable_data_parallel(model, group=None, wire_dtype=None, overlap=None, zero1
             gs.set_sparse_table(xg[1], wt.shape[0], wt.shape[1], lambda: rt.emb_ids)
     object.__setattr__(model, "_grad_sync", gs)
     rt.arena.sq_enabled = False  # the clip norm is that of the AVERAGED gradients: read them after the exchange
+    rt.arena.row_list_enabled = False  # ... and the word table's gradient holds the OTHER ranks' rows too
     if overlap is None:
         overlap = os.environ.get("XGGM_DP_OVERLAP", "1") != "0"
     rt.cut_enabled = bool(overlap)
