@@ -360,6 +360,30 @@ int xggm_embed_fwd_bf16(const int64_t* ids, const int64_t* seg, const void* word
                         const float* gamma, const float* beta, void* out, void* z_out, float* stats, int M, int Tlen, int H,
                         float eps, float p, const uint64_t* rng, uint32_t sid, void* out8, const float* qscale, float* amax,
                         int amax_slots, xggm_stream_t stream);
+/* xggm_embed_fwd_* with up to XGGM_SIDE_MAX pieces of a pass's input glue done by workgroups appended to its grid instead
+ * of launches of their own: XGGM_SIDE_ADDITIVE_MASK dst[i] (fp32) = (1 - src[i] (int64)) * -10000 (xggm_additive_mask,
+ * src/lxrt/modeling.py:919-928); XGGM_SIDE_CAST_BF16 dst[i] (bf16) = src[i] (fp32) (xggm_cast_f32_to_bf16: the visual
+ * features / boxes, src/lxrt/modeling.py:546-550).  The embedding kernel itself reads none of the outputs. */
+#define XGGM_SIDE_MAX 3
+#define XGGM_SIDE_ADDITIVE_MASK 1
+#define XGGM_SIDE_CAST_BF16 2
+typedef struct xggm_side_jobs {
+    int n;
+    struct {
+        int kind;
+        const void* src;
+        void* dst;
+        int64_t count;
+    } job[XGGM_SIDE_MAX];
+} xggm_side_jobs;
+int xggm_embed_fwd_side_f32(const int64_t* ids, const int64_t* seg, const void* word, const void* pos, const void* type,
+                            const float* gamma, const float* beta, void* out, void* z_out, float* stats, int M, int Tlen, int H,
+                            float eps, float p, const uint64_t* rng, uint32_t sid, void* out8, const float* qscale, float* amax,
+                            int amax_slots, const xggm_side_jobs* side, xggm_stream_t stream);
+int xggm_embed_fwd_side_bf16(const int64_t* ids, const int64_t* seg, const void* word, const void* pos, const void* type,
+                             const float* gamma, const float* beta, void* out, void* z_out, float* stats, int M, int Tlen, int H,
+                             float eps, float p, const uint64_t* rng, uint32_t sid, void* out8, const float* qscale, float* amax,
+                             int amax_slots, const xggm_side_jobs* side, xggm_stream_t stream);
 int xggm_embed_bwd_f32(const int64_t* ids, const int64_t* seg, const void* dy, const void* z, const float* stats,
                        const float* gamma, void* dz_ws, float* dword, float* dpos, float* dtype, float* dgamma,
                        float* dbeta, int M, int Tlen, int H, float p, const uint64_t* rng, uint32_t sid, float* ws,
@@ -407,6 +431,13 @@ int xggm_aggregate_f32(const float* M, const void* x, void* out, int B, int N, i
                        const float* scale_ptr, float self_w, int accumulate, xggm_stream_t stream);
 int xggm_aggregate_bf16(const float* M, const void* x, void* out, int B, int N, int H, int mode, float scale,
                         const float* scale_ptr, float self_w, int accumulate, xggm_stream_t stream);
+/* GCNConv's tail in one launch (bf16 storage): out = LayerNorm(res + M @ y; gamma, beta, eps) per sample, y = x W^T
+ * taken first by a plain product -- LN(x + W (A x)) = LN(x + A (x W^T)), src/module/gcn.py:22-29.  y, res, out, z_out:
+ * bf16 [B, N, H], H in {64, 128, 256, 768}; z_out (or NULL) = the rounded pre-normalisation rows and stats (or NULL) =
+ * [B*N][2] (mean, rstd), both as xggm_ln_fwd_* leaves them for xggm_ln_bwd_*.  res may be y's own input x; out / z_out
+ * may not alias y. */
+int xggm_agg_residual_ln_bf16(const float* M, const void* y, const void* res, const float* gamma, const float* beta, void* out,
+                              void* z_out, float* stats, int B, int N, int H, float eps, xggm_stream_t stream);
 /* *out += sum_{b,i,c} dh[b,i,c] * (M @ x)[b,i,c]   (gradient of GIN's eps); ws: see XGGM_SUM_WS_FLOATS */
 int xggm_agg_dot_f32(const float* M, const void* x, const void* dh, float* out, int B, int N, int H, float* ws,
                      xggm_stream_t stream);
@@ -589,6 +620,11 @@ typedef struct {
 int xggm_clip_norm_f32(const float* g, const int64_t* offsets, const int64_t* lengths, int n, const float* slots,
                        const int64_t* slot_offsets, const int64_t* slot_lengths, int n_slots, float* out, float* norm, float* ws,
                        float mul, const xggm_pass_tail* tail, xggm_stream_t stream);
+/* the same pair of launches over up to 24 ranges of a BF16 buffer (the data-parallel wire arena, offsets multiples of 8):
+ * *out = ((accumulate ? *out : 0) + sum g^2) * mul -- accumulate = 1 extends a sum another call (or an all-reduce over the
+ * ranks, sharded update) has left in *out; mul = 1 / world^2 turns the norm of SUMMED gradients into that of their mean. */
+int xggm_clip_norm_bf16(const void* g, const int64_t* offsets, const int64_t* lengths, int n, float* out, float* norm, float* ws,
+                        int accumulate, float mul, const xggm_pass_tail* tail, xggm_stream_t stream);
 
 /* out = in with the diagonal of every [N, N] matrix zeroed: adj_true.triu(1) + adj_true.tril(-1), src/vqa/vqacpv2.py:188 */
 int xggm_zero_diag_f32(const float* in, float* out, int B, int N, xggm_stream_t stream);

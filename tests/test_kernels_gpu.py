@@ -339,6 +339,40 @@ def test_sum_of_layernorms_in_one_launch(ops, dt, M, H, n):
         ops.call("xggm_ln_sum_fwd_" + ops.sfx(dt), ops._ct.byref(a), ops.stream())
 
 
+@pytest.mark.parametrize("B,N,H", [(32, 36, 768), (64, 64, 768), (5, 36, 128), (3, 17, 64), (9, 64, 256), (2, 1, 64)])
+def test_gcnconv_tail_in_one_launch(ops, B, N, H):
+    """xggm_agg_residual_ln_bf16: LayerNorm(res + M y) per sample -- GCNConv's tail (src/module/gcn.py:22-29) once the
+    product y = x W^T has been taken -- against float64 on the same bf16 inputs, the saved rows / statistics against what
+    ln_fwd saves for the same sum, and LayerNorm's own backward running on them."""
+    gen = torch.Generator().manual_seed(B * 100 + N)
+    M = torch.rand(B, N, N, generator=gen).to(DEV)
+    y, yr = rnd((B, N, H), torch.bfloat16, 1)
+    res, rr = rnd((B, N, H), torch.bfloat16, 2)
+    gamma = (1 + 0.1 * torch.randn(H, generator=gen)).to(DEV)
+    beta = (0.1 * torch.randn(H, generator=gen)).to(DEV)
+    out, z, stats = ops.agg_residual_ln(M, y, res, gamma, beta, 1e-5)
+    zr = rr + M.double().cpu() @ yr
+    assert rel_err(z, zr) < 5e-3
+    ref = torch.nn.functional.layer_norm(zr, (H,), gamma.double().cpu(), beta.double().cpu(), 1e-5)
+    assert rel_err(out, ref) < 1.2e-2
+    # the statistics are those of the ROUNDED rows (what the backward recomputes from), as ln_fwd's
+    zs = z.double().cpu().view(B * N, H)
+    mean = zs.mean(1)
+    rstd = 1.0 / torch.sqrt(zs.var(1, unbiased=False) + 1e-5)
+    assert float((stats[:, 0].double().cpu() - mean).abs().max()) < 1e-5 * (1 + float(mean.abs().max()))
+    assert float((stats[:, 1].double().cpu() / rstd - 1).abs().max()) < 1e-5
+    o2, z2, st2 = ops.ln_fwd(z.view(B * N, H).clone(), None, None, gamma, beta, 1e-5)
+    assert torch.equal(z2, z.view(B * N, H)) and float((st2 - stats).abs().max()) < 1e-5 * (1 + float(st2.abs().max()))
+    assert float((o2.float() - out.view(B * N, H).float()).abs().max()) <= 2 ** -6 * float(o2.float().abs().max())
+    dy = rnd((B * N, H), torch.bfloat16, 3)[0]
+    d1, _ = ops.ln_bwd(dy, z.view(B * N, H), stats, gamma, None, None, None)
+    d2, _ = ops.ln_bwd(dy, z2, st2, gamma, None, None, None)
+    assert rel_err(d1, d2.double().cpu()) < 1e-2
+    with pytest.raises(RuntimeError, match="may not alias"):
+        ops.call("xggm_agg_residual_ln_bf16", M.data_ptr(), y.data_ptr(), res.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                 y.data_ptr(), None, None, B, N, H, 1e-5, ops.stream())
+
+
 @pytest.mark.parametrize("dt", DTS)
 def test_grouped_row_requests_equal_separate_launches(ops, dt):
     """the language (640 rows, 20 tokens) and vision (1152 rows, 36 objects) LayerNorms / attention cores
@@ -453,6 +487,20 @@ def test_embeddings(ops, dt):
                                   dev["e.position_embeddings.weight"], dev["e.token_type_embeddings.weight"],
                                   dev["e.LayerNorm.weight"], dev["e.LayerNorm.bias"], 1e-12, 0.0, None, 0)
     assert rel_err(out.view(B, T, H), ref) < tol(dt)
+    # the pass's input glue riding on this launch (xggm_embed_fwd_side_*): additive mask (src/lxrt/modeling.py:919-928) and
+    # fp32 -> bf16 casts by appended workgroups; the embedding's own results are untouched
+    mask = (ids != 0).long().to(DEV)
+    feats = torch.randn(B * 36 * 200 + 3, generator=gen).to(DEV)
+    boxes = torch.rand(B * 36 * 4, generator=gen).to(DEV)
+    m_out = torch.empty(mask.shape, device=DEV)
+    f_out, b_out = (torch.empty(t.shape, device=DEV, dtype=torch.bfloat16) for t in (feats, boxes))
+    o2, z2, s2 = ops.embed_fwd(ids.to(DEV), seg.to(DEV), dev["e.word_embeddings.weight"], dev["e.position_embeddings.weight"],
+                               dev["e.token_type_embeddings.weight"], dev["e.LayerNorm.weight"], dev["e.LayerNorm.bias"], 1e-12,
+                               0.0, None, 0, side=[(ops.SIDE_ADDITIVE_MASK, mask, m_out), (ops.SIDE_CAST_BF16, feats, f_out),
+                                                   (ops.SIDE_CAST_BF16, boxes, b_out)])
+    assert torch.equal(o2, out) and torch.equal(z2, z) and torch.equal(s2, stats)
+    assert torch.equal(m_out, ops.additive_mask(mask)) and torch.equal(m_out, (1.0 - mask.float()) * -10000.0)
+    assert torch.equal(f_out, feats.to(torch.bfloat16)) and torch.equal(b_out, boxes.to(torch.bfloat16))
     dy, dyr = rnd((B * T, H), dt, 2)
     (ref * dyr.view(B, T, H)).sum().backward()
     g = {k: torch.zeros(v.shape, device=DEV) for k, v in P.items()}
@@ -932,6 +980,32 @@ def test_clip_norm_pair_with_the_pass_tail(ops):
     assert float(o3) == 0.0
     with pytest.raises(RuntimeError, match="listed twice"):
         ops.clip_norm(g, spans[:1], None, [], o3, sched=(steps, scale, [(1, 20, 0.1), (1, 20, 0.1)]))
+
+
+def test_clip_norm_over_the_bf16_wire(ops):
+    """xggm_clip_norm_bf16: the data-parallel norm pass (sum of squares of the bf16 wire arena's active ranges, times
+    1 / world^2) in one pair of launches, against float64; ``accumulate`` extends a sum another call (or an all-reduce)
+    left in *out -- the sharded update's two halves give what one call over all ranges gives, to rounding."""
+    gen = torch.Generator(device="cpu").manual_seed(6)
+    g = (torch.randn(2_000_003, generator=gen) * 0.1).to(torch.bfloat16).to(DEV)
+    spans = [(0, 700_000), (700_008, 700_008 + 13), (1_000_000, 2_000_003)]
+    want = sum(float((g[a:b].double() ** 2).sum()) for a, b in spans)
+    out, norm = torch.full((1,), 9.0, device=DEV), torch.zeros(1, device=DEV)
+    ops.clip_norm_bf16(g, spans, out, norm, mul=0.25)
+    assert abs(float(out) - 0.25 * want) < 2e-6 * want and abs(float(norm) - (0.25 * want) ** 0.5) < 2e-6 * want ** 0.5
+    o2 = torch.zeros(1, device=DEV)
+    ops.clip_norm_bf16(g, spans[:2], o2)                                    # first half seeds
+    steps = torch.tensor([4], dtype=torch.int64, device=DEV)
+    scale = torch.zeros(1, device=DEV)
+    ops.clip_norm_bf16(g, spans[2:], o2, norm, accumulate=True, mul=0.25, sched=(steps, scale, [(0, -1, 0.1)]))
+    assert abs(float(o2) - float(out)) < 2e-6 * want and steps.tolist() == [5] and float(scale) == 1.0
+    first = float(out)
+    for _ in range(2):
+        o3 = torch.zeros(1, device=DEV)
+        ops.clip_norm_bf16(g, spans, o3, None, mul=0.25)
+        assert float(o3) == first
+    with pytest.raises(RuntimeError, match="multiple of 8"):
+        ops.clip_norm_bf16(g, [(4, 100)], o2)
 
 
 # ------------------------------------------------------------------------------------------------ fp8 forward (C5)

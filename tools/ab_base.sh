@@ -11,7 +11,7 @@ for i in $(seq $N); do
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):
-        d=json.loads(l); print('$v', d['ms_per_step'], d['ms_per_pass'], (d.get('value_with_loader') or {}).get('ms_per_step'))
+        d=json.loads(l); print('$v', d['ms_per_step'], d.get('ms_per_pass'), (d.get('value_with_loader') or {}).get('ms_per_step'))
 "
   done
 done

@@ -216,6 +216,150 @@ __global__ __launch_bounds__(NT) void aggregate_bf16_kernel(const float* __restr
     }
 }
 
+// ---- GCNConv's tail in one launch: out = LayerNorm(res + M y) ------------------------------------------------------
+// GCNConv (src/module/gcn.py:22-29) is LN(x + W (A x)) = LN(x + A (x W^T)): with the product y = x W^T taken FIRST (a
+// plain GEMM over all B * N rows), what is left per sample is M y + x and a LayerNorm over whole rows -- one kernel
+// instead of aggregate, product epilogue and LayerNorm (three launches, two round trips of a [B, N, H] tensor).
+// One workgroup = one sample x 16 output rows x ALL H columns, so the row statistics never leave the workgroup:
+//   y slab [N, H] bf16 -> LDS [k = j][c] (row stride H + 8), read transposed as the A operand y^T exactly as in
+//   aggregate_bf16_kernel; the 16 adjacency rows split into hi + lo bf16 (16 mantissa bits) as the B operand;
+//   wave w owns the column groups 16 (w CG .. w CG + CG - 1), CG = H / 64: a lane ends with row fr, four consecutive
+//   columns of each of its CG groups; + res, rounded to the storage type (the saved z, as ln_fwd_kernel does), mean and
+//   centred variance by two shuffles across the lanes of a row and a fixed-order sum over the four waves through LDS.
+// The row tiles of a sample run on ONE XCD (its y slab is fetched into one L2), as the column blocks of the aggregate.
+template <int CG>
+__global__ __launch_bounds__(NT) void agg_res_ln_kernel(const float* __restrict__ Mx, const bf16* __restrict__ y,
+                                                        const bf16* __restrict__ res, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, bf16* out, bf16* z_out, float* stats,
+                                                        int B, int N, float eps) {
+    constexpr int H = CG * 64, NK = 64, LDY = H + 8, LDM = 72;
+    extern __shared__ __attribute__((aligned(16))) unsigned char agg_lds[];
+    bf16* ys = reinterpret_cast<bf16*>(agg_lds);                    // [NK][LDY]
+    bf16* Mh = ys + NK * LDY;                                       // [16][LDM]
+    bf16* Ml = Mh + 16 * LDM;                                       // [16][LDM]
+    float* red = reinterpret_cast<float*>(Ml + 16 * LDM);           // [4][16]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int ntile = (N + 15) >> 4;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int b = (q / ntile) * 8 + xcd, i0 = (q % ntile) * 16;
+    if (b >= B) return;  // whole workgroup (padding of a batch that is not a multiple of 8)
+    const int fr = lane & 15, fq = lane >> 4;
+    const int row = i0 + fr;
+    const bool row_ok = row < N;
+    // the residual rows go straight to registers: issued first, used last
+    agg_short4 rres[CG];
+    const bf16* rb = res + ((int64_t)b * N + (row_ok ? row : 0)) * H + wid * CG * 16 + 4 * fq;
+#pragma unroll
+    for (int g = 0; g < CG; ++g) rres[g] = *reinterpret_cast<const agg_short4*>(rb + g * 16);
+    // the 16 adjacency rows of this tile -> hi / lo bf16, k beyond N zero
+    const float* Mb = Mx + (int64_t)b * N * N;
+    for (int e = tid; e < 16 * NK / 4; e += NT) {
+        const int i = (4 * e) / NK, j0 = (4 * e) % NK;
+        agg_short4 h4, l4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u;
+            const float v = (i0 + i < N && j < N) ? Mb[(int64_t)(i0 + i) * N + j] : 0.f;
+            const bf16 hi = __float2bfloat16(v);
+            h4[u] = __builtin_bit_cast(short, hi);
+            l4[u] = __builtin_bit_cast(short, __float2bfloat16(v - __bfloat162float(hi)));
+        }
+        *reinterpret_cast<agg_short4*>(Mh + i * LDM + j0) = h4;
+        *reinterpret_cast<agg_short4*>(Ml + i * LDM + j0) = l4;
+    }
+    // y slab of the sample: 16-byte chunks, rows beyond N zero (they meet zero adjacency entries, but not as NaNs).
+    // ALL loads of a thread are issued before the first LDS store (rows beyond N read row N - 1 and are zeroed on the
+    // way): the first form, a load -> store loop behind a row test, waited for every load on its own -- 24 serial round
+    // trips per thread, 17.8 us per launch at B = 64, N = 64 where aggregate + LayerNorm together had taken 17.5.
+    const bf16* yb = y + (int64_t)b * N * H;
+    constexpr int CH = H / 8, ITER = NK * CH / NT;
+    static_assert(NK * CH % NT == 0, "the slab's chunks divide over the workgroup");
+    {
+        agg_short8 v[ITER];
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int e = tid + it * NT, j = e / CH, c = (e % CH) * 8;
+            v[it] = *reinterpret_cast<const agg_short8*>(yb + (int64_t)min(j, N - 1) * H + c);
+        }
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int e = tid + it * NT, j = e / CH, c = (e % CH) * 8;
+            const agg_short8 zero = {};
+            *reinterpret_cast<agg_short8*>(ys + j * LDY + c) = j < N ? v[it] : zero;
+        }
+    }
+    __syncthreads();
+    float4_t acc[CG];
+#pragma unroll
+    for (int g = 0; g < CG; ++g) acc[g] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    const int qq = fr >> 2, pp = fr & 3;
+#pragma unroll
+    for (int ks = 0; ks < NK; ks += 32) {
+        const agg_bf16x8 bh = __builtin_bit_cast(agg_bf16x8, *reinterpret_cast<const agg_short8*>(Mh + fr * LDM + ks + fq * 8));
+        const agg_bf16x8 bl = __builtin_bit_cast(agg_bf16x8, *reinterpret_cast<const agg_short8*>(Ml + fr * LDM + ks + fq * 8));
+#pragma unroll
+        for (int g = 0; g < CG; ++g) {
+            const bf16* a0 = ys + (ks + 8 * fq + qq) * LDY + (wid * CG + g) * 16 + 4 * pp;
+            const agg_short4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) agg_short4*)(a0));
+            const agg_short4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) agg_short4*)(a0 + 4 * LDY));
+            agg_short8 av;
+            av[0] = lo4[0]; av[1] = lo4[1]; av[2] = lo4[2]; av[3] = lo4[3];
+            av[4] = hi4[0]; av[5] = hi4[1]; av[6] = hi4[2]; av[7] = hi4[3];
+            const agg_bf16x8 a = __builtin_bit_cast(agg_bf16x8, av);
+            acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bh, acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bl, acc[g], 0, 0, 0);
+        }
+    }
+    // z = res + M y, rounded to the storage type; lane: row fr, columns (wid CG + g) 16 + 4 fq + r
+    float sum = 0.f;
+#pragma unroll
+    for (int g = 0; g < CG; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = acc[g][r] + __bfloat162float(__builtin_bit_cast(bf16, (short)rres[g][r]));
+            acc[g][r] = __bfloat162float(__float2bfloat16(v));
+            sum += acc[g][r];
+        }
+    auto row_total = [&](float v) {  // over the four lanes of the row, then the four waves in index order
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        __syncthreads();  // (the previous round's reads of red are done)
+        if (fq == 0) red[wid * 16 + fr] = v;
+        __syncthreads();
+        return ((red[fr] + red[16 + fr]) + red[32 + fr]) + red[48 + fr];
+    };
+    const float mean = row_total(sum) / (float)H;
+    float var = 0.f;
+#pragma unroll
+    for (int g = 0; g < CG; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float t = acc[g][r] - mean;
+            var += t * t;
+        }
+    const float rstd = rsqrtf(row_total(var) / (float)H + eps);
+    if (!row_ok) return;
+    if (stats && wid == 0 && fq == 0) {
+        stats[2 * ((int64_t)b * N + row)] = mean;
+        stats[2 * ((int64_t)b * N + row) + 1] = rstd;
+    }
+    const int64_t ob = ((int64_t)b * N + row) * H + wid * CG * 16 + 4 * fq;
+#pragma unroll
+    for (int g = 0; g < CG; ++g) {
+        const int c = wid * CG * 16 + g * 16 + 4 * fq;
+        float g4[4], be4[4], o[4], zz[4];
+        load4(gamma + c, g4);
+        load4(beta + c, be4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            zz[r] = acc[g][r];
+            o[r] = (acc[g][r] - mean) * rstd * g4[r] + be4[r];
+        }
+        if (z_out) store4(z_out + ob + g * 16, zz);
+        store4(out + ob + g * 16, o);
+    }
+}
+
 // d eps of GIN: sum_{b,i,c} dh[b,i,c] * (A @ x)[b,i,c]  -> one scalar
 template <typename T, int NP>
 __global__ __launch_bounds__(NT) void agg_dot_kernel(const float* __restrict__ Mx, const T* __restrict__ x,
@@ -457,6 +601,21 @@ int aggregate(const float* M, const void* x, void* out, int B, int N, int H, int
     return xggm_check_launch("xggm_aggregate");
 }
 
+template <int CG>
+int launch_agg_res_ln(const float* M, const bf16* y, const bf16* res, const float* gamma, const float* beta, bf16* out, bf16* z_out,
+                      float* stats, int B, int N, float eps, hipStream_t st) {
+    constexpr int H = CG * 64;
+    const size_t lds = sizeof(bf16) * (64 * (H + 8) + 2 * 16 * 72) + sizeof(float) * 64;
+    static bool once = [] {  // more than the default 64 KB of dynamic LDS: opt in once per instantiation
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(agg_res_ln_kernel<CG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(sizeof(bf16) * (64 * (H + 8) + 2 * 16 * 72) + sizeof(float) * 64)) == hipSuccess;
+    }();
+    XGGM_REQUIRE(once, "xggm_agg_residual_ln_bf16: cannot reserve %zu bytes of LDS", lds);
+    const int grid = ceil_div(B, 8) * 8 * ceil_div(N, 16);
+    hipLaunchKernelGGL((agg_res_ln_kernel<CG>), dim3(grid), dim3(NT), lds, st, M, y, res, gamma, beta, out, z_out, stats, B, N, eps);
+    return xggm_check_launch("xggm_agg_residual_ln_bf16");
+}
+
 template <typename T>
 int agg_dot(const float* M, const void* x, const void* dh, float* out, int B, int N, int H, float* ws, hipStream_t st) {
     XGGM_REQUIRE(M && x && dh && out && ws && B > 0 && N > 0 && N <= 64 && H > 0 && B <= 65535, "xggm_agg_dot: bad arguments");
@@ -471,6 +630,24 @@ int agg_dot(const float* M, const void* x, const void* dh, float* out, int B, in
 }
 
 }  // namespace
+
+extern "C" int xggm_agg_residual_ln_bf16(const float* M, const void* y, const void* res, const float* gamma, const float* beta,
+                                        void* out, void* z_out, float* stats, int B, int N, int H, float eps, hipStream_t st) {
+    XGGM_REQUIRE(M && y && res && gamma && beta && out && B > 0 && N > 0, "xggm_agg_residual_ln_bf16: bad arguments");
+    XGGM_REQUIRE(N <= 64, "xggm_agg_residual_ln_bf16: N=%d exceeds the 64-row adjacency tile", N);
+    XGGM_REQUIRE(H == 768 || H == 256 || H == 128 || H == 64, "xggm_agg_residual_ln_bf16: H=%d (built for 64, 128, 256, 768)", H);
+    XGGM_REQUIRE((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(out) |
+                  reinterpret_cast<uintptr_t>(z_out) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) % 16 == 0,
+                 "xggm_agg_residual_ln_bf16: pointers must be 16-byte aligned");
+    XGGM_REQUIRE(out != y && out != res && z_out != y && (z_out == nullptr || z_out != out),
+                 "xggm_agg_residual_ln_bf16: out / z_out may not alias y (read by every row tile of the sample), each other or res");
+    const bf16 *yy = (const bf16*)y, *rr = (const bf16*)res;
+    bf16 *oo = (bf16*)out, *zz = (bf16*)z_out;
+    if (H == 768) return launch_agg_res_ln<12>(M, yy, rr, gamma, beta, oo, zz, stats, B, N, eps, st);
+    if (H == 256) return launch_agg_res_ln<4>(M, yy, rr, gamma, beta, oo, zz, stats, B, N, eps, st);
+    if (H == 128) return launch_agg_res_ln<2>(M, yy, rr, gamma, beta, oo, zz, stats, B, N, eps, st);
+    return launch_agg_res_ln<1>(M, yy, rr, gamma, beta, oo, zz, stats, B, N, eps, st);
+}
 
 extern "C" int xggm_adj_regen_fwd(const float* S, float* adj, float* colmax, int32_t* argmax, int B, int N, hipStream_t st) {
     XGGM_REQUIRE(S && adj && colmax && argmax && B > 0 && N > 0, "xggm_adj_regen_fwd: bad arguments");

@@ -259,6 +259,49 @@ __global__ __launch_bounds__(NT) void clip_norm_kernel(NormSpans sp, float* ws) 
     const float acc = k < sp.n_sq ? span_partial<true>(sp.ptr[k], sp.len[k], b, nb) : span_partial<false>(sp.ptr[k], sp.len[k], b, nb);
     if (threadIdx.x == 0) ws[blockIdx.x] = acc;
 }
+// the same grid over ranges of a bf16 buffer (the data-parallel wire arena): 8 elements per 16-byte load, four in flight
+__device__ __forceinline__ float span_partial_bf16(const bf16* __restrict__ g, int64_t n, int b, int nb) {
+    typedef short __attribute__((ext_vector_type(8))) s8;
+    const s8* g8 = reinterpret_cast<const s8*>(g);
+    const int64_t n8 = n >> 3, stride = (int64_t)nb * NT;
+    float acc = 0.f;
+    auto sq8 = [](const s8 v) {
+        float t = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float f = __bfloat162float(__builtin_bit_cast(bf16, (short)v[e]));
+            t += f * f;
+        }
+        return t;
+    };
+    int64_t i = (int64_t)b * NT + threadIdx.x;
+    for (; i + 3 * stride < n8; i += 4 * stride) {
+        const s8 a = __builtin_nontemporal_load(g8 + i), bb = __builtin_nontemporal_load(g8 + i + stride),
+                 c = __builtin_nontemporal_load(g8 + i + 2 * stride), d = __builtin_nontemporal_load(g8 + i + 3 * stride);
+        acc += (sq8(a) + sq8(bb)) + (sq8(c) + sq8(d));
+    }
+    for (; i < n8; i += stride) acc += sq8(g8[i]);
+    if (b == 0 && threadIdx.x < (n & 7)) {
+        const float f = __bfloat162float(g[(n8 << 3) + threadIdx.x]);
+        acc += f * f;
+    }
+    return block_sum(acc);
+}
+struct NormSpans16 {
+    const bf16* ptr[MAX_NORM_SPANS];
+    int64_t len[MAX_NORM_SPANS];
+    int blk0[MAX_NORM_SPANS + 1];
+    int n;
+};
+__global__ __launch_bounds__(NT) void clip_norm_bf16_kernel(NormSpans16 sp, float* ws) {
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < MAX_NORM_SPANS; ++j)
+        if (j < sp.n && (int)blockIdx.x >= sp.blk0[j]) k = j;
+    const float acc = span_partial_bf16(sp.ptr[k], sp.len[k], blockIdx.x - sp.blk0[k], sp.blk0[k + 1] - sp.blk0[k]);
+    if (threadIdx.x == 0) ws[blockIdx.x] = acc;
+}
+
 __global__ __launch_bounds__(NT) void sqnorm_multi_finish_kernel(const float* __restrict__ ws, int nblk, float* out, float* norm,
                                                                  int overwrite, float mul) {
     float t = 0.f;
@@ -799,12 +842,12 @@ extern "C" int xggm_sched_step_multi(int64_t* steps, float* lr_scale, const int*
 namespace {
 __global__ __launch_bounds__(NT) void clip_norm_finish_kernel(const float* __restrict__ ws, int nblk, float* out, float* norm, float mul,
                                                               int64_t* steps, float* lr_scale, SchedArgs sa, uint64_t* rng,
-                                                              uint64_t rng_by) {
+                                                              uint64_t rng_by, int accumulate) {
     float t = 0.f;
     for (int b = threadIdx.x; b < nblk; b += NT) t += ws[b];
     t = block_sum(t);
     if (threadIdx.x == 0) {
-        const float s = t * mul;
+        const float s = ((accumulate ? *out : 0.f) + t) * mul;
         *out = s;
         if (norm) *norm = sqrtf(s);
         if (rng) rng[1] += rng_by;
@@ -821,6 +864,37 @@ __global__ __launch_bounds__(NT) void clip_norm_finish_kernel(const float* __res
         lr_scale[k] = sc;
         steps[k] = s + 1;
     }
+}
+}  // namespace
+
+namespace {
+struct TailArgs {
+    SchedArgs sa;
+    int64_t* steps = nullptr;
+    float* lr_scale = nullptr;
+    uint64_t* rng = nullptr;
+    uint64_t rng_by = 0;
+};
+int tail_args_of(const xggm_pass_tail* tail, TailArgs& ta) {
+    ta.sa.n = 0;
+    if (!tail) return XGGM_OK;
+    XGGM_REQUIRE(tail->n >= 0 && tail->n <= MAX_SCHED && (tail->n == 0 || (tail->steps && tail->lr_scale && tail->index &&
+                                                                         tail->t_total && tail->warmup)),
+                 "xggm_clip_norm: bad schedule entries (n = %d, at most %d)", tail->n, MAX_SCHED);
+    ta.sa.n = tail->n;
+    for (int i = 0; i < tail->n; ++i) {
+        XGGM_REQUIRE(tail->index[i] >= 0, "xggm_clip_norm: negative schedule index");
+        for (int j = 0; j < i; ++j)
+            XGGM_REQUIRE(tail->index[j] != tail->index[i], "xggm_clip_norm: counter %d listed twice", tail->index[i]);
+        ta.sa.index[i] = tail->index[i];
+        ta.sa.t_total[i] = tail->t_total[i];
+        ta.sa.warmup[i] = tail->warmup[i];
+    }
+    ta.steps = tail->steps;
+    ta.lr_scale = tail->lr_scale;
+    ta.rng = tail->rng;
+    ta.rng_by = tail->rng_by;
+    return XGGM_OK;
 }
 }  // namespace
 
@@ -851,33 +925,41 @@ extern "C" int xggm_clip_norm_f32(const float* g, const int64_t* offsets, const 
     }
     sp.blk0[sp.n] = nblk;
     XGGM_REQUIRE(nblk <= 4100, "xggm_clip_norm_f32: internal: %d partials", nblk);
-    SchedArgs sa;
-    sa.n = 0;
-    int64_t* steps = nullptr;
-    float* lr_scale = nullptr;
-    uint64_t* rng = nullptr;
-    uint64_t rng_by = 0;
-    if (tail) {
-        XGGM_REQUIRE(tail->n >= 0 && tail->n <= MAX_SCHED && (tail->n == 0 || (tail->steps && tail->lr_scale && tail->index &&
-                                                                             tail->t_total && tail->warmup)),
-                     "xggm_clip_norm_f32: bad schedule entries (n = %d, at most %d)", tail->n, MAX_SCHED);
-        sa.n = tail->n;
-        for (int i = 0; i < sa.n; ++i) {
-            XGGM_REQUIRE(tail->index[i] >= 0, "xggm_clip_norm_f32: negative schedule index");
-            for (int j = 0; j < i; ++j)
-                XGGM_REQUIRE(tail->index[j] != tail->index[i], "xggm_clip_norm_f32: counter %d listed twice", tail->index[i]);
-            sa.index[i] = tail->index[i];
-            sa.t_total[i] = tail->t_total[i];
-            sa.warmup[i] = tail->warmup[i];
-        }
-        steps = tail->steps;
-        lr_scale = tail->lr_scale;
-        rng = tail->rng;
-        rng_by = tail->rng_by;
-    }
+    TailArgs ta;
+    if (int e = tail_args_of(tail, ta)) return e;
     if (nblk > 0) hipLaunchKernelGGL(clip_norm_kernel, dim3(nblk), dim3(NT), 0, st, sp, ws);
-    hipLaunchKernelGGL(clip_norm_finish_kernel, dim3(1), dim3(NT), 0, st, ws, nblk, out, norm, mul, steps, lr_scale, sa, rng, rng_by);
+    hipLaunchKernelGGL(clip_norm_finish_kernel, dim3(1), dim3(NT), 0, st, ws, nblk, out, norm, mul, ta.steps, ta.lr_scale, ta.sa, ta.rng, ta.rng_by, 0);
     return xggm_check_launch("xggm_clip_norm_f32");
+}
+
+extern "C" int xggm_clip_norm_bf16(const void* g, const int64_t* offsets, const int64_t* lengths, int n, float* out, float* norm,
+                                   float* ws, int accumulate, float mul, const xggm_pass_tail* tail, hipStream_t st) {
+    XGGM_REQUIRE(out && ws && n >= 0 && n <= MAX_NORM_SPANS && (n == 0 || (g && offsets && lengths)),
+                 "xggm_clip_norm_bf16: bad arguments (%d ranges, at most %d)", n, MAX_NORM_SPANS);
+    XGGM_REQUIRE(reinterpret_cast<uintptr_t>(g) % 16 == 0, "xggm_clip_norm_bf16: the buffer must be 16-byte aligned");
+    NormSpans16 sp;
+    sp.n = n;
+    int64_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        XGGM_REQUIRE(offsets[i] >= 0 && lengths[i] > 0 && offsets[i] % 8 == 0, "xggm_clip_norm_bf16: range %d (offset %lld, length "
+                     "%lld) must be non-empty and start on a multiple of 8", i, (long long)offsets[i], (long long)lengths[i]);
+        sp.ptr[i] = reinterpret_cast<const bf16*>(g) + offsets[i];
+        sp.len[i] = lengths[i];
+        total += lengths[i];
+    }
+    int nblk = 0;
+    for (int i = 0; i < n; ++i) {
+        sp.blk0[i] = nblk;
+        nblk += (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div64(sp.len[i], (int64_t)NT * 64), (4096 - n) * sp.len[i] / total + 1));
+    }
+    sp.blk0[n] = nblk;
+    XGGM_REQUIRE(nblk <= 4100, "xggm_clip_norm_bf16: internal: %d partials", nblk);
+    TailArgs ta;
+    if (int e = tail_args_of(tail, ta)) return e;
+    if (nblk > 0) hipLaunchKernelGGL(clip_norm_bf16_kernel, dim3(nblk), dim3(NT), 0, st, sp, ws);
+    hipLaunchKernelGGL(clip_norm_finish_kernel, dim3(1), dim3(NT), 0, st, ws, nblk, out, norm, mul, ta.steps, ta.lr_scale, ta.sa, ta.rng, ta.rng_by,
+                       accumulate);
+    return xggm_check_launch("xggm_clip_norm_bf16");
 }
 
 extern "C" int xggm_rng_advance(uint64_t* rng, uint64_t by, hipStream_t st) {

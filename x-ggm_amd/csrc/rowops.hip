@@ -679,12 +679,47 @@ template <int W> __device__ __forceinline__ void emit8_record(const Emit8& e8, c
     }
 }
 
+// Input glue of a pass riding on its first row kernel (xggm_embed_fwd_side_*): the additive attention mask
+// (src/lxrt/modeling.py:919-928) and the fp32 -> bf16 casts of the visual inputs were launches of their own in front
+// of the embeddings; here workgroups appended to the embedding kernel's grid do them.  Nothing in the embedding kernel
+// reads their outputs.
+struct SideJobs {
+    int n, main_blocks;
+    int kind[XGGM_SIDE_MAX];
+    const void* src[XGGM_SIDE_MAX];
+    void* dst[XGGM_SIDE_MAX];
+    long long count[XGGM_SIDE_MAX];
+    int blk0[XGGM_SIDE_MAX + 1];  // first appended workgroup of each job
+};
+__device__ __forceinline__ void side_role(const SideJobs& sj, int b) {
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < XGGM_SIDE_MAX; ++j)
+        if (j < sj.n && b >= sj.blk0[j]) k = j;
+    const int nb = sj.blk0[k + 1] - sj.blk0[k];
+    const long long n = sj.count[k], stride = (long long)nb * NT;
+    long long i = (long long)(b - sj.blk0[k]) * NT + threadIdx.x;
+    if (sj.kind[k] == XGGM_SIDE_ADDITIVE_MASK) {
+        const int64_t* m = reinterpret_cast<const int64_t*>(sj.src[k]);
+        float* o = reinterpret_cast<float*>(sj.dst[k]);
+        for (; i < n; i += stride) o[i] = (1.0f - (float)m[i]) * -10000.0f;
+    } else {  // XGGM_SIDE_CAST_BF16
+        const float* x = reinterpret_cast<const float*>(sj.src[k]);
+        bf16* o = reinterpret_cast<bf16*>(sj.dst[k]);
+        for (; i < n; i += stride) o[i] = __float2bfloat16(x[i]);
+    }
+}
+
 template <typename T, int NV>
 __global__ __launch_bounds__(NT) void embed_fwd_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ seg,
                                                        const T* __restrict__ word, const T* __restrict__ pos,
                                                        const T* __restrict__ type, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, T* out, T* z_out, float* stats, int M,
-                                                       int Tlen, int H, float eps, DropArgs d, Emit8 e8) {
+                                                       int Tlen, int H, float eps, DropArgs d, Emit8 e8, SideJobs sj) {
+    if ((int)blockIdx.x >= sj.main_blocks) {  // appended workgroups (whole workgroups: no barrier below is left waiting)
+        side_role(sj, (int)blockIdx.x - sj.main_blocks);
+        return;
+    }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     uint64_t seed, off;
     rng_load(d.rng, seed, off);
@@ -692,7 +727,7 @@ __global__ __launch_bounds__(NT) void embed_fwd_kernel(const int64_t* __restrict
     unsigned char* out8 = sizeof(T) == 2 ? e8.out8 : nullptr;
     const Q8 qs(out8 ? e8.qscale : nullptr);
     float amax8 = 0.f;
-    for (int row = blockIdx.x * WPB + wid; row < M; row += gridDim.x * WPB) {
+    for (int row = blockIdx.x * WPB + wid; row < M; row += sj.main_blocks * WPB) {
         const int64_t rb = (int64_t)row * H;
         const int64_t wi = ids[row], pi = row % Tlen, ti = seg ? seg[row] : 0;
         float z[NV][4];
@@ -1274,8 +1309,28 @@ template <typename T>
 int embed_fwd(const int64_t* ids, const int64_t* seg, const void* word, const void* pos, const void* type,
               const float* gamma, const float* beta, void* out, void* z_out, float* stats, int M, int Tlen, int H,
               float eps, float p, const uint64_t* rng, uint32_t sid, void* out8, const float* qscale, float* amax,
-              int amax_slots, hipStream_t st) {
+              int amax_slots, const xggm_side_jobs* side, hipStream_t st) {
     if (int e = check_row_shape("xggm_embed_fwd", M, H)) return e;
+    SideJobs sj;
+    sj.n = 0;
+    sj.main_blocks = rows_grid(M, 4096);
+    int side_blocks = 0;
+    if (side) {
+        XGGM_REQUIRE(side->n >= 0 && side->n <= XGGM_SIDE_MAX, "xggm_embed_fwd_side: %d side jobs (at most %d)", side->n, XGGM_SIDE_MAX);
+        for (int k = 0; k < side->n; ++k) {
+            const auto& j = side->job[k];
+            XGGM_REQUIRE((j.kind == XGGM_SIDE_ADDITIVE_MASK || j.kind == XGGM_SIDE_CAST_BF16) && j.src && j.dst && j.count > 0,
+                         "xggm_embed_fwd_side: bad side job %d (kind %d, %lld elements)", k, j.kind, (long long)j.count);
+            sj.kind[k] = j.kind;
+            sj.src[k] = j.src;
+            sj.dst[k] = j.dst;
+            sj.count[k] = j.count;
+            sj.blk0[k] = side_blocks;
+            side_blocks += (int)std::min<int64_t>(ceil_div64(j.count, (int64_t)NT * 8), 256);
+        }
+        sj.n = side->n;
+        sj.blk0[sj.n] = side_blocks;
+    }
     XGGM_REQUIRE(!out8 || (sizeof(T) == 2 && reinterpret_cast<uintptr_t>(out8) % 4 == 0),
                  "xggm_embed_fwd: the e4m3 output copy needs bf16 storage and a 4-byte aligned buffer");
     const Emit8 e8{reinterpret_cast<unsigned char*>(out8), qscale, amax, amax_slots > 1 ? amax_slots : 1};
@@ -1283,9 +1338,9 @@ int embed_fwd(const int64_t* ids, const int64_t* seg, const void* word, const vo
     XGGM_REQUIRE(Tlen > 0 && M % Tlen == 0, "xggm_embed_fwd: M=%d is not a multiple of T=%d", M, Tlen);
     XGGM_REQUIRE(p == 0.f || rng, "xggm_embed_fwd: dropout needs an rng state");
     DropArgs d{0.f, p, rng, 0, sid};
-    DISPATCH_NV(H, hipLaunchKernelGGL((embed_fwd_kernel<T, NV>), dim3(rows_grid(M, 4096)), dim3(NT), 0, st, ids, seg,
+    DISPATCH_NV(H, hipLaunchKernelGGL((embed_fwd_kernel<T, NV>), dim3(sj.main_blocks + side_blocks), dim3(NT), 0, st, ids, seg,
                                        (const T*)word, (const T*)pos, (const T*)type, gamma, beta, (T*)out, (T*)z_out, stats,
-                                       M, Tlen, H, eps, d, e8));
+                                       M, Tlen, H, eps, d, e8, sj));
     return xggm_check_launch("xggm_embed_fwd");
 }
 
@@ -1413,7 +1468,15 @@ size_t ws_colsum(int M, int N) { return sizeof(float) * (size_t)ceil_div(M, CS_R
                                         uint32_t sid, void* out8, const float* qscale, float* amax, int amax_slots,       \
                                         hipStream_t st) {                                                                 \
         return embed_fwd<T>(ids, seg, word, pos, type, gamma, beta, out, z_out, stats, M, Tlen, H, eps, p, rng, sid, out8, \
-                            qscale, amax, amax_slots, st);                                                                 \
+                            qscale, amax, amax_slots, nullptr, st);                                                        \
+    }                                                                                                                       \
+    extern "C" int xggm_embed_fwd_side_##SUF(const int64_t* ids, const int64_t* seg, const void* word, const void* pos,    \
+                                             const void* type, const float* gamma, const float* beta, void* out,           \
+                                             void* z_out, float* stats, int M, int Tlen, int H, float eps, float p,         \
+                                             const uint64_t* rng, uint32_t sid, void* out8, const float* qscale,           \
+                                             float* amax, int amax_slots, const xggm_side_jobs* side, hipStream_t st) {    \
+        return embed_fwd<T>(ids, seg, word, pos, type, gamma, beta, out, z_out, stats, M, Tlen, H, eps, p, rng, sid, out8, \
+                            qscale, amax, amax_slots, side, st);                                                           \
     }                                                                                                                       \
     extern "C" int xggm_embed_bwd_##SUF(const int64_t* ids, const int64_t* seg, const void* dy, const void* z,             \
                                         const float* stats, const float* gamma, void* dz_ws, float* dword, float* dpos,    \

@@ -114,7 +114,7 @@ class CapturedTrainer:
             clip_norm_local(arena)
         z.exchange_norm(arena.sqnorm)
         with torch.cuda.graph(g2, pool=pool, capture_error_mode=self.capture_mode):
-            total = clip_norm_finish(arena, self.clip)
+            total = clip_norm_finish(arena, self.clip, tail=(self.optim, None))  # (the schedule step rides on the finish)
             self.optim.step()
         z.gather()
         self.optim.zero_grad()

@@ -184,10 +184,11 @@ class EmbedFn(Function):
         # this kernel as e4m3 too (no quantisation launch)
         f8 = a.fp8 if a.w(mod.word_embeddings.weight).dtype == torch.bfloat16 else None
         e8 = f8.emit(("emb", id(mod))) if f8 is not None else (None, None)
+        side, rt.side_jobs = getattr(rt, "side_jobs", None), None  # input glue LXRTModel.forward queued for this launch
         res = ops.embed_fwd(ids, seg, a.w(mod.word_embeddings.weight),
                             a.w(mod.position_embeddings.weight),
                             a.w(mod.token_type_embeddings.weight), mod.LayerNorm.weight.data,
-                            mod.LayerNorm.bias.data, 1e-12, rt.p(rt.p_hidden), rt.rng, mod._sid, emit8=e8[0])
+                            mod.LayerNorm.bias.data, 1e-12, rt.p(rt.p_hidden), rt.rng, mod._sid, emit8=e8[0], side=side)
         out, z, stats = res[:3]
         if f8 is not None:
             f8.put(out, res[3], e8[1])
@@ -741,13 +742,23 @@ class GCNFn(Function):
         B, N, H = x.shape
         hs = [x.contiguous()]
         convs = []
+        # bf16 storage: W (A x) = A (x W^T) -- the product first, then aggregate + residual + LayerNorm as ONE kernel
+        # (xggm_agg_residual_ln_bf16) instead of three launches; the backward follows the same order (d y = A^T d t)
+        swapped = ops.agg_residual_ln_ok(x, N)
         for conv in gcn.gnn_layers:
-            agg = ops.aggregate(adj, hs[-1])
-            t, _ = ops.linear_fwd(agg.view(B * N, H), a.w(conv.ctx_layer.weight), None)
-            h, z, stats = ops.ln_fwd(t, None, hs[-1].view(B * N, H), conv.layer_norm.weight.data,
-                                     conv.layer_norm.bias.data, 1e-5)
-            convs.append((agg, z, stats))
+            if swapped:
+                y, _ = ops.linear_fwd(hs[-1].view(B * N, H), a.w(conv.ctx_layer.weight), None)
+                h, z, stats = ops.agg_residual_ln(adj, y.view(B, N, H), hs[-1], conv.layer_norm.weight.data,
+                                                  conv.layer_norm.bias.data, 1e-5)
+                convs.append((y, z.view(B * N, H), stats))
+            else:
+                agg = ops.aggregate(adj, hs[-1])
+                t, _ = ops.linear_fwd(agg.view(B * N, H), a.w(conv.ctx_layer.weight), None)
+                h, z, stats = ops.ln_fwd(t, None, hs[-1].view(B * N, H), conv.layer_norm.weight.data,
+                                         conv.layer_norm.bias.data, 1e-5)
+                convs.append((agg, z, stats))
             hs.append(h.view(B, N, H))
+        ctx.swapped = swapped
         p_ro = rt.p(gcn.dropout_p)
         pf = [ops.p_fwd(h.view(B * N, H), a.w(mlp[0].weight), mlp[0].bias.data, act=ops.ACT_GELU, want_preact=True)
               for mlp, h in zip(gcn.linear_prediction, hs)]
@@ -789,13 +800,20 @@ class GCNFn(Function):
             d_t, _ = ops.ln_bwd(dh[k + 1], z, stats, conv.layer_norm.weight.data,
                                 a.atomic_target(conv.layer_norm.weight), a.atomic_target(conv.layer_norm.bias), None,
                                 d_res=dh[k], defer=rt.defer_list())
+            if ctx.swapped:
+                # t = A y, y = h_k W^T (agg holds y): d y = A^T d t; d W = d y^T h_k; d h_k += d y W; d A += d t y^T
+                d_y = ops.aggregate(adj, d_t.view(B, N, H), mode=ops.AGG_TRANSPOSE).view(B * N, H)
+                pd, _ = ops.p_dgrad(d_y, a.w(conv.ctx_layer.weight), into=dh[k])
+                ops.gemm_group(d_t.dtype, [_p_wgrad(rt, d_y, hs[k].view(B * N, H), conv.ctx_layer.weight), pd])
+                if ctx.needs_input_grad[3]:
+                    d_adj = ops.bmm_nt(d_t.view(B, N, H), agg.view(B, N, H), into=d_adj)
+                continue
             pd, d_agg = ops.p_dgrad(d_t, a.w(conv.ctx_layer.weight))
             ops.gemm_group(d_t.dtype, [_p_wgrad(rt, d_t, agg.view(B * N, H), conv.ctx_layer.weight), pd])
             d_agg = d_agg.view(B, N, H)
             ops.aggregate(adj, d_agg, mode=ops.AGG_TRANSPOSE, out=dh[k].view(B, N, H))
             if ctx.needs_input_grad[3]:
-                g = ops.bmm_nt(d_agg, hs[k])
-                d_adj = g if d_adj is None else ops.add_n([d_adj, g], out=d_adj)
+                d_adj = ops.bmm_nt(d_agg, hs[k], into=d_adj)  # the second layer's product adds into the first one's
         dx = dh[0].view(B, N, H) if ctx.needs_input_grad[2] else None
         return (None, None, dx, d_adj) + (None,) * ctx.np
 

@@ -465,9 +465,13 @@ class LXRTModel(BertPreTrainedModel):
         if token_type_ids is None:
             token_type_ids = torch.zeros_like(input_ids)
         # additive masks (1 - m) * -10000, [B,1,1,S] as in the reference (:919-939)
+        rt = runtime_of(self)
+        side = []  # input glue done by workgroups appended to the embedding kernel's launch (ops.embed_fwd, side=)
         if attention_mask.is_cuda and attention_mask.dtype == torch.int64 and attention_mask.is_contiguous():
-            # one kernel for the reference's cast / subtract / multiply
-            extended_attention_mask = ops.additive_mask(attention_mask).unsqueeze(1).unsqueeze(2)
+            # the reference's cast / subtract / multiply
+            m = torch.empty(attention_mask.shape, device=attention_mask.device, dtype=torch.float32)
+            side.append((ops.SIDE_ADDITIVE_MASK, attention_mask, m))
+            extended_attention_mask = m.unsqueeze(1).unsqueeze(2)
         else:
             extended_attention_mask = (1.0 - attention_mask.unsqueeze(1).unsqueeze(2).to(torch.float32)) * -10000.0
         if visual_attention_mask is not None:
@@ -478,10 +482,24 @@ class LXRTModel(BertPreTrainedModel):
         # fp8 forward: the producers' e4m3 copies of THIS forward start here -- in front of the embeddings, whose kernels
         # write the first two (begun inside the encoder, as it was, the registry was cleared right after they had
         # registered, and both streams of every pass went through the stand-alone quantiser)
-        rt = runtime_of(self)
         if rt.arena.fp8 is not None:
             rt.arena.fp8.begin_forward()
+        if visual_feats is not None and rt.arena.compute_dtype == torch.bfloat16:
+            # fp32 visual features / boxes: their bf16 copies (VisualFeatEncoder.forward) ride along too
+            cast = []
+            for t in visual_feats:
+                if t.is_cuda and t.dtype == torch.float32 and len(side) < ops.SIDE_MAX:
+                    t = t.contiguous()
+                    c = torch.empty(t.shape, device=t.device, dtype=torch.bfloat16)
+                    side.append((ops.SIDE_CAST_BF16, t, c))
+                    t = c
+                cast.append(t)
+            visual_feats = tuple(cast)
+        rt.side_jobs = side or None
         embedding_output = self.embeddings(input_ids, token_type_ids)
+        if rt.side_jobs:  # an embedding module that does not take them along: launches of their own
+            ops.run_side_jobs(rt.side_jobs)
+            rt.side_jobs = None
         lang_feats, visn_feats = self.encoder(embedding_output, extended_attention_mask, visn_feats=visual_feats,
                                               visn_attention_mask=extended_visual_attention_mask)
         pooled_output = self.pooler(lang_feats)

@@ -57,10 +57,20 @@ def clip_grad_norm_(parameters, max_norm, tail=None):
     if arena is None:
         raise RuntimeError("clip_grad_norm_: parameters are not arena-managed; run a forward first")
     if arena.wire is not None:  # data parallel, bf16 wire arena: the (averaged) gradients live there
+        if arena.zero1 is None:
+            spans = [(a, b) for a, b in _active_ranges(arena) if b > a]
+            if len(spans) <= ops.CLIP_NORM_MAX_SPANS and all(a % 8 == 0 for a, _ in spans):
+                # replicated update: every rank sums the whole wire itself -- one pair of launches, the pass's scalar
+                # bookkeeping on the finishing one (as on one GPU); |mean|^2 = |sum|^2 / world^2
+                total = torch.empty(1, device=arena.grads.device, dtype=torch.float32)
+                sched, rng = _tail_of(arena, tail)
+                ops.clip_norm_bf16(arena.wire, spans, arena.sqnorm, total, mul=arena.grad_scale ** 2, sched=sched, rng=rng)
+                arena.pending_clip = float(max_norm)
+                return total.view(())
         clip_norm_local(arena)
         if arena.zero1 is not None:
             arena.zero1.exchange_norm(arena.sqnorm)
-        return clip_norm_finish(arena, max_norm)
+        return clip_norm_finish(arena, max_norm, tail)
     # ranges of the flat gradient buffer the norm pass has to READ: everything of the active groups except the
     # matrices whose weight-gradient GEMM already left its sum of squares in the slot table (arena.sq_target);
     # adjacent ranges are merged
@@ -99,16 +109,7 @@ def clip_grad_norm_(parameters, max_norm, tail=None):
     total = torch.empty(1, device=arena.grads.device, dtype=torch.float32)
     if len(spans) + len(slot_spans) <= ops.CLIP_NORM_MAX_SPANS:
         # one pair of launches for the ranges AND the slot table; the finishing one carries the pass's scalar bookkeeping
-        sched = rng = None
-        if tail is not None:
-            optim, rt = tail
-            entries = [(gi, pg['t_total'], pg['warmup']) for _, pg, gi in optim._todo(arena)]
-            if entries and len(entries) <= ops.CLIP_NORM_MAX_SCHED:
-                sched = (arena.steps, arena.lr_scale, entries)
-                arena.sched_done = True
-            if rt is not None:
-                rng = (rt.rng, 1)
-                rt.rng_advanced = True
+        sched, rng = _tail_of(arena, tail)
         ops.clip_norm(arena.grads, spans, arena.sq_slots if slot_spans else None, slot_spans, arena.sqnorm, total, sched=sched,
                       rng=rng)
     else:
@@ -119,6 +120,22 @@ def clip_grad_norm_(parameters, max_norm, tail=None):
     return total.view(())
 
 
+def _tail_of(arena, tail):
+    """(sched, rng) arguments of ops.clip_norm* for ``tail`` = (optimiser, runtime or None) of clip_grad_norm_, and the
+    marks that tell ``optimiser.step()`` / ``runtime.advance()`` that their launch has been made"""
+    sched = rng = None
+    if tail is not None:
+        optim, rt = tail
+        entries = [(gi, pg['t_total'], pg['warmup']) for _, pg, gi in optim._todo(arena)]
+        if entries and len(entries) <= ops.CLIP_NORM_MAX_SCHED:
+            sched = (arena.steps, arena.lr_scale, entries)
+            arena.sched_done = True
+        if rt is not None:
+            rng = (rt.rng, 1)
+            rt.rng_advanced = True
+    return sched, rng
+
+
 def _active_ranges(arena):
     return [(arena.groups[g].start, arena.groups[g].end)
             for g in sorted(arena.active_groups(), key=lambda n: arena.groups[n].start)]
@@ -127,23 +144,30 @@ def _active_ranges(arena):
 def clip_norm_local(arena):
     """wire-arena norm, first half: seed the running sum and add what THIS rank sums alone -- everything without a
     sharded update, the own slices of the matrix runs with one (their sum is then all-reduced: ShardedUpdate)"""
-    ops.sqnorm_multi(arena.grads, [], arena.sqnorm, None, overwrite=True)
     z = arena.zero1
     spans = _active_ranges(arena) if z is None else z.norm_spans(_active_ranges(arena))[0]
+    spans = [(a, b) for a, b in spans if b > a]
+    if len(spans) <= ops.CLIP_NORM_MAX_SPANS and all(a % 8 == 0 for a, _ in spans):
+        ops.clip_norm_bf16(arena.wire, spans, arena.sqnorm)  # seeds the sum: one pair of launches for all ranges
+        return
+    ops.sqnorm_multi(arena.grads, [], arena.sqnorm, None, overwrite=True)
     for a, b in spans:
-        if b > a:
-            ops.sqnorm_bf16(arena.wire[a:b], arena.sqnorm)
+        ops.sqnorm_bf16(arena.wire[a:b], arena.sqnorm)
 
 
-def clip_norm_finish(arena, max_norm):
+def clip_norm_finish(arena, max_norm, tail=None):
     """second half: the vector ranges every rank holds in full (sharded update only), then the norm"""
     z = arena.zero1
-    if z is not None:
-        for a, b in z.norm_spans(_active_ranges(arena))[1]:
-            ops.sqnorm_bf16(arena.wire[a:b], arena.sqnorm)
+    spans = [(a, b) for a, b in (z.norm_spans(_active_ranges(arena))[1] if z is not None else []) if b > a]
     total = torch.empty(1, device=arena.grads.device, dtype=torch.float32)
     # the wire holds sums over the ranks: |mean|^2 = |sum|^2 / world^2
-    ops.sqnorm_multi(arena.grads, [], arena.sqnorm, total, overwrite=False, mul=arena.grad_scale ** 2)
+    if len(spans) <= ops.CLIP_NORM_MAX_SPANS and all(a % 8 == 0 for a, _ in spans):
+        sched, rng = _tail_of(arena, tail)
+        ops.clip_norm_bf16(arena.wire, spans, arena.sqnorm, total, accumulate=True, mul=arena.grad_scale ** 2, sched=sched, rng=rng)
+    else:
+        for a, b in spans:
+            ops.sqnorm_bf16(arena.wire[a:b], arena.sqnorm)
+        ops.sqnorm_multi(arena.grads, [], arena.sqnorm, total, overwrite=False, mul=arena.grad_scale ** 2)
     arena.pending_clip = float(max_norm)
     return total.view(())
 

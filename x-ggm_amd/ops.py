@@ -383,15 +383,21 @@ def colsum(x, out):
     call("xggm_colsum_" + sfx(x.dtype), ptr(x), ptr(out), M, N, ld, ptr(ws), nb, stream())
 
 
-def bmm_nt(a, b, out_f32=True):
-    """out[z] = a[z] @ b[z]^T for contiguous a [Z,M,K], b [Z,N,K] -> [Z,M,N]."""
+def bmm_nt(a, b, out_f32=True, into=None):
+    """out[z] = a[z] @ b[z]^T for contiguous a [Z,M,K], b [Z,N,K] -> [Z,M,N].  ``into``: an existing [Z,M,N] result the
+    product is ADDED to (returned)."""
     Z, M, K = a.shape
     Z2, N, K2 = b.shape
     assert Z == Z2 and K == K2 and a.dtype == b.dtype
     _c(a), _c(b)
-    out = torch.empty((Z, M, N), device=a.device, dtype=F32 if out_f32 else a.dtype)
+    if into is not None:
+        _c(into, F32 if out_f32 else a.dtype)
+        assert tuple(into.shape) == (Z, M, N)
+        out = into
+    else:
+        out = torch.empty((Z, M, N), device=a.device, dtype=F32 if out_f32 else a.dtype)
     gemm_raw(a.dtype, a, b, out, M, N, K, K, 1, K, 1, N, batch=Z, a_bs=M * K, b_bs=N * K, c_bs=M * N,
-             c_f32=out_f32)
+             c_f32=out_f32, accumulate=into is not None)
     return out
 
 
@@ -810,8 +816,31 @@ def _emit8_args(emit8, shape, device):
     return out8, ptr(emit8[0]), ptr(emit8[1]), (emit8[1].numel() if emit8[1] is not None else 0)
 
 
-def embed_fwd(ids, seg, word, pos, typ, gamma, beta, eps, p, rng, sid, emit8=None):
-    """``emit8`` = (qscale, amax): the output is also written as e4m3 (returned as a 4th value)"""
+SIDE_MAX, SIDE_ADDITIVE_MASK, SIDE_CAST_BF16 = 3, 1, 2
+
+
+class _SideJob(_ct.Structure):
+    _fields_ = [("kind", _ct.c_int), ("src", _ct.c_void_p), ("dst", _ct.c_void_p), ("count", _ct.c_int64)]
+
+
+class SideJobs(_ct.Structure):
+    """mirror of ``xggm_side_jobs`` (include/xggm.h)"""
+    _fields_ = [("n", _ct.c_int), ("job", _SideJob * SIDE_MAX)]
+
+
+def run_side_jobs(jobs):
+    """the stand-alone launches of side jobs nobody carried: [(kind, src, dst)]"""
+    for kind, src, dst in jobs:
+        if kind == SIDE_ADDITIVE_MASK:
+            call("xggm_additive_mask", ptr(src), ptr(dst), src.numel(), stream())
+        else:
+            call("xggm_cast_from_f32_bf16", ptr(src), ptr(dst), src.numel(), stream())
+
+
+def embed_fwd(ids, seg, word, pos, typ, gamma, beta, eps, p, rng, sid, emit8=None, side=None):
+    """``emit8`` = (qscale, amax): the output is also written as e4m3 (returned as a 4th value).  ``side``: up to three
+    (kind, src, dst) pieces of the pass's input glue (SIDE_ADDITIVE_MASK: int64 mask -> fp32 additive mask;
+    SIDE_CAST_BF16: fp32 -> bf16) done by workgroups appended to this launch (xggm_embed_fwd_side_*)."""
     B, T = ids.shape
     _c(ids, torch.int64, "input_ids")
     if seg is not None:
@@ -826,9 +855,21 @@ def embed_fwd(ids, seg, word, pos, typ, gamma, beta, eps, p, rng, sid, emit8=Non
     z = torch.empty_like(out)
     stats = torch.empty((B * T, 2), device=word.device, dtype=F32)
     out8, q, am, slots = _emit8_args(emit8 if word.dtype == BF16 else None, (B * T, H), word.device)
-    call("xggm_embed_fwd_" + sfx(word.dtype), ptr(ids), ptr(seg), ptr(word), ptr(pos), ptr(typ), ptr(gamma),
-         ptr(beta), ptr(out), ptr(z), ptr(stats), B * T, T, H, float(eps), float(p), ptr(rng), sid, ptr(out8), q, am, slots,
-         stream())
+    if side:
+        assert len(side) <= SIDE_MAX
+        sj = SideJobs()
+        sj.n = len(side)
+        for k, (kind, src, dst) in enumerate(side):
+            _c(src, torch.int64 if kind == SIDE_ADDITIVE_MASK else F32), _c(dst, F32 if kind == SIDE_ADDITIVE_MASK else BF16)
+            assert dst.numel() == src.numel()
+            sj.job[k].kind, sj.job[k].src, sj.job[k].dst, sj.job[k].count = kind, ptr(src), ptr(dst), src.numel()
+        call("xggm_embed_fwd_side_" + sfx(word.dtype), ptr(ids), ptr(seg), ptr(word), ptr(pos), ptr(typ), ptr(gamma),
+             ptr(beta), ptr(out), ptr(z), ptr(stats), B * T, T, H, float(eps), float(p), ptr(rng), sid, ptr(out8), q, am, slots,
+             _ct.byref(sj), stream())
+    else:
+        call("xggm_embed_fwd_" + sfx(word.dtype), ptr(ids), ptr(seg), ptr(word), ptr(pos), ptr(typ), ptr(gamma),
+             ptr(beta), ptr(out), ptr(z), ptr(stats), B * T, T, H, float(eps), float(p), ptr(rng), sid, ptr(out8), q, am, slots,
+             stream())
     if emit8 is not None:
         return out, z, stats, out8
     return out, z, stats
@@ -903,6 +944,24 @@ def aggregate(Mx, x, mode=AGG_PLAIN, scale=1.0, scale_ptr=None, self_w=0.0, out=
     call("xggm_aggregate_" + sfx(x.dtype), ptr(Mx), ptr(x), ptr(out), B, N, H, mode, float(scale),
          ptr(scale_ptr), float(self_w), int(acc), stream())
     return out
+
+
+def agg_residual_ln(Mx, y, res, gamma, beta, eps):
+    """LayerNorm(res + Mx @ y) per sample in ONE launch (bf16 [B, N, H], H in 64 / 128 / 256 / 768, N <= 64): GCNConv's
+    tail once y = x W^T has been taken (xggm_agg_residual_ln_bf16).  Returns (out, z, stats) as ``ln_fwd`` does."""
+    _c(Mx, F32, "adjacency"), _c(y, BF16), _c(res, BF16), _c(gamma, F32, "gamma"), _c(beta, F32, "beta")
+    B, N, H = y.shape
+    assert tuple(Mx.shape) == (B, N, N) and res.shape == y.shape and gamma.numel() == H and beta.numel() == H
+    out, z = torch.empty_like(y), torch.empty_like(y)
+    stats = torch.empty((B * N, 2), device=y.device, dtype=F32)
+    call("xggm_agg_residual_ln_bf16", ptr(Mx), ptr(y), ptr(res), ptr(gamma), ptr(beta), ptr(out), ptr(z), ptr(stats), B, N, H,
+         float(eps), stream())
+    return out, z, stats
+
+
+def agg_residual_ln_ok(x, N):
+    """shapes the fused GCNConv tail is built for"""
+    return x.dtype == BF16 and x.shape[-1] in (64, 128, 256, 768) and N <= 64
 
 
 def agg_dot(Mx, x, dh, out):
@@ -1143,6 +1202,45 @@ CLIP_NORM_MAX_SPANS = 24
 CLIP_NORM_MAX_SCHED = 16
 
 
+def _pass_tail(sched, rng):
+    """(xggm_pass_tail or None, objects to keep alive) for clip_norm / clip_norm_bf16"""
+    if sched is None and rng is None:
+        return None, ()
+    tail, keep = _PassTail(), []
+    if sched is not None:
+        steps, lr_scale, entries = sched
+        _c(steps, torch.int64), _c(lr_scale, F32)
+        n = len(entries)
+        assert n <= CLIP_NORM_MAX_SCHED
+        idx = (_ct.c_int * max(n, 1))(*[int(e[0]) for e in entries])
+        tt = (_ct.c_int64 * max(n, 1))(*[int(e[1]) for e in entries])
+        wu = (_ct.c_float * max(n, 1))(*[float(e[2]) for e in entries])
+        keep += [idx, tt, wu]
+        tail.steps, tail.lr_scale, tail.n = ptr(steps), ptr(lr_scale), n
+        tail.index, tail.t_total, tail.warmup = (_ct.cast(a, _ct.c_void_p) for a in (idx, tt, wu))
+    if rng is not None:
+        tail.rng, tail.rng_by = ptr(rng[0]), int(rng[1])
+    return tail, keep
+
+
+def clip_norm_bf16(g, spans, out, norm=None, accumulate=False, mul=1.0, sched=None, rng=None):
+    """out (1 fp32) = ((out if accumulate else 0) + sum over the (start, end) ranges of the bf16 buffer g of g^2) * mul,
+    ``norm`` = sqrt(out): the norm pass over the data-parallel wire arena in two launches (at most 24 ranges, starts
+    multiples of 8); ``sched`` / ``rng`` as in ``clip_norm``."""
+    _c(g, BF16), _c(out, F32)
+    rs = [(s, e) for s, e in spans if e > s]
+    assert len(rs) <= CLIP_NORM_MAX_SPANS
+    ws = _SQNORM_WS.get(g.device)
+    if ws is None:
+        ws = _SQNORM_WS[g.device] = torch.zeros(4100, device=g.device, dtype=F32)
+    offs = (_ct.c_int64 * max(len(rs), 1))(*[s for s, _ in rs])
+    lens = (_ct.c_int64 * max(len(rs), 1))(*[e - s for s, e in rs])
+    tail, keep = _pass_tail(sched, rng)
+    call("xggm_clip_norm_bf16", ptr(g), _ct.cast(offs, _ct.c_void_p), _ct.cast(lens, _ct.c_void_p), len(rs), ptr(out),
+         ptr(norm) if norm is not None else None, ptr(ws), int(accumulate), float(mul),
+         _ct.byref(tail) if tail is not None else None, stream())
+
+
 def clip_norm(g, spans, slots, slot_spans, out, norm=None, mul=1.0, sched=None, rng=None):
     """out (1 fp32) = mul * (sum over the (start, end) ranges ``spans`` of g^2 + sum over ``slot_spans`` of slots), fixed
     summation order, ``norm`` (1 fp32 or None) = sqrt(out): the whole norm of a pass in two launches.  The finishing
@@ -1163,23 +1261,7 @@ def clip_norm(g, spans, slots, slot_spans, out, norm=None, mul=1.0, sched=None, 
 
     o1, l1 = arrs(rs)
     o2, l2 = arrs(ss)
-    tail = None
-    if sched is not None or rng is not None:
-        tail = _PassTail()
-        keep = []
-        if sched is not None:
-            steps, lr_scale, entries = sched
-            _c(steps, torch.int64), _c(lr_scale, F32)
-            n = len(entries)
-            assert n <= CLIP_NORM_MAX_SCHED
-            idx = (_ct.c_int * max(n, 1))(*[int(e[0]) for e in entries])
-            tt = (_ct.c_int64 * max(n, 1))(*[int(e[1]) for e in entries])
-            wu = (_ct.c_float * max(n, 1))(*[float(e[2]) for e in entries])
-            keep += [idx, tt, wu]
-            tail.steps, tail.lr_scale, tail.n = ptr(steps), ptr(lr_scale), n
-            tail.index, tail.t_total, tail.warmup = (_ct.cast(a, _ct.c_void_p) for a in (idx, tt, wu))
-        if rng is not None:
-            tail.rng, tail.rng_by = ptr(rng[0]), int(rng[1])
+    tail, keep = _pass_tail(sched, rng)
     call("xggm_clip_norm_f32", ptr(g), _ct.cast(o1, _ct.c_void_p), _ct.cast(l1, _ct.c_void_p), len(rs),
          ptr(slots) if ss else None, _ct.cast(o2, _ct.c_void_p), _ct.cast(l2, _ct.c_void_p), len(ss), ptr(out),
          ptr(norm) if norm is not None else None, ptr(ws), float(mul), _ct.byref(tail) if tail is not None else None, stream())
