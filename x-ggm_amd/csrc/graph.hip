@@ -238,6 +238,7 @@ __global__ __launch_bounds__(NT) void agg_res_ln_kernel(const float* __restrict_
     bf16* Mh = ys + NK * LDY;                                       // [16][LDM]
     bf16* Ml = Mh + 16 * LDM;                                       // [16][LDM]
     float* red = reinterpret_cast<float*>(Ml + 16 * LDM);           // [4][16]
+    float* gb = red + 64;                                           // gamma [H], beta [H]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int ntile = (N + 15) >> 4;
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
@@ -251,6 +252,12 @@ __global__ __launch_bounds__(NT) void agg_res_ln_kernel(const float* __restrict_
     const bf16* rb = res + ((int64_t)b * N + (row_ok ? row : 0)) * H + wid * CG * 16 + 4 * fq;
 #pragma unroll
     for (int g = 0; g < CG; ++g) rres[g] = *reinterpret_cast<const agg_short4*>(rb + g * 16);
+    // gamma / beta through LDS: read here, beside the slab, instead of twelve dependent global loads per lane behind the
+    // row statistics (the kernel's tail was those round trips)
+    for (int e = tid; e < H / 4; e += NT) {
+        *reinterpret_cast<float4*>(gb + 4 * e) = *reinterpret_cast<const float4*>(gamma + 4 * e);
+        *reinterpret_cast<float4*>(gb + H + 4 * e) = *reinterpret_cast<const float4*>(beta + 4 * e);
+    }
     // the 16 adjacency rows of this tile -> hi / lo bf16, k beyond N zero
     const float* Mb = Mx + (int64_t)b * N * N;
     for (int e = tid; e < 16 * NK / 4; e += NT) {
@@ -347,9 +354,9 @@ __global__ __launch_bounds__(NT) void agg_res_ln_kernel(const float* __restrict_
 #pragma unroll
     for (int g = 0; g < CG; ++g) {
         const int c = wid * CG * 16 + g * 16 + 4 * fq;
-        float g4[4], be4[4], o[4], zz[4];
-        load4(gamma + c, g4);
-        load4(beta + c, be4);
+        float o[4], zz[4];
+        const float4 g4v = *reinterpret_cast<const float4*>(gb + c), be4v = *reinterpret_cast<const float4*>(gb + H + c);
+        const float g4[4] = {g4v.x, g4v.y, g4v.z, g4v.w}, be4[4] = {be4v.x, be4v.y, be4v.z, be4v.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             zz[r] = acc[g][r];
@@ -605,10 +612,10 @@ template <int CG>
 int launch_agg_res_ln(const float* M, const bf16* y, const bf16* res, const float* gamma, const float* beta, bf16* out, bf16* z_out,
                       float* stats, int B, int N, float eps, hipStream_t st) {
     constexpr int H = CG * 64;
-    const size_t lds = sizeof(bf16) * (64 * (H + 8) + 2 * 16 * 72) + sizeof(float) * 64;
+    constexpr size_t lds = sizeof(bf16) * (64 * (H + 8) + 2 * 16 * 72) + sizeof(float) * (64 + 2 * H);
     static bool once = [] {  // more than the default 64 KB of dynamic LDS: opt in once per instantiation
         return hipFuncSetAttribute(reinterpret_cast<const void*>(agg_res_ln_kernel<CG>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)(sizeof(bf16) * (64 * (H + 8) + 2 * 16 * 72) + sizeof(float) * 64)) == hipSuccess;
+                                   (int)lds) == hipSuccess;
     }();
     XGGM_REQUIRE(once, "xggm_agg_residual_ln_bf16: cannot reserve %zu bytes of LDS", lds);
     const int grid = ceil_div(B, 8) * 8 * ceil_div(N, 16);

@@ -1241,7 +1241,14 @@ int ln_fwd(const void* in, const float* bias, const void* residual, const float*
 }
 
 inline size_t bwd_ws_bytes(int M, int H, int K) { return sizeof(float) * (size_t)rows_grid(M, 512) * K * H; }
-inline int ln_bwd_grid(int M) { return std::min(ceil_div(M, LN_BWD_W), 512); }
+// workgroups of a LayerNorm backward = partial [3, H] rows its reduce job reads: at most 256 (one per CU).  With 512 the
+// launches of >= 2048 rows (the reference batch of 92, the 64 x 64 stress configuration) left twice the partial rows for
+// the batched reduction: 256 measured -0.15 ms per iteration at 92 samples and -20 us per C4 pass, nothing at 32 samples
+// (224 workgroups either way); 128 / 192 no better (tools/exp_ln_bwd_grid.sh, XGGM_LN_BWD_GRID overrides)
+inline int ln_bwd_grid(int M) {
+    static const int cap = getenv("XGGM_LN_BWD_GRID") ? std::max(1, atoi(getenv("XGGM_LN_BWD_GRID"))) : 256;
+    return std::min(ceil_div(M, LN_BWD_W), cap);
+}
 inline size_t ln_bwd_ws_bytes(int M, int H) { return sizeof(float) * (size_t)ln_bwd_grid(M) * 3 * H; }
 
 inline void launch_reduce(const float* ws, int nblk, int K, int H, const ReduceTargets& tg, hipStream_t st) {
