@@ -19,7 +19,7 @@ def main():
     f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
     rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))]
     rows.sort()
-    adv = [i for i, r in enumerate(rows) if "rng_advance" in r[2]]
+    adv = [i + 1 for i, r in enumerate(rows) if "bertadam_multi" in r[2]]  # a pass ends with its update
     for p in (3, 2):
         seg = rows[adv[-p]:adv[-p + 1]]
         print("---- pass of %d launches, %.3f ms" % (len(seg), (seg[-1][1] - seg[0][0]) / 1e6))

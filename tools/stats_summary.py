@@ -1,6 +1,7 @@
 """families, launches and the GEMM roofline fraction out of a rocprofv3 --kernel-trace --stats CSV of bench.py
-(python tools/stats_summary.py profiles/r03_bench_kernel_stats.csv): iterations are counted from the rng_advance
-launches (one per pass, two passes per iteration); 2.04 TFLOP of GEMM work per iteration at 32 samples."""
+(python tools/stats_summary.py profiles/r03_bench_kernel_stats.csv): iterations are counted from the update launches
+(bertadam_multi: one per pass, two passes per iteration; before round 4's single update launch: from rng_advance, which
+has since moved into the norm's finishing launch); 2.04 TFLOP of GEMM work per iteration at 32 samples."""
 import csv
 import sys
 
@@ -23,7 +24,9 @@ def calls_us(r):
     return c, tot / 1e3
 
 
-iters = sum(int(r["Calls"]) for r in rows if "rng_advance" in r["Name"]) / 2.0
+iters = sum(int(r["Calls"]) for r in rows if "bertadam_multi" in r["Name"]) / 2.0
+if not iters:  # profiles of rounds 1-3
+    iters = sum(int(r["Calls"]) for r in rows if "rng_advance" in r["Name"]) / 2.0
 fam = {}
 for r in rows:
     n = r["Name"]

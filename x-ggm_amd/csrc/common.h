@@ -244,14 +244,29 @@ __device__ __forceinline__ bool ordered_grid_sum(float part, float* ws, int nblk
     __shared__ float s_red[16];
     unsigned* counter = reinterpret_cast<unsigned*>(ws);
     if (threadIdx.x == 0) {
+        // The partial goes out as a device-scope atomic store (write-through, past this XCD's L2) and the ticket is a
+        // device-scope atomic as well; all the ticket has to wait for is THAT store's acknowledgement (s_waitcnt vmcnt(0):
+        // a wave's memory operations are acknowledged in order on this path), not a release fence -- which on gfx950 is
+        // a write-back of the XCD's whole L2 (buffer_wbl2) and cost the loss kernels more than their arithmetic:
+        // symkl forward 29 us against its backward's 12 (rocprofv3, round 4).  Nothing else is published here.
+#ifdef XGGM_SUM_FENCE
         __hip_atomic_store(ws + SUM_WS_HEAD + blk, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();  // release: the partial is visible device-wide before the ticket is
+        __threadfence();
         const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+#else
+        __hip_atomic_store(ws + SUM_WS_HEAD + blk, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         s_last = (t == (unsigned)nblk - 1u) ? 1 : 0;
     }
     __syncthreads();
     if (!s_last) return false;
+#ifdef XGGM_SUM_FENCE
     __threadfence();  // acquire: every other workgroup's partial
+#endif
+    // (the partials are read with device-scope atomic loads below: they do not come from this XCD's L2)
     float t = 0.f;
     for (int b = threadIdx.x; b < nblk; b += blockDim.x)  // thread-strided, then waves in index order: fixed
         t += __hip_atomic_load(ws + SUM_WS_HEAD + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

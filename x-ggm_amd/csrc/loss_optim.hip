@@ -27,16 +27,29 @@ __device__ __forceinline__ float block_sum(float v) {
 }
 
 inline int grid1d(int64_t n, int cap = 1024) { return (int)std::min<int64_t>(ceil_div64(n, NT), cap); }
-// workgroups of a kernel that ends in ordered_grid_sum: every one pays a device-scope release fence and a ticket, and
-// the last one adds them all -- 1024 of them made the DSM loss 36 us instead of 15 (rocprofv3, round 3)
-constexpr int LOSS_GRID = 128;
+// workgroups of a kernel that ends in ordered_grid_sum: every one pays a ticket, and the last one adds them all.  While
+// the ticket sat behind a device-scope release fence (a write-back of the XCD's L2), 1024 workgroups made the DSM loss
+// 36 us instead of 15 and the grid was held at 128 -- which left the symmetric KL's forward with nine rows per workgroup
+// (29 us against its backward's 12).  The fence is gone (common.h): one workgroup per four rows again, up to 512.
+constexpr int LOSS_GRID = 512;
 
 // ------------------------------------------------------------------------------- DSM
 template <typename T>
 __global__ __launch_bounds__(NT) void dsm_fwd_kernel(const T* __restrict__ s, const float* __restrict__ g, float* loss,
                                                      int64_t n, float coef, float* ws) {
     float acc = 0.f;
-    for (int64_t t = (int64_t)blockIdx.x * NT + threadIdx.x; t < n; t += (int64_t)gridDim.x * NT) {
+    const int64_t n4 = ((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(g)) & 15) == 0 ? n >> 2 : 0;
+    for (int64_t t = (int64_t)blockIdx.x * NT + threadIdx.x; t < n4; t += (int64_t)gridDim.x * NT) {  // four elements per load
+        float sv[4], gv[4];
+        load4(s + 4 * t, sv);
+        load4(g + 4 * t, gv);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float d = sv[i] - gv[i];
+            acc += d * d;
+        }
+    }
+    for (int64_t t = 4 * n4 + (int64_t)blockIdx.x * NT + threadIdx.x; t < n; t += (int64_t)gridDim.x * NT) {
         const float d = to_f32(s[t]) - g[t];
         acc += d * d;
     }
@@ -646,7 +659,7 @@ int symkl(const void* x, const void* y, float* loss, const float* gout, void* dx
     extern "C" int xggm_dsm_loss_fwd_##SUF(const void* s, const float* g, float* loss, int64_t n, float coef, float* ws,  \
                                            hipStream_t st) {                                                              \
         XGGM_REQUIRE(s && g && loss && ws && n > 0, "xggm_dsm_loss_fwd: bad arguments");                                   \
-        hipLaunchKernelGGL((dsm_fwd_kernel<T>), dim3(grid1d(n, LOSS_GRID)), dim3(NT), 0, st, (const T*)s, g, loss, n, coef, ws); \
+        hipLaunchKernelGGL((dsm_fwd_kernel<T>), dim3(grid1d(n / 4 + 1, LOSS_GRID)), dim3(NT), 0, st, (const T*)s, g, loss, n, coef, ws); \
         return xggm_check_launch("xggm_dsm_loss_fwd");                                                                    \
     }                                                                                                                      \
     extern "C" int xggm_dsm_loss_bwd_##SUF(const void* s, const float* g, const float* gout, void* ds, int64_t n,         \

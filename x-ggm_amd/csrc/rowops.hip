@@ -139,6 +139,7 @@ struct BatchJobs {
 // 37 us per launch of 72 jobs (41 MB = 1.1 TB/s: five dependent round trips per thread, rocprofv3 round 3).
 constexpr int RB_COLS = 64;
 constexpr int RB_SL = 16;
+constexpr int RB_FLIGHT = 16;  // loads a thread issues before it adds the first one
 __global__ __launch_bounds__(NT) void partial_reduce_batch_kernel(BatchJobs bj) {
     __shared__ float4 red[RB_SL][RB_COLS / 4];
     int ji = 0;
@@ -154,15 +155,17 @@ __global__ __launch_bounds__(NT) void partial_reduce_batch_kernel(BatchJobs bj) 
         const float* p = job.ws + idx;
         const f4 zero = {0.f, 0.f, 0.f, 0.f};
         // a thread's rows are added in row order whatever the batching: the result does not depend on scheduling
-        for (int b = sl; b < job.nblk; b += 8 * RB_SL) {  // read once: non-temporal
-            f4 r[8];
+        // (round 4: SIXTEEN loads in flight -- the 144 partial rows of the vision stream's LayerNorm backward took two
+        // dependent round trips with eight)
+        for (int b = sl; b < job.nblk; b += RB_FLIGHT * RB_SL) {  // read once: non-temporal
+            f4 r[RB_FLIGHT];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < RB_FLIGHT; ++q) {
                 const int row = b + q * RB_SL;
                 r[q] = row < job.nblk ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(p + (int64_t)row * KH)) : zero;
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc += r[q];
+            for (int q = 0; q < RB_FLIGHT; ++q) acc += r[q];
         }
     }
     red[sl][ci] = make_float4(acc[0], acc[1], acc[2], acc[3]);
