@@ -428,8 +428,11 @@ def g_attn_bwd(rt, saved, dy, defer_wgrad=False, link=None):
     return dxq, dxkv
 
 
-# split-K of the FFN output product (XGGM_SPLIT_K = 0 / 1 turns it off; same-box A/B hook)
-_SPLIT_K = int(os.environ.get("XGGM_SPLIT_K", "3"))
+# split-K of the FFN output product (XGGM_SPLIT_K = 0 / 1 turns it off; same-box A/B hook).  Three slabs until round 4;
+# with the weights prefetched and the role tiles two measure better at every batch (32 samples: 10.57 / 10.58 ms against
+# 10.61 / 10.63, 64: 14.41 against 14.45-14.57, 92: 17.94 / 17.95 against 18.17 / 18.21 -- the LayerNorm behind reads a
+# third less fp32; profiles/r04_experiments/split_k_*.txt)
+_SPLIT_K = int(os.environ.get("XGGM_SPLIT_K", "2"))
 
 
 def g_ffn_fwd(rt, inter, outm, x):
