@@ -37,7 +37,7 @@ for r in rows:
         # ~1 MB whatever --steps is; tools/find_aten.py finds none inside a pass)
         SETUP.append((n[:40], int(r["Calls"])))
         continue
-    k = ("gemm" if "gemm_" in n else "bertadam + norm" if ("bertadam" in n or "sqnorm" in n) else
+    k = ("gemm" if "gemm_" in n else "bertadam + norm" if ("bertadam" in n or "sqnorm" in n or "clip_norm" in n) else
          "layernorm" if ("ln_fwd" in n or "ln_bwd" in n) else "attention core" if "attn_" in n else "everything else")
     f = fam.setdefault(k, [0, 0.0])
     c, t = calls_us(r)
