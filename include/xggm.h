@@ -135,7 +135,7 @@ int xggm_gemm_grouped_bf16(const xggm_gemm_problem* probs, int n, xggm_stream_t 
 int xggm_gemm_fp8e4m3(const void* A, const void* B, void* C, int M, int N, int K, int64_t a_rs, int64_t b_ns, int64_t ldc,
                       const float* scale_a, const float* scale_b, const float* bias, const void* residual, void* preact,
                       int act, int c_f32, xggm_stream_t stream);
-/* The same product for up to 4 problems in one launch (the language and the vision stream of a layer, the two
+/* The same product for up to 6 problems in one launch (the language and the vision stream of a layer, the two
  * directions of a cross-attention layer): every problem has e4m3 operands A [M, K] / B [N, K], k contiguous (a_ks =
  * b_ks = 1, strides in elements = bytes, multiples of 16 like K), its own scale_a / scale_b, and the bf16 epilogue of
  * xggm_gemm_grouped_bf16 (bias, GELU + pre-activation, residual, fp32 split-K slabs through batch / c_f32, c8).  Not

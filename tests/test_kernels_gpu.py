@@ -146,6 +146,24 @@ def test_grouped_gemm(ops, dt, group_tile):
         assert rel_err(y2, xvr @ w2r.t()) < tol(dt)
         assert rel_err(dx, dyr @ w2r + resr) < tol(dt)
         assert rel_err(gw, 3.0 + dyr.t() @ xvr) < tol(dt, 2e-5, 1e-4)
+        # six problems in ONE launch (the cross-attention backward's five, the graph blocks' six read-out problems) give
+        # the bits of the same problems launched alone
+        def six():
+            ps, outs = [], []
+            for k in range(3):
+                p, y, _ = ops.p_fwd(xv if k else xl, w2, None)
+                pd, d = ops.p_dgrad(dy, w2)
+                ps += [p, pd]
+                outs += [y, d]
+            return ps, outs
+        ps, together = six()
+        assert len(ps) == ops.GROUP_MAX
+        ops.gemm_group(dt, ps)
+        ps, alone = six()
+        for p in ps:
+            ops.gemm_group(dt, [p])
+        for a_, b_ in zip(together, alone):
+            assert torch.equal(a_, b_)
         # odd shapes fall back to single launches and still agree
         xo, xor_ = rnd((37, 100), dt, 8)
         wo, wor = rnd((50, 100), dt, 9, 0.1)

@@ -1518,11 +1518,13 @@ template <int BM, int BN, int D> int launch_fp8_tile(const GemmArgs& g, const fl
     return xggm_check_launch("xggm_gemm_fp8e4m3");
 }
 
-// ---- grouped launch: up to 4 independent GEMMs (forward of both modalities, dgrad + wgrad of one
+// ---- grouped launch: up to MAX_GROUP independent GEMMs (forward of both modalities, dgrad + wgrad of one
 // layer, ...) share ONE grid, so skinny problems that cannot fill 256 CUs alone fill them together
 // and the per-launch latency is paid once.  Every workgroup looks up its problem from the tile
 // prefix sums and runs the layout-specialised tile routine.
-constexpr int MAX_GROUP = 4;
+// (6 since round 4: launch cost does not depend on the size of the argument block, tools/micro/launch_gap.hip, and the
+// cross-attention backward's fifth problem and the graph blocks' six read-out problems were launches of their own)
+constexpr int MAX_GROUP = 6;
 struct GroupArgs {
     GemmArgs p[MAX_GROUP];
     int tile_start[MAX_GROUP + 1];

@@ -246,11 +246,14 @@ def p_fwd8(x8, w8, sx, sw, bias=None, act=ACT_NONE, want_preact=False, emit8=Non
     return p, y, pre
 
 
+GROUP_MAX = 6  # MAX_GROUP of gemm.hip: problems one grouped launch takes
+
+
 def gemm_group8(problems):
-    """launch up to 4 e4m3 forward products in one grid (more: consecutive groups of 4); the measured tile table
+    """launch up to GROUP_MAX e4m3 forward products in one grid (more: consecutive groups); the measured tile table
     applies as for the bf16 groups (signatures start with ``e4m3|``)."""
-    for i in range(0, len(problems), 4):
-        chunk = problems[i:i + 4]
+    for i in range(0, len(problems), GROUP_MAX):
+        chunk = problems[i:i + GROUP_MAX]
         arr = (GemmProblem * len(chunk))(*chunk)
         pin = 0
         if TILE_TABLE or TILE_HOOK is not None:
@@ -354,9 +357,9 @@ def gemm_signature(dt, chunk):
 
 
 def gemm_group(dt, problems):
-    """launch up to 4 independent products in one grid (more: consecutive groups of 4)."""
-    for i in range(0, len(problems), 4):
-        chunk = problems[i:i + 4]
+    """launch up to GROUP_MAX independent products in one grid (more: consecutive groups)."""
+    for i in range(0, len(problems), GROUP_MAX):
+        chunk = problems[i:i + GROUP_MAX]
         arr = (GemmProblem * len(chunk))(*chunk)
         pin = 0
         if TILE_TABLE or TILE_HOOK is not None:
