@@ -1473,97 +1473,6 @@ __global__ __launch_bounds__(NT, (min_waves<BM, BN>())) void gemm_fast_kernel(Ge
     gemm_tile<BM, BN, AK, BKM, D>(g, tile_m, tile_n, blockIdx.z, fsm);
 }
 
-// ---- skinny products: M <= 64 rows (the heads behind the encoder: pooler, answer / relation / node / fusion heads --
-// one row per SAMPLE, src/lxrt/modeling.py:608-620, src/vqa/vqacpv2_model.py:63-84).  The tiled kernels above give such a
-// product ceil(N / 64) workgroups that each walk the WHOLE K through a barrier-per-tile pipeline: 12-24 dependent
-// iterations for a few MFLOP (14 us for the 32 x 768 x 768 pooler).  Here the four waves of a workgroup split K instead:
-// every wave computes the whole 16 MB x 64 tile over every fourth 32-deep k-step, with operand fragments loaded straight
-// from global memory (k-contiguous operands: a lane's 8 k-values are one 16-byte load; four k-steps in flight), the four
-// partial tiles meet in LDS, are added in wave order and leave through the common epilogue.
-template <int MB>
-__global__ __launch_bounds__(NT) void gemm_skinny_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) bf16 fsm[];
-    constexpr int ROWS = 16 * MB, LD = 68, UNR = 4;
-    const int tile_n = blockIdx.x, bz = blockIdx.z;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
-    const bf16* A = reinterpret_cast<const bf16*>(g.A) + (int64_t)bz * g.a_bs;
-    const bf16* B = reinterpret_cast<const bf16*>(g.B) + (int64_t)bz * g.b_bs;
-    const bf16* ap[MB];
-    const bf16* bp[4];
-#pragma unroll
-    for (int i = 0; i < MB; ++i) ap[i] = A + (int64_t)min(i * 16 + fr, g.M - 1) * g.a_rs + 8 * fq;  // rows >= M: never stored
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bp[j] = B + (int64_t)min(tile_n * 64 + j * 16 + fr, g.N - 1) * g.b_ns + 8 * fq;
-    float4_t accf[MB][4];
-#pragma unroll
-    for (int i = 0; i < MB; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) accf[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
-    const int nks = g.K >> 5;
-    for (int s0 = wid; s0 < nks; s0 += 4 * UNR) {
-        bf16x8_t a[UNR][MB], b[UNR][4];
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int k = (min(s0 + 4 * u, nks - 1)) << 5;  // (a step beyond K re-reads the last one and is not used)
-#pragma unroll
-            for (int i = 0; i < MB; ++i) a[u][i] = *reinterpret_cast<const bf16x8_t*>(ap[i] + k);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[u][j] = *reinterpret_cast<const bf16x8_t*>(bp[j] + k);
-        }
-#pragma unroll
-        for (int u = 0; u < UNR; ++u)
-            if (s0 + 4 * u < nks) {  // wave-uniform
-#pragma unroll
-                for (int i = 0; i < MB; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        accf[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[u][j], a[u][i], accf[i][j], 0, 0, 0);
-            }
-    }
-    float* red = reinterpret_cast<float*>(fsm);  // [4 waves][ROWS][LD]
-#pragma unroll
-    for (int i = 0; i < MB; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            *reinterpret_cast<float4_t*>(red + ((wid * ROWS + i * 16 + fr) * LD + j * 16 + 4 * fq)) = accf[i][j];
-    __syncthreads();
-    // the common epilogue's layout: wave w owns rows (w >> 1) * 32 .., columns (w & 1) * 32 .. of the 64 x 64 tile
-    float4_t acc[2][2];
-    const int wm = (wid >> 1) * 32, wn = (wid & 1) * 32;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int row = wm + i * 16 + fr, col = wn + j * 16 + 4 * fq;
-            float4_t v = {0.f, 0.f, 0.f, 0.f};
-            if (row < ROWS) {
-                v = *reinterpret_cast<const float4_t*>(red + (row * LD + col));
-#pragma unroll
-                for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const float4_t*>(red + ((w * ROWS + row) * LD + col));  // wave order: fixed
-            }
-            acc[i][j] = v;
-        }
-    __syncthreads();  // the epilogue may stage through the same LDS
-    gemm_finish<64, 64>(g, 0, tile_n, bz, fsm, acc);
-}
-
-inline bool skinny_ok(const GemmArgs& g) {
-    static const bool off = getenv("XGGM_SKINNY") && atoi(getenv("XGGM_SKINNY")) == 0;
-    return !off && g.M <= 64 && g.a_mode == 1 && g.b_mode == 1 && !g.a_tail && !g.b_tail && g.K % 32 == 0 && g.K >= 256 &&
-           !g.sqsum && !g.c8;
-}
-template <int MB> int launch_skinny(const GemmArgs& g, int batch, hipStream_t stream) {
-    constexpr size_t lds = std::max(sizeof(float) * 4 * 16 * MB * 68, sizeof(float) * 32 * 68);
-    static bool attr_set = false;
-    if (lds > 48 * 1024 && !attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<MB>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm_skinny_kernel<MB>), dim3(ceil_div(g.N, 64), 1, batch), dim3(NT), lds, stream, g);
-    return xggm_check_launch("xggm_gemm(skinny)");
-}
-
 // ---- fp8 forward GEMM (BASELINE config C5: e4m3 operands for the QKV / FFN products, everything else bf16).
 // C = epilogue(sa * sb * sum_k A8(m,k) B8(n,k)): A8, B8 OCP e4m3 bytes, k-contiguous, quantised with per-tensor scales
 // whose reciprocals sa, sb are device scalars; accumulation in fp32 on the matrix cores, epilogue and output as
@@ -1893,8 +1802,6 @@ template <typename T> int launch(GemmArgs g, int batch, hipStream_t stream) {
     dim3 grid(ceil_div(g.N, BN), ceil_div(g.M, BM), batch);
     XGGM_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "xggm_gemm: grid too large");
     if constexpr (sizeof(T) == 2) {
-        if (!g_force_generic && !g_tile_override && skinny_ok(g))
-            return g.M <= 32 ? launch_skinny<2>(g, batch, stream) : launch_skinny<4>(g, batch, stream);
         if (g.a_mode != 0 && g.b_mode != 0 && !g_force_generic) return launch_fast(g, batch, stream);
     }
     XGGM_REQUIRE(!g.sqsum, "xggm_gemm: sqsum needs the tuned bf16 kernels (8-aligned operands); this problem runs on the "
