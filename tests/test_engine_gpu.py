@@ -50,6 +50,51 @@ def _same_state(m1, m2):
     assert a1.steps.tolist() == a2.steps.tolist() and runtime_of(m1).rng.tolist() == runtime_of(m2).rng.tolist()
 
 
+def test_replays_survive_what_eager_code_does_between_them():
+    """a replay runs no Python of the pass, so host-side bookkeeping the captured kernels rely on has to be re-established
+    by ``run_pass``: (a) after an EAGER pass that touched word-table rows the device-side row list does not name (two
+    look-ups in one pass: the list is dropped), the captured clear -- which only knows the list -- must not leave those
+    rows in the gradient; (b) an evaluation forward between two replays changes nothing.  (A loader batch shorter than
+    the captured one: test_prefetching_loader_feeds_the_captured_trainer.)"""
+    from xggm_amd.engine import CapturedTrainer
+    from xggm_amd.runtime import runtime_of
+    from xggm_amd.vqa.vqacpv2 import BCEWithLogitsLoss
+    B, A = 4, 29
+    cfg, m1, o1 = _tiny(5, 11, vocab=512)
+    _, m2, o2 = _tiny(5, 11, vocab=512)
+    b = [batch_tensors(synth.vqa_batch(B, A=A, F=cfg["feat_dim"], vocab=cfg["vocab"], seed=s), DEV) for s in (3, 4, 5)]
+    t1 = CapturedTrainer(m1, o1, b[0], sigma=1.0, warmup_iters=1)
+    t2 = CapturedTrainer(m2, o2, b[0], sigma=1.0, warmup_iters=1)
+    for t in (t1, t2):
+        t.load_batch(b[1])
+        t.iteration("rel")
+    _same_state(m1, m2)
+    # (a) on the first twin only: an eager double look-up over OTHER ids, gradients accumulated, no update
+    rt, arena = runtime_of(m1), runtime_of(m1).arena
+    assert arena.row_list is not None and arena.row_list.clean
+    bce = BCEWithLogitsLoss()
+    m1.zero_grad()
+    for k in (2, 0):
+        sent = (b[k]["input_ids"], b[k]["input_mask"], b[k]["segment_ids"])
+        _, _, x = m1(b[k]["feats"], b[k]["boxes"], sent)
+        rt.backward(bce(m1.logit_fc(x), b[k]["target"], scale=A))
+    assert not arena.row_list.clean
+    # (b) on both: an evaluation forward
+    for m in (m1, m2):
+        m.eval()
+        with torch.no_grad():
+            m(b[2]["feats"], b[2]["boxes"], (b[2]["input_ids"], b[2]["input_mask"], b[2]["segment_ids"]))
+        m.train()
+    for t in (t1, t2):
+        t.load_batch(b[1])
+        t.iteration("node")
+    wt = m1.lxrt_encoder.model.bert.embeddings.word_embeddings.weight
+    used = torch.zeros(wt.shape[0], dtype=torch.bool, device=DEV)
+    used[b[1]["input_ids"].view(-1)] = True
+    assert float(wt.grad[~used].abs().max()) == 0.0
+    _same_state(m1, m2)
+
+
 @pytest.mark.parametrize("order", ["vqa", "gqa"])
 def test_captured_replay_equals_eager_passes(order):
     """CapturedTrainer: each pass kind is captured once and replayed; the replays must train the model exactly as the
@@ -425,6 +470,12 @@ def test_prefetching_loader_feeds_the_captured_trainer(tmp_path, handover):
     # replay or a buffer rewritten under a queued copy would show here, and nothing else can (every reduction on the
     # path has a fixed order)
     assert len(losses) == n_img // B and losses == losses2, (losses, losses2)
+    if handover == "inline":
+        # a batch shorter than the captured one fills only the head of its slot: refused, not trained on with a stale tail
+        assert it.rows == B
+        it.rows = B - 1
+        with pytest.raises(ValueError, match="holds %d samples" % (B - 1)):
+            tr.load_packed(it)
     assert losses[-1][0] < losses[0][0], losses  # lr 1e-4: the tiny model learns; the run is not a chaotic one
     torch.cuda.synchronize()
 

@@ -961,6 +961,31 @@ def test_sched_step_multi_matches_reference_schedule(ops):
         ops.sched_step_multi(steps, scale, [(1, 20, 0.1), (1, 20, 0.1)])
 
 
+def test_grid_sum_workspace_is_per_stream(ops):
+    """ops.sum_ws: the ticket workspace of the loss kernels' grid-wide sum belongs to ONE stream (launches of one stream run
+    in order; two overlapping launches on one counter would corrupt it for good) -- another stream gets its own, and both
+    give the right sums when they run side by side."""
+    home = ops.sum_ws(DEV)
+    side = torch.cuda.Stream()
+    gen = torch.Generator().manual_seed(2)
+    s = torch.randn(1152 * 768, generator=gen).to(torch.bfloat16).to(DEV)
+    g = torch.randn(1152 * 768, generator=gen).to(DEV)
+    want = float(((s.double() - g.double()) ** 2).sum() * 0.5)
+    torch.cuda.synchronize()
+    outs = []
+    with torch.cuda.stream(side):
+        assert ops.sum_ws(DEV).data_ptr() != home.data_ptr()
+        for _ in range(50):
+            outs.append(ops.dsm_fwd(s, g, 0.5))
+    for _ in range(50):
+        outs.append(ops.dsm_fwd(s, g, 0.5))
+    torch.cuda.synchronize()
+    assert ops.sum_ws(DEV).data_ptr() == home.data_ptr()
+    for o in outs:
+        assert abs(float(o) - want) < 1e-5 * want
+    assert float(home[0]) == 0.0
+
+
 def test_clip_norm_pair_with_the_pass_tail(ops):
     """xggm_clip_norm_f32: the norm nn.utils.clip_grad_norm_ returns (src/vqa/vqacpv2.py:175) over ranges of the gradient
     buffer (squared) and of the slot table (summed as they are) in one pair of launches, against float64; the finishing

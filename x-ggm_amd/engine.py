@@ -21,6 +21,8 @@ import gc
 
 import torch
 
+from . import ops
+
 from .runtime import runtime_of
 from .vqa.vqacpv2 import (forward_backward_plain, forward_backward_ggm, clip_and_step, _sync_grads,
                           BCEWithLogitsLoss)
@@ -276,6 +278,12 @@ class CapturedTrainer:
             raise RuntimeError("load_packed needs CapturedTrainer(packed_spec=loader.spec)")
         if it.flat is None or it.flat.numel() != self.static_flat.numel():
             raise ValueError("the iterator's slot does not have this trainer's layout (handover='inline', same batch size)")
+        rows = getattr(it, "rows", None)
+        if rows is not None and rows != self.static["feats"].shape[0]:
+            # a short (last) batch fills only the head of the slot: the captured step would train on its rows PLUS the
+            # stale tail of an older batch (the ring path fails on the shape in copy_; this one has to say so itself)
+            raise ValueError("load_packed: the batch holds %d samples, the captured step %d -- iterate the loader with "
+                             "drop_last=True (or run the short batch through an eager pass)" % (rows, self.static["feats"].shape[0]))
         self.static_flat.copy_(it.flat, non_blocking=True)
         it.mark_copied()
 
@@ -283,8 +291,20 @@ class CapturedTrainer:
         if not self.use_graph:
             return self._eager_pass(kind)
         gs = self.graphs[kind]
-        if self.rt.arena.zero1 is not None:
-            self.rt.arena.zero1.reset()  # the runs of this pass are recorded again by its exchanges
+        arena = self.rt.arena
+        # host-side bookkeeping a replay relies on but never runs (the Python of a pass executes at CAPTURE time only):
+        # the sparse exchange of the word table gathers the rows of THIS trainer's ids, looked up once per pass -- an eval
+        # forward or a second trainer's capture in between would otherwise leave another batch's ids or a count != 1 behind
+        self.rt.emb_ids = self.static["input_ids"]
+        arena.emb_uses = 1
+        rl = arena.row_list
+        if rl is not None and not rl.clean and arena.row_list_enabled:
+            # an eager pass in between left rows of the word table's gradient the device-side list does not name (two
+            # look-ups, accumulation): the captured clear only knows the list -- clear the whole table once
+            ops.zero_ranges(arena.grads, [(rl.o, rl.o + rl.R * rl.H)])
+            rl.clean = True
+        if arena.zero1 is not None:
+            arena.zero1.reset()  # the runs of this pass are recorded again by its exchanges
         if len(gs) == 1:
             gs[0].replay()
         elif gs[0] != "staged":

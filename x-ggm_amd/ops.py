@@ -1079,6 +1079,7 @@ def _scalar(out, device):
 
 SUM_WS_FLOATS = 4104  # XGGM_SUM_WS_FLOATS (include/xggm.h)
 _SUM_WS = {}
+_SUM_WS_HOME = {}
 
 
 def sum_ws(device):
@@ -1092,7 +1093,20 @@ def sum_ws(device):
     ws = _SUM_WS.get(device)
     if ws is None:
         ws = _SUM_WS[device] = torch.zeros(SUM_WS_FLOATS, device=device, dtype=F32)
-    return ws
+        _SUM_WS_HOME[device] = torch.cuda.current_stream(device).cuda_stream
+        return ws
+    # launches on ANOTHER stream (an evaluation beside the training stream, tools/exp_two_streams.py) may overlap the
+    # home stream's: two kernels sharing the arrival counter corrupt it for good (no workgroup ever draws the last ticket
+    # again).  Every other stream gets a workspace of its own; a capture keeps the home one (its graph replays where the
+    # trainer runs, and allocating inside a capture would tie the buffer to the graph's pool).
+    sid = torch.cuda.current_stream(device).cuda_stream
+    if sid == _SUM_WS_HOME[device] or torch.cuda.is_current_stream_capturing():
+        return ws
+    key = (device, sid)
+    side = _SUM_WS.get(key)
+    if side is None:
+        side = _SUM_WS[key] = torch.zeros(SUM_WS_FLOATS, device=device, dtype=F32)
+    return side
 
 
 def dsm_fwd(s, g, coef, out=None):

@@ -133,6 +133,7 @@ class _Iter:
         self.err = None
         self.held = None
         self.flat = None
+        self.rows = 0
         self._marked = False
         self.t = threading.Thread(target=self._produce, daemon=True)
         self.t.start()
@@ -219,6 +220,7 @@ class _Iter:
         self.held = slot
         # "inline" hand-over: the slot's flat pinned buffer, for the consumer's own single copy (then ``mark_copied``)
         self.flat = self.L.host_flat[slot] if getattr(self.L, "handover", "ring") == "inline" else None
+        self.rows = len(ids)  # samples of THIS batch (a short last batch fills only the head of the slot)
         self._marked = False
         if "adj" in out:
             return ids, out["feats"], out["boxes"], sent, out["target"], out["adj"]
