@@ -317,6 +317,23 @@ def _sharded_worker(rank, world, port, q):
         a.params[:] = -1.0
         ParamArena.gather_sharded_state(a)  # nothing updated since: no second gather
         ok &= bool((a.params == -1.0).all())
+        # a rank that enters the state gather ALONE (``if rank == 0: save(state_dict())``) gets an error that
+        # says what to do, not a hung group; the next symmetric call works again
+        z.stale = True
+        if rank == 0:
+            os.environ["XGGM_COLLECTIVE_TIMEOUT"] = "1.5"
+            try:
+                z.gather_state()
+                ok = False
+            except RuntimeError as e:
+                ok &= "COLLECTIVE" in str(e) and "1 of %d ranks" % world in str(e)
+            os.environ.pop("XGGM_COLLECTIVE_TIMEOUT")
+            ok &= z.stale is True
+        else:
+            z._calls = getattr(z, "_calls", 0) + 1  # (the call rank 0 made alone)
+        dist.barrier()
+        z.gather_state()
+        ok &= z.stale is False
         z.reset()
         ok &= z.runs == []
         # the plain in-place exchange (no sharding) on the same arena

@@ -545,6 +545,30 @@ class ShardedUpdate(GradSync):
         for ev in self.take_pending():
             torch.cuda.current_stream().wait_event(ev)
 
+    def _rendezvous(self, what, timeout=None):
+        """every rank of the group has reached the same collective call, or RuntimeError after ``timeout`` seconds
+        (XGGM_COLLECTIVE_TIMEOUT, default 120): host side, through the default store, whatever the backend"""
+        import time
+        timeout = float(os.environ.get("XGGM_COLLECTIVE_TIMEOUT", "120")) if timeout is None else float(timeout)
+        try:
+            store = dist.distributed_c10d._get_default_store()
+        except Exception:
+            return  # no store to ask (not the default initialisation): the collective is entered as it always was
+        ranks = dist.get_process_group_ranks(self.group) if self.group is not None else list(range(dist.get_world_size()))
+        self._calls = getattr(self, "_calls", 0) + 1
+        key = "xggm/%s/%s/%d" % (what, "-".join(str(r) for r in ranks), self._calls)
+        n = store.add(key, 1)
+        t0 = time.time()
+        while n < self.world:
+            if time.time() - t0 > timeout:
+                raise RuntimeError(
+                    "sharded update: only %d of %d ranks reached %s (call %d) within %.0f s.  Under the sharded update the "
+                    "fp32 masters and moments are spread over the ranks, so model.state_dict(), BertAdam.state_dict(), "
+                    "save_training_state(), VQA.save() and sync_weights() are COLLECTIVE calls: make them on every rank "
+                    "(and keep rank 0's result), not inside `if rank == 0:`" % (n, self.world, what, self._calls, timeout))
+            time.sleep(0.005)
+            n = store.add(key, 0)
+
     @torch.no_grad()
     def gather_state(self):
         """fp32 masters and BertAdam moments of EVERY matrix range from their owners (before state_dict / a
@@ -552,9 +576,14 @@ class ShardedUpdate(GradSync):
         ``ParamArena.gather_sharded_state``: model.state_dict(), BertAdam.state_dict(), save_training_state, VQA.save
         and sync_shadow all do, so under the sharded update those are collective calls too -- as a sharded framework's
         state_dict is)."""
-        self.stale = False
         if self.world == 1:
+            self.stale = False
             return
+        # ADVICE r3: the usual ``if rank == 0: torch.save(model.state_dict())`` enters this collective on ONE rank and used
+        # to hang the group without a word.  A host-side rendezvous through the process group's store first: every rank
+        # counts itself in under the same (call number) key and waits for the others with a timeout.
+        self._rendezvous("gather_state")
+        self.stale = False
         for run in sorted(self.all_runs):
             a, b = run
             o0, o1 = self.own(run)
