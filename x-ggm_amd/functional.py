@@ -798,7 +798,7 @@ class GCNFn(Function):
         d_adj = None
         for k in reversed(range(len(gcn.gnn_layers))):
             conv = gcn.gnn_layers[k]
-            agg, z, stats = convs[k]
+            agg, z, stats = convs[k]  # (swapped order: ``agg`` holds y = h_k W^T, the product taken first)
             # dh[k+1] is complete here; its residual branch adds into dh[k]
             d_t, _ = ops.ln_bwd(dh[k + 1], z, stats, conv.layer_norm.weight.data,
                                 a.atomic_target(conv.layer_norm.weight), a.atomic_target(conv.layer_norm.bias), None,
